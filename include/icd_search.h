@@ -1,0 +1,162 @@
+/*
+ * icd_search.h — C ABI of libicdsearch.so: exact inner-product (FLAT / IP) top-k search over a dense
+ * fp32 corpus on one MI355X (gfx950), with the ICD level reweight of the reference fused in.
+ *
+ * This is the drop-in boundary for the reference's vector-engine calls. The reference has no FFI of
+ * its own (pure Python); each entry point below names the reference call it
+ * replaces (paths relative to the reference repository root):
+ *
+ *   icd_index_create            <- MilvusClient.create_collection + insert + load_collection
+ *                                  services/milvus_service.py:163-206 (schema, FLAT/IP index),
+ *                                  :208-269 (insert_records), :137-161 (load to memory)
+ *   icd_index_search            <- MilvusClient.search(data=[q], limit=top_k)
+ *                                  services/milvus_service.py:280-285
+ *   icd_index_search_reweighted <- the same call plus the per-hit level weight and stable re-sort
+ *                                  services/milvus_service.py:290-295,314,550-558
+ *   icd_index_stats             <- get_collection_stats / get_memory_usage
+ *                                  services/milvus_service.py:322-341,498-522
+ *   icd_index_destroy           <- release_collection / disconnect
+ *                                  services/milvus_service.py:400-424,452-496
+ *   icd_merge_topk              <- no counterpart (the reference is single-process); merges the
+ *                                  per-shard partial top-k lists of a row-sharded corpus after the
+ *                                  RCCL all-gather.
+ *
+ * Conventions
+ *   - All matrices are dense row-major (exactly numpy's C order): corpus [n][dim], queries [nq][dim],
+ *     outputs [nq][k].
+ *   - Pointers are borrowed for the duration of the call. `*_on_device` says whether a pointer is a
+ *     HIP device pointer (1) or host memory (0). Outputs are caller-allocated.
+ *   - `stream` is a hipStream_t (NULL = the default stream). Calls with device inputs AND device
+ *     outputs only enqueue work (no allocation, no synchronisation: graph-capturable); calls that
+ *     touch host buffers synchronise the stream before returning.
+ *   - Result order: best first by (score descending, row id ascending). Scores are the canonical
+ *     fp32 fmaf chain over d = 0..dim-1, bit-identical to oracle/icd_oracle.c.
+ *     Slots beyond the number of valid hits (n < k, NaN scores) hold id = -1, score = -inf.
+ *   - Row ids are `id_base + row index` (id_base != 0 for a shard of a larger corpus).
+ *   - Every function returns ICD_OK (0) or a negative icd_status; icd_last_error() gives the text.
+ *   - A handle is thread-compatible: one search at a time per handle.
+ */
+#ifndef ICD_SEARCH_H
+#define ICD_SEARCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICD_ABI_VERSION 1
+#define ICD_MAX_K 128
+
+typedef struct icd_index icd_index;
+
+typedef enum icd_status {
+    ICD_OK = 0,
+    ICD_ERR_INVALID = -1,     /* bad argument */
+    ICD_ERR_HIP = -2,         /* a HIP runtime call failed */
+    ICD_ERR_NOMEM = -3,       /* device or host allocation failed */
+    ICD_ERR_UNSUPPORTED = -4, /* shape / device not supported (not gfx950, dim, k) */
+    ICD_ERR_STATE = -5        /* handle destroyed or not initialised */
+} icd_status;
+
+typedef enum icd_mode {
+    ICD_MODE_AUTO = 0,  /* fp16-MFMA coarse pass + exact fp32 rescoring, certified per query;
+                           uncertified queries re-run on the exact kernel. Results identical to EXACT. */
+    ICD_MODE_EXACT = 1  /* fp32-MFMA kernel only */
+} icd_mode;
+
+typedef struct icd_stats {
+    int64_t n;                  /* rows in this index / shard */
+    int32_t dim;
+    int32_t device;
+    int64_t id_base;
+    int64_t bytes_corpus_f32;   /* HBM bytes held */
+    int64_t bytes_corpus_f16;
+    int64_t bytes_workspace;
+    int32_t max_nq;
+    int32_t max_k;
+    int32_t fast_path;          /* 1 if the fp16 coarse path is usable for this index */
+    float   rmax;               /* max row L2 norm */
+    /* counters of the most recent search (valid after the stream is synchronised) */
+    int64_t last_nq;
+    int64_t last_fallback;      /* queries that took the exact fallback in AUTO mode */
+    int32_t last_chunks;        /* corpus chunks (P) used by the coarse kernel */
+    int32_t last_mode;
+} icd_stats;
+
+/* per-kernel device time of the most recent search, measured with hipEvents on the search stream.
+ * Only recorded while profiling is enabled (icd_index_set_profiling). */
+typedef struct icd_profile {
+    float ms_prep;      /* query fp32->fp16 + norms */
+    float ms_coarse;    /* fp16 MFMA + fused top-k' (dominant kernel) */
+    float ms_finalize;  /* merge + certify + exact rescoring + reweight */
+    float ms_exact;     /* fp32 MFMA kernel (EXACT mode, or the AUTO fallback) */
+    float ms_exact_finalize;
+    float ms_total;     /* first event to last event */
+} icd_profile;
+
+int icd_abi_version(void);
+
+/* Text of the most recent error on this thread (never NULL). */
+const char *icd_last_error(void);
+
+/* Number of HIP devices visible, or a negative icd_status. */
+int icd_device_count(void);
+
+/*
+ * Build an index over `n` rows of `dim` floats. `levels` (int32[n], ICD hierarchy level of each row:
+ * 1, 2 or 3) may be NULL (all rows level 1 -> weight 1.2, the reference default level,
+ * services/milvus_service.py:247). The corpus is copied to HBM; the caller's buffer is not retained.
+ * max_nq: largest query batch a single search call will receive (workspace is sized for it).
+ * max_k:  largest k (<= ICD_MAX_K).
+ */
+int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t *levels,
+                     int64_t id_base, int32_t device, int32_t max_nq, int32_t max_k,
+                     int32_t corpus_on_device, icd_index **out);
+
+int icd_index_destroy(icd_index *idx);
+
+/* Raw top-k by inner product. out_scores float[nq][k], out_ids int64[nq][k]. */
+int icd_index_search(icd_index *idx, const float *queries, int64_t nq, int32_t k,
+                     int32_t queries_on_device, int32_t mode,
+                     float *out_scores, int64_t *out_ids, int32_t out_on_device, void *stream);
+
+/*
+ * Raw top-k, then adj = (double)score * w[level] and a stable descending re-sort of the k hits
+ * (the order MilvusService.search returns). All four outputs are [nq][k] in the re-sorted order:
+ * out_adj (double), out_raw (float, the inner product), out_ids, out_levels. Any of out_raw /
+ * out_levels may be NULL.
+ */
+int icd_index_search_reweighted(icd_index *idx, const float *queries, int64_t nq, int32_t k,
+                                int32_t queries_on_device, int32_t mode,
+                                double *out_adj, float *out_raw, int64_t *out_ids, int32_t *out_levels,
+                                int32_t out_on_device, void *stream);
+
+/*
+ * Row-sharded search, step 2: merge `G` best-first lists per query (layout [G][nq][k], as produced by
+ * all-gathering the outputs of icd_index_search on every shard, together with the level of every
+ * hit) into the global top-k, then reweight + stable re-sort as above. Device pointers only;
+ * enqueues on `stream`. `device` selects the GPU.
+ */
+int icd_merge_topk(int32_t device, const float *scores, const int64_t *ids, const int32_t *levels,
+                   int32_t G, int64_t nq, int32_t k,
+                   double *out_adj, float *out_raw, int64_t *out_ids, int32_t *out_levels, void *stream);
+
+/* Level of each hit id (device pointers, [count]); ids < 0 give level 0. Used by the row-sharded
+ * path to attach levels to the raw hits before the all-gather. */
+int icd_index_lookup_levels(icd_index *idx, const int64_t *ids, int64_t count, int32_t *out_levels,
+                            void *stream);
+
+int icd_index_stats(icd_index *idx, icd_stats *out);
+
+/* Tuning knobs (0 = automatic): number of corpus chunks P per query tile for the coarse kernel. */
+int icd_index_set_chunks(icd_index *idx, int32_t chunks);
+
+int icd_index_set_profiling(icd_index *idx, int32_t enabled);
+/* Synchronises the events of the most recent search and fills `out`. */
+int icd_index_last_profile(icd_index *idx, icd_profile *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICD_SEARCH_H */

@@ -1,0 +1,196 @@
+// exact_kernel.hpp — exact FLAT / IP scoring on the fp32-input MFMA with a fused per-query top-KP.
+//
+// Replaces the engine behind MilvusClient.search on the FLAT/IP index
+// (services/milvus_service.py:33-34,189-194,280-285). v_mfma_f32_32x32x2_f32 is bit-for-bit the
+// k-ordered fmaf chain, and k = 2s + (lane>>5) is mapped to d ascending, so every score equals
+// oracle/icd_oracle.c's chain_score() bit for bit.
+//
+// Work-group = NW waves; tile = NW*32 queries x 128 corpus rows; stages of 32 floats of K,
+// register-staged double buffering, LDS rows padded to 33 floats (conflict-free ds_read_b32).
+#pragma once
+#include "topk_select.hpp"
+
+namespace icd {
+
+struct ExactArgs {
+    const float *corpus;   // [n][dim]
+    const float *queries;  // [*][dim]
+    const int *qlist;      // nullable: slot -> query index
+    const int *nq_ptr;     // nullable: device-side query count (fallback list length)
+    int nq;                // query slots (upper bound when nq_ptr is given)
+    int n;                 // rows
+    int dim;               // multiple of 32
+    int P;                 // corpus chunks
+    int rows_per_chunk;    // multiple of 128
+    float *part_scores;    // [slot][P][KP]
+    int *part_rows;        // [slot][P][KP]
+};
+
+template <int KP, int E, int NW>
+__global__ __launch_bounds__(NW * 64) void exact_topk_kernel(ExactArgs a) {
+    constexpr int BMQ = NW * 32, BN = 128, BK = 32, LDT = 33, NT = NW * 64;
+    constexpr int CAP = 64 * E, LIMIT = CAP - 32;
+    constexpr int CL = (BN * 8) / NT;  // corpus float4 loads per thread per stage
+    constexpr int QL = (BMQ * 8) / NT; // = 4
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *Qs = reinterpret_cast<float *>(smem);
+    float *Cs = Qs + 2 * BMQ * LDT;
+    u64 *bufs = reinterpret_cast<u64 *>(smem + (((size_t)(2 * BMQ * LDT + 2 * BN * LDT) * 4 + 15) & ~(size_t)15));
+
+    const int nq = a.nq_ptr ? min(*a.nq_ptr, a.nq) : a.nq;
+    const int mtile = blockIdx.x / a.P, chunk = blockIdx.x % a.P;
+    const int slot0 = mtile * BMQ;
+    if (slot0 >= nq) return;
+    const int row_begin = chunk * a.rows_per_chunk;
+    const int row_end = min(a.n, row_begin + a.rows_per_chunk);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dim = a.dim, nks = dim / BK;
+
+    // query source rows for this thread's staging loads
+    const float *qsrc[QL];
+    int qdst[QL];
+#pragma unroll
+    for (int i = 0; i < QL; ++i) {
+        const int idx = tid + NT * i, qr = idx >> 3, c4 = idx & 7;
+        int s = min(slot0 + qr, nq - 1);
+        const int gq = a.qlist ? a.qlist[s] : s;
+        qsrc[i] = a.queries + (size_t)gq * dim + c4 * 4;
+        qdst[i] = qr * LDT + c4 * 4;
+    }
+    int cdst[CL], crow_off[CL], ccol[CL];
+#pragma unroll
+    for (int i = 0; i < CL; ++i) {
+        const int idx = tid + NT * i;
+        crow_off[i] = idx >> 3;
+        ccol[i] = (idx & 7) * 4;
+        cdst[i] = crow_off[i] * LDT + ccol[i];
+    }
+
+    SelState st;
+    const int my_slot = slot0 + wave * 32 + (lane & 31);
+    const bool my_valid = my_slot < nq;
+    st.thr = my_valid ? -INFINITY : INFINITY;
+    st.thr_row = 0u;
+    st.cnt = 0;
+    u64 *wbuf = bufs + (size_t)(wave * 32) * CAP;
+    u64 *qbuf = wbuf + (size_t)(lane & 31) * CAP;
+
+    const int h = lane >> 5, c = lane & 31;
+
+    for (int tile_row0 = row_begin; tile_row0 < row_end; tile_row0 += BN) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+        const float *csrc[CL];
+#pragma unroll
+        for (int i = 0; i < CL; ++i) {
+            const int row = min(tile_row0 + crow_off[i], a.n - 1);
+            csrc[i] = a.corpus + (size_t)row * dim + ccol[i];
+        }
+        float4 qreg[QL], creg[CL];
+#pragma unroll
+        for (int i = 0; i < QL; ++i) qreg[i] = *reinterpret_cast<const float4 *>(qsrc[i]);
+#pragma unroll
+        for (int i = 0; i < CL; ++i) creg[i] = *reinterpret_cast<const float4 *>(csrc[i]);
+        __syncthreads();  // previous tile's readers are done with buffer 0
+#pragma unroll
+        for (int i = 0; i < QL; ++i) {
+            float *d = Qs + qdst[i];
+            d[0] = qreg[i].x; d[1] = qreg[i].y; d[2] = qreg[i].z; d[3] = qreg[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < CL; ++i) {
+            float *d = Cs + cdst[i];
+            d[0] = creg[i].x; d[1] = creg[i].y; d[2] = creg[i].z; d[3] = creg[i].w;
+        }
+        __syncthreads();
+
+        for (int ks = 0; ks < nks; ++ks) {
+            const int cur = ks & 1;
+            const bool more = ks + 1 < nks;
+            if (more) {
+                const int k0 = (ks + 1) * BK;
+#pragma unroll
+                for (int i = 0; i < QL; ++i) qreg[i] = *reinterpret_cast<const float4 *>(qsrc[i] + k0);
+#pragma unroll
+                for (int i = 0; i < CL; ++i) creg[i] = *reinterpret_cast<const float4 *>(csrc[i] + k0);
+            }
+            const float *qrow = Qs + cur * BMQ * LDT + (wave * 32 + c) * LDT + h;
+            const float *crow = Cs + cur * BN * LDT + c * LDT + h;
+#pragma unroll
+            for (int s = 0; s < BK / 2; ++s) {
+                const float b = qrow[2 * s];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float av = crow[t * 32 * LDT + 2 * s];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[t], 0, 0, 0);
+                }
+            }
+            if (more) {
+                float *qd = Qs + (cur ^ 1) * BMQ * LDT;
+                float *cd = Cs + (cur ^ 1) * BN * LDT;
+#pragma unroll
+                for (int i = 0; i < QL; ++i) {
+                    float *d = qd + qdst[i];
+                    d[0] = qreg[i].x; d[1] = qreg[i].y; d[2] = qreg[i].z; d[3] = qreg[i].w;
+                }
+#pragma unroll
+                for (int i = 0; i < CL; ++i) {
+                    float *d = cd + cdst[i];
+                    d[0] = creg[i].x; d[1] = creg[i].y; d[2] = creg[i].z; d[3] = creg[i].w;
+                }
+            }
+            __syncthreads();
+        }
+
+        // fused select
+        const bool partial = tile_row0 + BN > row_end;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t row0 = (uint32_t)(tile_row0 + t * 32);
+            if (partial) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (int)row0 + 4 * h + (r & 3) + 8 * (r >> 2);
+                    if (row >= row_end) acc[t][r] = __builtin_nanf("");
+                }
+            }
+            filter16<true>(acc[t], row0, st, qbuf, lane);
+            if (__any(st.cnt > LIMIT)) compact_wave<KP, E>(wbuf, st, lane, false);
+        }
+    }
+
+    // final: sorted top-KP of every query of this wave -> partial list
+    compact_wave<KP, E>(wbuf, st, lane, true);
+    for (int b = 0; b < 32; ++b) {
+        const int slot = slot0 + wave * 32 + b;
+        if (slot >= nq) break;
+        const int nb = min(readlane<int>(st.cnt, b), KP);
+        const u64 *qb = wbuf + (size_t)b * CAP;
+        const size_t o = ((size_t)slot * a.P + chunk) * KP;
+        for (int j = lane; j < KP; j += 64) {
+            float s = -INFINITY;
+            int row = -1;
+            if (j < nb) {
+                const u64 k = qb[j];
+                s = key_score(k);
+                row = (int)key_row(k);
+            }
+            a.part_scores[o + j] = s;
+            a.part_rows[o + j] = row;
+        }
+    }
+}
+
+template <int KP, int E, int NW>
+inline size_t exact_lds_bytes() {
+    constexpr int BMQ = NW * 32, BN = 128, LDT = 33;
+    size_t stage = (((size_t)(2 * BMQ * LDT + 2 * BN * LDT) * 4 + 15) & ~(size_t)15);
+    return stage + (size_t)BMQ * 64 * E * 8;
+}
+
+}  // namespace icd

@@ -1,0 +1,347 @@
+// finalize.hpp — one wave per query: merge the per-chunk partial lists, (fast path) certify and
+// rescore with the canonical fp32 chain, select the top-k by (score desc, row asc), then apply the
+// ICD level reweight and the stable re-sort.
+//
+// Reference call sites restated here:
+//   services/milvus_service.py:280-285  (top_k hits, best first)
+//   services/milvus_service.py:290-295  adjusted = float(base_score * level_weight)  [Python double]
+//   services/milvus_service.py:550-558  level weights {1:1.2, 2:1.0, 3:0.8}, default 1.0
+//   services/milvus_service.py:314      stable sort by adjusted score, descending
+#pragma once
+#include "topk_select.hpp"
+
+namespace icd {
+
+constexpr int FIN_MAX_CAND = 512;  // P * KP
+constexpr int FIN_MAX_K = 128;
+constexpr int FIN_EF = FIN_MAX_CAND / 64;
+
+struct FinArgs {
+    const float *part_scores;  // [slot][P][KP]
+    const int *part_rows;
+    int P, KP;
+    int nq;             // slots (upper bound if nq_ptr)
+    const int *nq_ptr;  // nullable
+    const int *qlist;   // nullable: slot -> query index
+    int k;
+    // fast path only
+    const float *queries;  // fp32 [*][dim]
+    const float *corpus;   // fp32 [n][dim]
+    int dim;
+    const float *qnorm;          // [query]
+    const unsigned char *qbad;   // [query] 1 = fp16 image unusable
+    float rmax, eps_rel;
+    int *nflag;    // fallback counter
+    int *flagged;  // fallback list
+    // level table
+    const int *levels;  // [n] or null
+    long long id_base;
+    // outputs, any may be null
+    float *out_scores;      // raw order [query][k]
+    long long *out_ids;
+    double *out_adj;        // re-sorted order [query][k]
+    float *out_adj_raw;
+    long long *out_adj_ids;
+    int *out_adj_levels;
+};
+
+__device__ __forceinline__ double level_weight(int level) {
+    return level == 1 ? 1.2 : (level == 3 ? 0.8 : 1.0);
+}
+
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+// Writes the final raw + re-sorted outputs for one query from sorted[0..nres) (best first).
+__device__ __forceinline__ void emit_outputs(const FinArgs &a, int qidx, const u64 *sorted, int nres,
+                                             double *adjbuf, int lane) {
+    const int k = a.k;
+    const size_t o = (size_t)qidx * k;
+    float sc[2];
+    int row[2], lvl[2];
+    double adj[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int j = lane + 64 * e;
+        sc[e] = -INFINITY; row[e] = -1; lvl[e] = 0; adj[e] = -INFINITY;
+        if (j < nres) {
+            const u64 key = sorted[j];
+            sc[e] = key_score(key);
+            row[e] = (int)key_row(key);
+            lvl[e] = a.levels ? a.levels[row[e]] : 1;
+            adj[e] = (double)sc[e] * level_weight(lvl[e]);
+            adjbuf[j] = adj[e];
+        }
+        if (j < k) {
+            if (a.out_scores) a.out_scores[o + j] = sc[e];
+            if (a.out_ids) a.out_ids[o + j] = row[e] >= 0 ? a.id_base + row[e] : -1ll;
+        }
+    }
+    if (!a.out_adj && !a.out_adj_ids && !a.out_adj_raw && !a.out_adj_levels) return;
+    // stable descending rank of adj among the nres hits
+    int pos[2] = {0, 0};
+    for (int i = 0; i < nres; ++i) {
+        const double ai = adjbuf[i];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int j = lane + 64 * e;
+            pos[e] += (ai > adj[e] || (ai == adj[e] && i < j)) ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int j = lane + 64 * e;
+        if (j < nres) {
+            const size_t w = o + pos[e];
+            if (a.out_adj) a.out_adj[w] = adj[e];
+            if (a.out_adj_raw) a.out_adj_raw[w] = sc[e];
+            if (a.out_adj_ids) a.out_adj_ids[w] = a.id_base + row[e];
+            if (a.out_adj_levels) a.out_adj_levels[w] = lvl[e];
+        } else if (j < k) {
+            const size_t w = o + j;
+            if (a.out_adj) a.out_adj[w] = -INFINITY;
+            if (a.out_adj_raw) a.out_adj_raw[w] = -INFINITY;
+            if (a.out_adj_ids) a.out_adj_ids[w] = -1ll;
+            if (a.out_adj_levels) a.out_adj_levels[w] = 0;
+        }
+    }
+}
+
+// LDS per wave: keys[512] u64 | sorted[128] u64 | adjbuf[128] double | qvec[dim] float (RESCORE)
+__host__ __device__ inline size_t fin_wave_lds_bytes(bool rescore, int dim) {
+    return (size_t)FIN_MAX_CAND * 8 + FIN_MAX_K * 8 + FIN_MAX_K * 8 + (rescore ? (size_t)dim * 4 : 0);
+}
+
+template <bool RESCORE>
+__global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nq = a.nq_ptr ? min(*a.nq_ptr, a.nq) : a.nq;
+    const int slot = blockIdx.x * 4 + wave;
+    if (slot >= nq) return;  // wave-uniform; no work-group barriers below
+    const int qidx = a.qlist ? a.qlist[slot] : slot;
+
+    char *wbase = smem + (size_t)wave * fin_wave_lds_bytes(RESCORE, a.dim);
+    u64 *keys = reinterpret_cast<u64 *>(wbase);
+    u64 *sorted = keys + FIN_MAX_CAND;
+    double *adjbuf = reinterpret_cast<double *>(sorted + FIN_MAX_K);
+    float *qvec = reinterpret_cast<float *>(adjbuf + FIN_MAX_K);
+
+    const int ncand = a.P * a.KP;
+    const int k = a.k;
+    const size_t pbase = (size_t)slot * ncand;
+
+    // 1. load candidates, stage keys
+    u64 key[FIN_EF];
+    int nvalid = 0;
+#pragma unroll
+    for (int e = 0; e < FIN_EF; ++e) {
+        const int i = lane + 64 * e;
+        key[e] = 0ull;
+        if (i < ncand) {
+            const int row = a.part_rows[pbase + i];
+            if (row >= 0) key[e] = make_key(a.part_scores[pbase + i], (uint32_t)row);
+            keys[i] = key[e];
+        }
+        nvalid += __popcll(__ballot(key[e] != 0ull));
+    }
+    // 2. rank all candidates; keep the best T sorted
+    const int T = RESCORE ? 64 : k;
+    int rank[FIN_EF];
+#pragma unroll
+    for (int e = 0; e < FIN_EF; ++e) rank[e] = 0;
+    const int ef = (ncand + 63) >> 6;
+    for (int j = 0; j < ncand; ++j) {
+        const u64 kj = keys[j];
+#pragma unroll
+        for (int e = 0; e < FIN_EF; ++e)
+            if (e < ef) rank[e] += (kj > key[e]) ? 1 : 0;
+    }
+    float tau = -INFINITY;  // largest coarse score that may have been dropped anywhere
+    if (RESCORE) {
+        // chunk lists that are full may have dropped rows scoring up to their last entry
+        if (lane < a.P) {
+            const u64 last = keys[lane * a.KP + a.KP - 1];
+            if (last != 0ull) tau = key_score(last);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < FIN_EF; ++e) {
+        if (key[e] != 0ull) {
+            if (rank[e] < T) sorted[rank[e]] = key[e];
+            else if (RESCORE && rank[e] == T) tau = fmaxf(tau, key_score(key[e]));
+        }
+    }
+    int nres = min(nvalid, T);
+
+    if (RESCORE) {
+        tau = wave_max_f32(tau);
+        // 3. certification window
+        const u64 mine = (lane < nres) ? sorted[lane] : 0ull;  // lane == coarse rank
+        const float coarse = (lane < nres) ? key_score(mine) : -INFINITY;
+        const float eps = a.eps_rel * a.qnorm[qidx] * a.rmax;
+        bool certified;
+        float L;
+        if (nres >= k) {
+            const float sk = key_score(sorted[k - 1]);
+            L = sk - 2.0f * eps;
+            L = L - fabsf(L) * 1.2e-7f;  // one ulp down: the subtraction itself rounds
+            certified = tau < L;
+        } else {
+            L = -INFINITY;
+            certified = (tau == -INFINITY);
+        }
+        if (a.qbad[qidx]) certified = false;
+        if (!certified) {
+            if (lane == 0) {
+                const int i = atomicAdd(a.nflag, 1);
+                a.flagged[i] = qidx;
+            }
+            return;
+        }
+        const bool inwin = (lane < nres) && (coarse >= L);
+        // 4. canonical rescoring of the window (scalar fmaf chain, d ascending)
+        const float *qsrc = a.queries + (size_t)qidx * a.dim;
+        for (int d = lane * 4; d < a.dim; d += 256)
+            *reinterpret_cast<float4 *>(qvec + d) = *reinterpret_cast<const float4 *>(qsrc + d);
+        u64 xkey = 0ull;
+        if (inwin) {
+            const uint32_t row = key_row(mine);
+            const float4 *c4 = reinterpret_cast<const float4 *>(a.corpus + (size_t)row * a.dim);
+            const float4 *q4 = reinterpret_cast<const float4 *>(qvec);
+            float acc = 0.0f;
+            const int n4 = a.dim >> 2;
+#pragma unroll 8
+            for (int i = 0; i < n4; ++i) {
+                const float4 cv = c4[i];
+                const float4 qv = q4[i];
+                acc = __builtin_fmaf(qv.x, cv.x, acc);
+                acc = __builtin_fmaf(qv.y, cv.y, acc);
+                acc = __builtin_fmaf(qv.z, cv.z, acc);
+                acc = __builtin_fmaf(qv.w, cv.w, acc);
+            }
+            if (acc == acc && acc != -INFINITY) xkey = make_key(acc, row);
+        }
+        // 5. rank the rescored candidates (one per lane) and keep the best k
+        keys[lane] = xkey;
+        int xr = 0;
+        for (int j = 0; j < 64; ++j) xr += (keys[j] > xkey) ? 1 : 0;
+        const int nx = __popcll(__ballot(xkey != 0ull));
+        if (xkey != 0ull && xr < k) sorted[xr] = xkey;
+        nres = min(nx, k);
+    }
+    // 6-7. outputs (raw order + level reweight / stable re-sort)
+    emit_outputs(a, qidx, sorted, nres, adjbuf, lane);
+}
+
+// ---- row-sharded merge: G gathered best-first lists per query -> global top-k + reweight ---------
+struct MergeArgs {
+    const float *scores;     // [G][nq][k]
+    const long long *ids;    // global ids
+    const int *levels;       // level of every hit
+    int G, nq, k;
+    double *out_adj;
+    float *out_raw;
+    long long *out_ids;
+    int *out_levels;
+};
+
+// One wave per query; G*k <= 1024 candidates handled with 16 per lane.
+__global__ __launch_bounds__(256) void merge_topk_kernel(MergeArgs a) {
+    constexpr int EM = 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wave;
+    if (q >= a.nq) return;
+    // per wave: sc[1024] f32 | id[1024] i64 | lv[1024] i32 | sel (k<=128): adj f64, raw f32, id i64, lvl i32
+    char *wb = smem + (size_t)wave * (1024 * 16 + 128 * 24);
+    float *csc = reinterpret_cast<float *>(wb);
+    long long *cid = reinterpret_cast<long long *>(wb + 4096);
+    int *clv = reinterpret_cast<int *>(wb + 4096 + 8192);
+    double *sadj = reinterpret_cast<double *>(wb + 16384);
+    float *sraw = reinterpret_cast<float *>(wb + 16384 + 1024);
+    long long *sid = reinterpret_cast<long long *>(wb + 16384 + 1024 + 512);
+    int *slv = reinterpret_cast<int *>(wb + 16384 + 1024 + 512 + 1024);
+    const int k = a.k, ncand = a.G * k;
+    float sc[EM];
+    long long id[EM];
+    int nvalid = 0;
+#pragma unroll
+    for (int e = 0; e < EM; ++e) {
+        const int i = lane + 64 * e;
+        sc[e] = -INFINITY;
+        id[e] = -1;
+        if (i < ncand) {
+            const int g = i / k, j = i - g * k;
+            const size_t src = ((size_t)g * a.nq + q) * k + j;
+            const long long v = a.ids[src];
+            const float s = a.scores[src];
+            if (v >= 0 && s == s) {
+                sc[e] = s;
+                id[e] = v;
+                clv[i] = a.levels[src];
+            }
+            csc[i] = sc[e];
+            cid[i] = id[e];
+        }
+        nvalid += __popcll(__ballot(id[e] >= 0));
+    }
+    int rank[EM];
+#pragma unroll
+    for (int e = 0; e < EM; ++e) rank[e] = 0;
+    const int ef = (ncand + 63) >> 6;
+    for (int j = 0; j < ncand; ++j) {
+        const float sj = csc[j];
+        const long long ij = cid[j];
+        if (ij < 0) continue;
+#pragma unroll
+        for (int e = 0; e < EM; ++e)
+            if (e < ef) rank[e] += (sj > sc[e] || (sj == sc[e] && ij < id[e])) ? 1 : 0;
+    }
+    const int nres = min(nvalid, k);
+#pragma unroll
+    for (int e = 0; e < EM; ++e) {
+        const int i = lane + 64 * e;
+        if (i < ncand && id[e] >= 0 && rank[e] < k) {
+            const int lv = clv[i];
+            sraw[rank[e]] = sc[e];
+            sid[rank[e]] = id[e];
+            slv[rank[e]] = lv;
+            sadj[rank[e]] = (double)sc[e] * level_weight(lv);
+        }
+    }
+    // stable re-sort by adjusted score
+    const size_t o = (size_t)q * k;
+    for (int j = lane; j < k; j += 64) {
+        if (j < nres) {
+            const double aj = sadj[j];
+            int pos = 0;
+            for (int i = 0; i < nres; ++i) {
+                const double ai = sadj[i];
+                pos += (ai > aj || (ai == aj && i < j)) ? 1 : 0;
+            }
+            if (a.out_adj) a.out_adj[o + pos] = aj;
+            if (a.out_raw) a.out_raw[o + pos] = sraw[j];
+            if (a.out_ids) a.out_ids[o + pos] = sid[j];
+            if (a.out_levels) a.out_levels[o + pos] = slv[j];
+        } else {
+            if (a.out_adj) a.out_adj[o + j] = -INFINITY;
+            if (a.out_raw) a.out_raw[o + j] = -INFINITY;
+            if (a.out_ids) a.out_ids[o + j] = -1ll;
+            if (a.out_levels) a.out_levels[o + j] = 0;
+        }
+    }
+}
+
+__global__ void lookup_levels_kernel(const long long *ids, long long count, const int *levels,
+                                     long long id_base, long long n, int *out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const long long r = ids[i] - id_base;
+    out[i] = (ids[i] >= 0 && r >= 0 && r < n) ? (levels ? levels[r] : 1) : 0;
+}
+
+}  // namespace icd

@@ -1,0 +1,552 @@
+// icd_search.hip — host side of libicdsearch.so (C ABI declared in include/icd_search.h).
+// gfx950 (MI355X) only. No allocation and no synchronisation inside a search whose inputs and
+// outputs are device buffers.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/icd_search.h"
+#include "coarse_kernel.hpp"
+#include "exact_kernel.hpp"
+#include "finalize.hpp"
+
+using namespace icd;
+
+namespace {
+
+thread_local std::string g_err = "";
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? ICD_ERR_NOMEM : ICD_ERR_HIP, "%s: %s (%s:%d)", \
+                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);                         \
+    } while (0)
+
+constexpr float EPS_REL = 1.2e-3f;
+constexpr int FAST_MAX_K = 12;       // coarse lists hold KP = 16 candidates per chunk
+constexpr int COARSE_MAX_P = 32;     // P * KP <= FIN_MAX_CAND
+constexpr int NUM_EV = 6;
+
+template <typename T>
+hipError_t dmalloc(T **p, size_t count) {
+    return hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(count, 1) * sizeof(T));
+}
+
+}  // namespace
+
+struct icd_index {
+    uint32_t magic = 0x1CD10A3Du;
+    int device = 0;
+    int64_t n = 0, id_base = 0;
+    int n_pad = 0;
+    int dim = 0;
+    int max_nq = 0, max_nq_pad = 0, max_k = 0;
+    bool fast = false;
+    float rmax = 0.f;
+    int num_cu = 256;
+    // corpus
+    float *corpus = nullptr;
+    _Float16 *c16 = nullptr;
+    int *levels = nullptr;
+    // workspace
+    float *qdev = nullptr;  // staging for host queries
+    _Float16 *q16 = nullptr;
+    float *qnorm = nullptr;
+    unsigned char *qbad = nullptr;
+    float *partc_s = nullptr; int *partc_r = nullptr; size_t partc_cap = 0;
+    float *partx_s = nullptr; int *partx_r = nullptr; size_t partx_cap = 0;
+    int *nflag = nullptr; int *flagged = nullptr;
+    unsigned int *scratch_u32 = nullptr;  // [0]=rmax bits, [1]=any_bad
+    // output staging (used when the caller's buffers are host memory)
+    float *o_scores = nullptr; long long *o_ids = nullptr;
+    double *o_adj = nullptr; float *o_adj_raw = nullptr; long long *o_adj_ids = nullptr; int *o_adj_lv = nullptr;
+    size_t bytes_ws = 0;
+    // knobs / counters
+    int chunks_override = 0;
+    bool profiling = false;
+    hipEvent_t ev[NUM_EV + 1] = {};
+    bool ev_valid[NUM_EV + 1] = {};
+    int64_t last_nq = 0;
+    int last_chunks = 0, last_mode = 0;
+    int *h_nflag = nullptr;  // pinned
+};
+
+namespace {
+
+bool valid(icd_index *idx) { return idx && idx->magic == 0x1CD10A3Du; }
+
+void free_all(icd_index *x) {
+    if (!x) return;
+    hipFree(x->corpus); hipFree(x->c16); hipFree(x->levels); hipFree(x->qdev); hipFree(x->q16);
+    hipFree(x->qnorm); hipFree(x->qbad); hipFree(x->partc_s); hipFree(x->partc_r); hipFree(x->partx_s);
+    hipFree(x->partx_r); hipFree(x->nflag); hipFree(x->flagged); hipFree(x->scratch_u32);
+    hipFree(x->o_scores); hipFree(x->o_ids); hipFree(x->o_adj); hipFree(x->o_adj_raw);
+    hipFree(x->o_adj_ids); hipFree(x->o_adj_lv);
+    if (x->h_nflag) hipHostFree(x->h_nflag);
+    for (int i = 0; i <= NUM_EV; ++i)
+        if (x->ev[i]) hipEventDestroy(x->ev[i]);
+    x->magic = 0;
+    delete x;
+}
+
+int exact_kp_for(int k) { return k <= 16 ? 16 : (k <= 64 ? 64 : 128); }
+
+// chunk count heuristic: enough work-groups to fill the chip, few enough lists to merge
+int pick_chunks(int mtiles, int row_tiles, int pmax, int target_wgs) {
+    int p = 1;
+    if (mtiles < target_wgs) {
+        p = std::max(1, target_wgs / mtiles);
+    } else {
+        // big batches: smallest p whose last round is at least 90 % full
+        double best = 0;
+        int bestp = 1;
+        for (int c = 1; c <= std::min(pmax, 4); ++c) {
+            const long items = (long)mtiles * c;
+            const double util = (double)items / (double)(((items + target_wgs - 1) / target_wgs) * target_wgs);
+            if (util > best + 1e-9) { best = util; bestp = c; }
+            if (util >= 0.9) { bestp = c; break; }
+        }
+        p = bestp;
+    }
+    p = std::min(p, pmax);
+    p = std::min(p, std::max(1, row_tiles));
+    return std::max(1, p);
+}
+
+template <int KP, int E, int NW>
+int launch_exact(icd_index *x, const ExactArgs &a, int mtiles, hipStream_t s) {
+    auto kern = exact_topk_kernel<KP, E, NW>;
+    const size_t lds = exact_lds_bytes<KP, E, NW>();
+    static thread_local int configured_dev = -1;
+    if (configured_dev != x->device) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured_dev = x->device;
+    }
+    hipLaunchKernelGGL(kern, dim3(mtiles * a.P), dim3(NW * 64), lds, s, a);
+    HIP_TRY(hipGetLastError());
+    return ICD_OK;
+}
+
+template <int D>
+int launch_coarse(icd_index *x, const CoarseArgs &a, int mtiles, hipStream_t s) {
+    auto kern = coarse_topk_kernel<D>;
+    static thread_local int configured_dev = -1;
+    if (configured_dev != x->device) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CO_LDS_BYTES));
+        configured_dev = x->device;
+    }
+    hipLaunchKernelGGL(kern, dim3(mtiles * a.P), dim3(256), CO_LDS_BYTES, s, a);
+    HIP_TRY(hipGetLastError());
+    return ICD_OK;
+}
+
+template <bool RESCORE>
+int launch_finalize(icd_index *x, const FinArgs &a, hipStream_t s) {
+    auto kern = finalize_kernel<RESCORE>;
+    const size_t lds = 4 * fin_wave_lds_bytes(RESCORE, x->dim);
+    static thread_local int configured_dev = -1;
+    if (configured_dev != x->device) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured_dev = x->device;
+    }
+    hipLaunchKernelGGL(kern, dim3((a.nq + 3) / 4), dim3(256), lds, s, a);
+    HIP_TRY(hipGetLastError());
+    return ICD_OK;
+}
+
+void rec(icd_index *x, int i, hipStream_t s) {
+    if (x->profiling) {
+        hipEventRecord(x->ev[i], s);
+        x->ev_valid[i] = true;
+    }
+}
+
+struct Outs {
+    float *scores; long long *ids;
+    double *adj; float *adj_raw; long long *adj_ids; int *adj_lv;
+};
+
+// Enqueue a search whose queries and outputs are device pointers.
+int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const Outs &o, hipStream_t s) {
+    const int row_tiles = (int)((x->n + 127) / 128);
+    const bool use_fast = (mode == ICD_MODE_AUTO) && x->fast && k <= FAST_MAX_K && (x->dim == 768 || x->dim == 1024);
+    for (int i = 0; i <= NUM_EV; ++i) x->ev_valid[i] = false;
+    x->last_nq = nq;
+    x->last_mode = use_fast ? ICD_MODE_AUTO : ICD_MODE_EXACT;
+    rec(x, 0, s);
+
+    FinArgs f{};
+    f.k = k; f.queries = dq; f.corpus = x->corpus; f.dim = x->dim; f.qnorm = x->qnorm; f.qbad = x->qbad;
+    f.rmax = x->rmax; f.eps_rel = EPS_REL; f.nflag = x->nflag; f.flagged = x->flagged;
+    f.levels = x->levels; f.id_base = x->id_base;
+    f.out_scores = o.scores; f.out_ids = o.ids; f.out_adj = o.adj; f.out_adj_raw = o.adj_raw;
+    f.out_adj_ids = o.adj_ids; f.out_adj_levels = o.adj_lv;
+
+    // exact-kernel configuration (full run, or fallback over the flagged list)
+    const int kpx = exact_kp_for(k);
+    const int nwx = kpx == 16 ? 4 : (kpx == 64 ? 2 : 1);
+    const int ex = kpx == 16 ? 1 : (kpx == 64 ? 2 : 3);
+    const int bmq = nwx * 32;
+    const int mtx = (nq + bmq - 1) / bmq;
+    const int pmax_x = std::min(16, FIN_MAX_CAND / kpx);
+    auto run_exact = [&](const int *qlist, const int *nq_ptr, int px) -> int {
+        ExactArgs a{};
+        a.corpus = x->corpus; a.queries = dq; a.qlist = qlist; a.nq_ptr = nq_ptr; a.nq = nq;
+        a.n = (int)x->n; a.dim = x->dim; a.P = px;
+        a.rows_per_chunk = ((row_tiles + px - 1) / px) * 128;
+        a.part_scores = x->partx_s; a.part_rows = x->partx_r;
+        int rc;
+        if (kpx == 16) rc = launch_exact<16, 1, 4>(x, a, mtx, s);
+        else if (kpx == 64) rc = launch_exact<64, 2, 2>(x, a, mtx, s);
+        else rc = launch_exact<128, 3, 1>(x, a, mtx, s);
+        if (rc) return rc;
+        rec(x, 4, s);
+        FinArgs g = f;
+        g.part_scores = x->partx_s; g.part_rows = x->partx_r; g.P = px; g.KP = kpx;
+        g.nq = nq; g.nq_ptr = nq_ptr; g.qlist = qlist;
+        rc = launch_finalize<false>(x, g, s);
+        rec(x, 5, s);
+        (void)ex;
+        return rc;
+    };
+    auto fit_p = [&](int p, size_t cap, int kp) {
+        while (p > 1 && (size_t)nq * p * kp > cap) --p;
+        return p;
+    };
+
+    if (!use_fast) {
+        int px = pick_chunks(mtx, row_tiles, pmax_x, 2 * x->num_cu);
+        px = fit_p(px, x->partx_cap, kpx);
+        if ((size_t)nq * px * kpx > x->partx_cap) return fail(ICD_ERR_INVALID, "workspace too small for nq=%d k=%d", nq, k);
+        {
+            const int tiles_per = (row_tiles + px - 1) / px;
+            px = (row_tiles + tiles_per - 1) / tiles_per;
+        }
+        x->last_chunks = px;
+        rec(x, 3, s);
+        return run_exact(nullptr, nullptr, px);
+    }
+
+    // ---- AUTO: prep -> coarse -> finalize(certify + rescore) -> exact fallback ------------------
+    const int nq_pad = ((nq + 127) / 128) * 128;
+    ConvertArgs cv{};
+    cv.src = dq; cv.dst = x->q16; cv.rows = nq; cv.rows_pad = nq_pad; cv.dim = x->dim;
+    cv.norm = x->qnorm; cv.bad = x->qbad;
+    hipLaunchKernelGGL(convert_rows_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, s, cv);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(x->nflag, 0, sizeof(int), s));
+    rec(x, 1, s);
+
+    const int mtc = nq_pad / 128;
+    const int ctiles = x->n_pad / 128;
+    int pc = x->chunks_override > 0 ? x->chunks_override : pick_chunks(mtc, ctiles, COARSE_MAX_P, x->num_cu);
+    pc = std::min(pc, std::min(COARSE_MAX_P, ctiles));
+    pc = fit_p(pc, x->partc_cap, CO_KP);
+    {
+        const int tiles_per = (ctiles + pc - 1) / pc;
+        pc = (ctiles + tiles_per - 1) / tiles_per;
+        CoarseArgs a{};
+        a.q16 = x->q16; a.c16 = x->c16; a.nq = nq; a.n = (int)x->n; a.n_pad = x->n_pad; a.P = pc;
+        a.rows_per_chunk = tiles_per * 128;
+        a.part_scores = x->partc_s; a.part_rows = x->partc_r;
+        x->last_chunks = pc;
+        int rc = x->dim == 768 ? launch_coarse<768>(x, a, mtc, s) : launch_coarse<1024>(x, a, mtc, s);
+        if (rc) return rc;
+    }
+    rec(x, 2, s);
+    {
+        FinArgs g = f;
+        g.part_scores = x->partc_s; g.part_rows = x->partc_r; g.P = pc; g.KP = CO_KP; g.nq = nq;
+        int rc = launch_finalize<true>(x, g, s);
+        if (rc) return rc;
+    }
+    rec(x, 3, s);
+    // fallback: exact kernel over the flagged list; work-groups beyond the list exit at once
+    int px = fit_p(pmax_x, x->partx_cap, kpx);
+    px = std::min(px, row_tiles);
+    {
+        const int tiles_per = (row_tiles + px - 1) / px;
+        px = (row_tiles + tiles_per - 1) / tiles_per;
+    }
+    return run_exact(x->flagged, x->nflag, px);
+}
+
+}  // namespace
+
+extern "C" {
+
+int icd_abi_version(void) { return ICD_ABI_VERSION; }
+
+const char *icd_last_error(void) { return g_err.c_str(); }
+
+int icd_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(ICD_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t *levels, int64_t id_base,
+                     int32_t device, int32_t max_nq, int32_t max_k, int32_t corpus_on_device,
+                     icd_index **out) {
+    if (!out) return fail(ICD_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!corpus || n <= 0 || n > 0x7FFFFF00ll) return fail(ICD_ERR_INVALID, "corpus NULL or n=%lld out of range", (long long)n);
+    if (dim <= 0 || dim % 32 != 0 || dim > 4096) return fail(ICD_ERR_UNSUPPORTED, "dim=%d: must be a multiple of 32, <= 4096", dim);
+    if (max_nq <= 0 || max_k <= 0 || max_k > ICD_MAX_K) return fail(ICD_ERR_INVALID, "max_nq=%d max_k=%d (max_k <= %d)", max_nq, max_k, ICD_MAX_K);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(ICD_ERR_INVALID, "device %d of %d", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(ICD_ERR_UNSUPPORTED, "device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+
+    icd_index *x = new (std::nothrow) icd_index();
+    if (!x) return fail(ICD_ERR_NOMEM, "host allocation failed");
+    x->device = device; x->n = n; x->id_base = id_base; x->dim = dim;
+    x->n_pad = (int)(((n + 127) / 128) * 128);
+    x->max_nq = max_nq; x->max_nq_pad = ((max_nq + 127) / 128) * 128; x->max_k = max_k;
+    x->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const bool fast_dim = (dim == 768 || dim == 1024);
+
+#define CR_TRY(expr)                                                                                 \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            free_all(x);                                                                             \
+            return fail(e_ == hipErrorOutOfMemory ? ICD_ERR_NOMEM : ICD_ERR_HIP, "%s: %s", #expr,    \
+                        hipGetErrorString(e_));                                                      \
+        }                                                                                            \
+    } while (0)
+
+    const size_t nelem = (size_t)n * dim;
+    CR_TRY(dmalloc(&x->corpus, nelem));
+    CR_TRY(hipMemcpy(x->corpus, corpus, nelem * sizeof(float), corpus_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    if (levels) {
+        CR_TRY(dmalloc(&x->levels, (size_t)n));
+        CR_TRY(hipMemcpy(x->levels, levels, (size_t)n * sizeof(int), corpus_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    }
+    CR_TRY(dmalloc(&x->scratch_u32, 4));
+    CR_TRY(hipMemset(x->scratch_u32, 0, 4 * sizeof(unsigned)));
+    size_t ws = 0;
+    auto wsalloc = [&](auto **p, size_t count) -> hipError_t {
+        hipError_t e = dmalloc(p, count);
+        if (e == hipSuccess) ws += std::max<size_t>(count, 1) * sizeof(**p);
+        return e;
+    };
+    if (fast_dim) {
+        CR_TRY(dmalloc(&x->c16, (size_t)x->n_pad * dim));
+        ConvertArgs cv{};
+        cv.src = x->corpus; cv.dst = x->c16; cv.rows = (int)n; cv.rows_pad = x->n_pad; cv.dim = dim;
+        cv.rmax_bits = x->scratch_u32; cv.any_bad = x->scratch_u32 + 1;
+        hipLaunchKernelGGL(convert_rows_kernel, dim3((x->n_pad + 3) / 4), dim3(256), 0, 0, cv);
+        CR_TRY(hipGetLastError());
+        unsigned hv[2] = {0, 0};
+        CR_TRY(hipMemcpy(hv, x->scratch_u32, sizeof hv, hipMemcpyDeviceToHost));
+        memcpy(&x->rmax, &hv[0], 4);
+        x->fast = (hv[1] == 0) && std::isfinite(x->rmax);
+        if (!x->fast) { hipFree(x->c16); x->c16 = nullptr; }
+    }
+    if (x->fast) {
+        CR_TRY(wsalloc(&x->q16, (size_t)x->max_nq_pad * dim));
+        x->partc_cap = std::max<size_t>((size_t)x->max_nq_pad * 4 * CO_KP, (size_t)1 << 20);
+        CR_TRY(wsalloc(&x->partc_s, x->partc_cap));
+        CR_TRY(wsalloc(&x->partc_r, x->partc_cap));
+    }
+    CR_TRY(wsalloc(&x->qnorm, (size_t)x->max_nq_pad));
+    CR_TRY(wsalloc(&x->qbad, (size_t)x->max_nq_pad));
+    CR_TRY(wsalloc(&x->qdev, (size_t)max_nq * dim));
+    x->partx_cap = std::max<size_t>((size_t)x->max_nq_pad * 2 * exact_kp_for(max_k), (size_t)1 << 21);
+    CR_TRY(wsalloc(&x->partx_s, x->partx_cap));
+    CR_TRY(wsalloc(&x->partx_r, x->partx_cap));
+    CR_TRY(wsalloc(&x->nflag, 4));
+    CR_TRY(wsalloc(&x->flagged, (size_t)x->max_nq_pad));
+    const size_t no = (size_t)max_nq * max_k;
+    CR_TRY(wsalloc(&x->o_scores, no)); CR_TRY(wsalloc(&x->o_ids, no)); CR_TRY(wsalloc(&x->o_adj, no));
+    CR_TRY(wsalloc(&x->o_adj_raw, no)); CR_TRY(wsalloc(&x->o_adj_ids, no)); CR_TRY(wsalloc(&x->o_adj_lv, no));
+    CR_TRY(hipHostMalloc(reinterpret_cast<void **>(&x->h_nflag), sizeof(int), hipHostMallocDefault));
+    *x->h_nflag = 0;
+    for (int i = 0; i <= NUM_EV; ++i) CR_TRY(hipEventCreate(&x->ev[i]));
+    CR_TRY(hipDeviceSynchronize());
+    x->bytes_ws = ws;
+#undef CR_TRY
+    *out = x;
+    return ICD_OK;
+}
+
+int icd_index_destroy(icd_index *idx) {
+    if (!valid(idx)) return fail(ICD_ERR_STATE, "invalid handle");
+    hipSetDevice(idx->device);
+    hipDeviceSynchronize();
+    free_all(idx);
+    return ICD_OK;
+}
+
+static int search_common(icd_index *x, const float *queries, int64_t nq, int32_t k, int32_t q_on_device,
+                         int32_t mode, Outs user, int32_t out_on_device, void *stream) {
+    if (!valid(x)) return fail(ICD_ERR_STATE, "invalid handle");
+    if (nq < 0 || nq > x->max_nq) return fail(ICD_ERR_INVALID, "nq=%lld exceeds max_nq=%d", (long long)nq, x->max_nq);
+    if (k <= 0 || k > x->max_k) return fail(ICD_ERR_INVALID, "k=%d exceeds max_k=%d", k, x->max_k);
+    if (mode != ICD_MODE_AUTO && mode != ICD_MODE_EXACT) return fail(ICD_ERR_INVALID, "mode=%d", mode);
+    if (nq == 0) return ICD_OK;
+    if (!queries) return fail(ICD_ERR_INVALID, "queries is NULL");
+    HIP_TRY(hipSetDevice(x->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const float *dq = queries;
+    if (!q_on_device) {
+        HIP_TRY(hipMemcpyAsync(x->qdev, queries, (size_t)nq * x->dim * sizeof(float), hipMemcpyHostToDevice, s));
+        dq = x->qdev;
+    }
+    Outs dev = user;
+    if (!out_on_device) {
+        dev.scores = user.scores ? x->o_scores : nullptr;
+        dev.ids = user.ids ? x->o_ids : nullptr;
+        dev.adj = user.adj ? x->o_adj : nullptr;
+        dev.adj_raw = user.adj_raw ? x->o_adj_raw : nullptr;
+        dev.adj_ids = user.adj_ids ? x->o_adj_ids : nullptr;
+        dev.adj_lv = user.adj_lv ? x->o_adj_lv : nullptr;
+    }
+    int rc = search_device(x, dq, (int)nq, k, mode, dev, s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(x->h_nflag, x->nflag, sizeof(int), hipMemcpyDeviceToHost, s));
+    rec(x, NUM_EV, s);
+    if (!out_on_device) {
+        const size_t no = (size_t)nq * k;
+        if (user.scores) HIP_TRY(hipMemcpyAsync(user.scores, dev.scores, no * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (user.ids) HIP_TRY(hipMemcpyAsync(user.ids, dev.ids, no * sizeof(long long), hipMemcpyDeviceToHost, s));
+        if (user.adj) HIP_TRY(hipMemcpyAsync(user.adj, dev.adj, no * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (user.adj_raw) HIP_TRY(hipMemcpyAsync(user.adj_raw, dev.adj_raw, no * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (user.adj_ids) HIP_TRY(hipMemcpyAsync(user.adj_ids, dev.adj_ids, no * sizeof(long long), hipMemcpyDeviceToHost, s));
+        if (user.adj_lv) HIP_TRY(hipMemcpyAsync(user.adj_lv, dev.adj_lv, no * sizeof(int), hipMemcpyDeviceToHost, s));
+    }
+    if (!out_on_device || !q_on_device) HIP_TRY(hipStreamSynchronize(s));
+    return ICD_OK;
+}
+
+int icd_index_search(icd_index *idx, const float *queries, int64_t nq, int32_t k, int32_t queries_on_device,
+                     int32_t mode, float *out_scores, int64_t *out_ids, int32_t out_on_device, void *stream) {
+    if (!out_scores || !out_ids) return fail(ICD_ERR_INVALID, "output pointer is NULL");
+    Outs o{};
+    o.scores = out_scores;
+    o.ids = reinterpret_cast<long long *>(out_ids);
+    return search_common(idx, queries, nq, k, queries_on_device, mode, o, out_on_device, stream);
+}
+
+int icd_index_search_reweighted(icd_index *idx, const float *queries, int64_t nq, int32_t k,
+                                int32_t queries_on_device, int32_t mode, double *out_adj, float *out_raw,
+                                int64_t *out_ids, int32_t *out_levels, int32_t out_on_device, void *stream) {
+    if (!out_adj || !out_ids) return fail(ICD_ERR_INVALID, "output pointer is NULL");
+    Outs o{};
+    o.adj = out_adj;
+    o.adj_raw = out_raw;
+    o.adj_ids = reinterpret_cast<long long *>(out_ids);
+    o.adj_lv = out_levels;
+    return search_common(idx, queries, nq, k, queries_on_device, mode, o, out_on_device, stream);
+}
+
+int icd_merge_topk(int32_t device, const float *scores, const int64_t *ids, const int32_t *levels, int32_t G,
+                   int64_t nq, int32_t k, double *out_adj, float *out_raw, int64_t *out_ids,
+                   int32_t *out_levels, void *stream) {
+    if (!scores || !ids || !levels) return fail(ICD_ERR_INVALID, "input pointer is NULL");
+    if (G <= 0 || k <= 0 || k > ICD_MAX_K || (int64_t)G * k > 1024) return fail(ICD_ERR_INVALID, "G=%d k=%d: need G*k <= 1024", G, k);
+    if (nq < 0 || nq > 0x7FFFFFFF) return fail(ICD_ERR_INVALID, "nq=%lld", (long long)nq);
+    if (nq == 0) return ICD_OK;
+    HIP_TRY(hipSetDevice(device));
+    MergeArgs a{};
+    a.scores = scores; a.ids = reinterpret_cast<const long long *>(ids); a.levels = levels;
+    a.G = G; a.nq = (int)nq; a.k = k;
+    a.out_adj = out_adj; a.out_raw = out_raw; a.out_ids = reinterpret_cast<long long *>(out_ids); a.out_levels = out_levels;
+    const size_t lds = 4 * (1024 * 16 + 128 * 24);
+    static thread_local int configured_dev = -1;
+    if (configured_dev != device) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(merge_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured_dev = device;
+    }
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(((int)nq + 3) / 4), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a);
+    HIP_TRY(hipGetLastError());
+    return ICD_OK;
+}
+
+int icd_index_lookup_levels(icd_index *idx, const int64_t *ids, int64_t count, int32_t *out_levels, void *stream) {
+    if (!valid(idx)) return fail(ICD_ERR_STATE, "invalid handle");
+    if (!ids || !out_levels || count < 0) return fail(ICD_ERR_INVALID, "bad arguments");
+    if (count == 0) return ICD_OK;
+    HIP_TRY(hipSetDevice(idx->device));
+    hipLaunchKernelGGL(lookup_levels_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const long long *>(ids),
+                       (long long)count, idx->levels, (long long)idx->id_base, (long long)idx->n, out_levels);
+    HIP_TRY(hipGetLastError());
+    return ICD_OK;
+}
+
+int icd_index_stats(icd_index *idx, icd_stats *out) {
+    if (!valid(idx)) return fail(ICD_ERR_STATE, "invalid handle");
+    if (!out) return fail(ICD_ERR_INVALID, "out is NULL");
+    memset(out, 0, sizeof *out);
+    out->n = idx->n; out->dim = idx->dim; out->device = idx->device; out->id_base = idx->id_base;
+    out->bytes_corpus_f32 = (int64_t)idx->n * idx->dim * 4;
+    out->bytes_corpus_f16 = idx->c16 ? (int64_t)idx->n_pad * idx->dim * 2 : 0;
+    out->bytes_workspace = (int64_t)idx->bytes_ws;
+    out->max_nq = idx->max_nq; out->max_k = idx->max_k; out->fast_path = idx->fast ? 1 : 0;
+    out->rmax = idx->rmax;
+    out->last_nq = idx->last_nq;
+    out->last_fallback = idx->h_nflag ? *idx->h_nflag : 0;
+    out->last_chunks = idx->last_chunks; out->last_mode = idx->last_mode;
+    return ICD_OK;
+}
+
+int icd_index_set_chunks(icd_index *idx, int32_t chunks) {
+    if (!valid(idx)) return fail(ICD_ERR_STATE, "invalid handle");
+    if (chunks < 0 || chunks > COARSE_MAX_P) return fail(ICD_ERR_INVALID, "chunks=%d (0..%d)", chunks, COARSE_MAX_P);
+    idx->chunks_override = chunks;
+    return ICD_OK;
+}
+
+int icd_index_set_profiling(icd_index *idx, int32_t enabled) {
+    if (!valid(idx)) return fail(ICD_ERR_STATE, "invalid handle");
+    idx->profiling = enabled != 0;
+    return ICD_OK;
+}
+
+int icd_index_last_profile(icd_index *idx, icd_profile *out) {
+    if (!valid(idx)) return fail(ICD_ERR_STATE, "invalid handle");
+    if (!out) return fail(ICD_ERR_INVALID, "out is NULL");
+    memset(out, 0, sizeof *out);
+    if (!idx->ev_valid[0] || !idx->ev_valid[NUM_EV]) return fail(ICD_ERR_STATE, "no profiled search recorded");
+    HIP_TRY(hipSetDevice(idx->device));
+    HIP_TRY(hipEventSynchronize(idx->ev[NUM_EV]));
+    auto span = [&](int a, int b) -> float {
+        float ms = 0.f;
+        if (idx->ev_valid[a] && idx->ev_valid[b]) hipEventElapsedTime(&ms, idx->ev[a], idx->ev[b]);
+        return ms;
+    };
+    out->ms_prep = span(0, 1);
+    out->ms_coarse = span(1, 2);
+    out->ms_finalize = span(2, 3);
+    out->ms_exact = span(3, 4);
+    out->ms_exact_finalize = span(4, 5);
+    out->ms_total = span(0, NUM_EV);
+    return ICD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+// topk_select.hpp — lane-local threshold filter + LDS candidate buffers + wave-cooperative compaction.
+//
+// Shared by the exact (fp32 MFMA) and coarse (fp16 MFMA) kernels. Both compute 32x32 score tiles with
+// "corpus rows = M, queries = N", so after an MFMA tile lane l holds 16 scores of ONE query
+// (query column l&31) for rows (r&3) + 8*(r>>2) + 4*(l>>5), r = register index (C/D layout of every
+// 32x32 MFMA on gfx950). Lanes l and l+32 own the same query and share its candidate buffer.
+//
+// Replaces the k-selection inside the Milvus FLAT search called at
+// services/milvus_service.py:280-285 (reference has no code of its own for it).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace icd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned long long u64;
+
+// ---- 64-bit sortable key: larger key = better hit (score desc, row asc) -----------------------------
+__device__ __forceinline__ uint32_t order_f32(float v) {
+    uint32_t u = __float_as_uint(v);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float unorder_f32(uint32_t o) {
+    uint32_t u = o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ u64 make_key(float score, uint32_t row) {
+    return ((u64)order_f32(score) << 32) | (u64)(~row);
+}
+__device__ __forceinline__ float key_score(u64 k) { return unorder_f32((uint32_t)(k >> 32)); }
+__device__ __forceinline__ uint32_t key_row(u64 k) { return ~(uint32_t)k; }
+// key 0 is below every real key (a real key has row <= 0x7FFFFFFE so its low word is >= 0x80000001)
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+template <typename T>
+__device__ __forceinline__ T readlane(T v, int l);
+template <>
+__device__ __forceinline__ int readlane<int>(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+template <>
+__device__ __forceinline__ uint32_t readlane<uint32_t>(uint32_t v, int l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+__device__ __forceinline__ u64 readlane_u64(u64 v, int l) {
+    uint32_t lo = readlane<uint32_t>((uint32_t)v, l), hi = readlane<uint32_t>((uint32_t)(v >> 32), l);
+    return ((u64)hi << 32) | lo;
+}
+
+// Per-lane select state (query-level values are duplicated in lanes l and l+32).
+struct SelState {
+    float thr;         // score of the query's current KP-th best (−inf until KP candidates exist)
+    uint32_t thr_row;  // its row (exact tie rule)
+    int cnt;           // entries in the query's LDS buffer
+};
+
+// Capacity of one query's buffer = 64*E entries (E keys per lane during compaction).
+// A 16-register group appends at most 32 entries per query, so compaction is triggered when
+// cnt > CAP-32 after a group.
+
+// Compact the buffer of ONE query (wave-cooperative, nb entries, wave-uniform): keep the best
+// min(nb,KP), rewritten sorted best-first at qbuf[0..]. Returns the key of rank KP-1 via kth
+// (valid iff nb >= KP).
+template <int KP, int E>
+__device__ __forceinline__ void compact_one(u64 *qbuf, int nb, int lane, u64 &kth) {
+    u64 key[E];
+    int rank[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = lane + 64 * e;
+        key[e] = (i < nb) ? qbuf[i] : 0ull;
+        rank[e] = 0;
+    }
+    // rank by counting; the reads below are wave-uniform addresses (LDS broadcast, conflict-free)
+    for (int j = 0; j < nb; ++j) {
+        const u64 kj = qbuf[j];
+#pragma unroll
+        for (int e = 0; e < E; ++e) rank[e] += (kj > key[e]) ? 1 : 0;
+    }
+    // all reads of this wave precede the writes in program order; LDS serves one wave's ops in order
+    u64 kth_local = 0ull;
+    bool have = false;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = lane + 64 * e;
+        if (i < nb && rank[e] < KP) qbuf[rank[e]] = key[e];
+        if (i < nb && rank[e] == KP - 1) { kth_local = key[e]; have = true; }
+    }
+    const u64 m = __ballot(have);
+    kth = 0ull;
+    if (m) {
+        const int src = __ffsll((long long)m) - 1;
+        kth = readlane_u64(kth_local, src);
+    }
+}
+
+// Compact every query of this wave whose buffer could overflow in the next group (or all when
+// force is set). wbuf = this wave's 32 buffers, CAP apart.
+template <int KP, int E>
+__device__ __forceinline__ void compact_wave(u64 *wbuf, SelState &st, int lane, bool force) {
+    constexpr int CAP = 64 * E;
+    constexpr int LIMIT = CAP - 32;
+    uint32_t need = (uint32_t)__ballot(force ? (st.cnt > 0) : (st.cnt > LIMIT));
+    while (need) {
+        const int b = __ffs((int)need) - 1;
+        need &= need - 1;
+        const int nb = readlane<int>(st.cnt, b);
+        u64 kth;
+        compact_one<KP, E>(wbuf + (size_t)b * CAP, nb, lane, kth);
+        if ((lane & 31) == b) {
+            if (nb >= KP) {
+                st.thr = key_score(kth);
+                st.thr_row = key_row(kth);
+                st.cnt = KP;
+            }
+        }
+    }
+}
+
+// Threshold-filter one 32x32 MFMA tile's 16 registers. row0 = absolute row of the tile's row 0.
+// EXACT_TIES: also accept score == thr with a lower row than the current KP-th (canonical order).
+template <bool EXACT_TIES>
+__device__ __forceinline__ void filter16(const f32x16 &acc, uint32_t row0, SelState &st, u64 *qbuf, int lane) {
+    const uint32_t rbase = row0 + 4u * (uint32_t)(lane >> 5);
+    const uint32_t c = (uint32_t)lane & 31u;
+    const uint32_t hi_half = (uint32_t)lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float v = acc[r];
+        const uint32_t row = rbase + (uint32_t)((r & 3) + 8 * (r >> 2));
+        bool pass = v > st.thr;
+        if (EXACT_TIES) pass = pass || (v == st.thr && row < st.thr_row);
+        const u64 m = __ballot(pass);
+        if (m) {
+            const uint32_t plo = ((uint32_t)m >> c) & 1u;
+            const uint32_t phi = ((uint32_t)(m >> 32) >> c) & 1u;
+            if (pass) {
+                const int slot = st.cnt + (int)(hi_half ? plo : 0u);
+                qbuf[slot] = make_key(v, row);
+            }
+            st.cnt += (int)(plo + phi);
+        }
+    }
+}
+
+}  // namespace icd
