@@ -152,6 +152,10 @@ int icd_index_stats(icd_index *idx, icd_stats *out);
 /* Tuning knobs (0 = automatic): number of corpus chunks P per query tile for the coarse kernel. */
 int icd_index_set_chunks(icd_index *idx, int32_t chunks);
 
+/* Diagnostic builds only (env ICD_COARSE_VAR=8): per-wave cycle sums of the coarse kernel,
+ * [work-group][wave][4] = {wait+barrier, stage body, fused select, tiles}. */
+int icd_index_debug_counters(icd_index *idx, unsigned long long *out, int32_t count);
+
 int icd_index_set_profiling(icd_index *idx, int32_t enabled);
 /* Synchronises the events of the most recent search and fills `out`. */
 int icd_index_last_profile(icd_index *idx, icd_profile *out);

@@ -165,7 +165,12 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
         // chunk lists that are full may have dropped rows scoring up to their last entry
         if (lane < a.P) {
             const u64 last = keys[lane * a.KP + a.KP - 1];
-            if (last != 0ull) tau = key_score(last);
+            if (last != 0ull) {
+                // the coarse kernel ranks by a key with 6 low score bits dropped (Sel2): a dropped row
+                // may exceed the list's last entry by that relative slack
+                const float sl = key_score(last);
+                tau = sl + fabsf(sl) * COARSE_KEY_SLACK;
+            }
         }
     }
 #pragma unroll

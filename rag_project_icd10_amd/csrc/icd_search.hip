@@ -87,6 +87,7 @@ struct icd_index {
     int64_t last_nq = 0;
     int last_chunks = 0, last_mode = 0;
     int *h_nflag = nullptr;  // pinned
+    unsigned long long *dbg = nullptr;  // diagnostic cycle counters [8192][4][4]
 };
 
 namespace {
@@ -100,6 +101,7 @@ void free_all(icd_index *x) {
     hipFree(x->partx_r); hipFree(x->nflag); hipFree(x->flagged); hipFree(x->scratch_u32);
     hipFree(x->o_scores); hipFree(x->o_ids); hipFree(x->o_adj); hipFree(x->o_adj_raw);
     hipFree(x->o_adj_ids); hipFree(x->o_adj_lv);
+    hipFree(x->dbg);
     if (x->h_nflag) hipHostFree(x->h_nflag);
     for (int i = 0; i <= NUM_EV; ++i)
         if (x->ev[i]) hipEventDestroy(x->ev[i]);
@@ -145,9 +147,9 @@ int launch_exact(icd_index *x, const ExactArgs &a, int mtiles, hipStream_t s) {
     return ICD_OK;
 }
 
-template <int D>
+template <int D, int VAR>
 int launch_coarse(icd_index *x, const CoarseArgs &a, int mtiles, hipStream_t s) {
-    auto kern = coarse_topk_kernel<D>;
+    auto kern = coarse_topk_kernel<D, VAR>;
     static thread_local int configured_dev = -1;
     if (configured_dev != x->device) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CO_LDS_BYTES));
@@ -191,6 +193,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     for (int i = 0; i <= NUM_EV; ++i) x->ev_valid[i] = false;
     x->last_nq = nq;
     x->last_mode = use_fast ? ICD_MODE_AUTO : ICD_MODE_EXACT;
+    HIP_TRY(hipMemsetAsync(x->nflag, 0, sizeof(int), s));
     rec(x, 0, s);
 
     FinArgs f{};
@@ -252,7 +255,6 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     cv.norm = x->qnorm; cv.bad = x->qbad;
     hipLaunchKernelGGL(convert_rows_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, s, cv);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemsetAsync(x->nflag, 0, sizeof(int), s));
     rec(x, 1, s);
 
     const int mtc = nq_pad / 128;
@@ -268,7 +270,25 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         a.rows_per_chunk = tiles_per * 128;
         a.part_scores = x->partc_s; a.part_rows = x->partc_r;
         x->last_chunks = pc;
-        int rc = x->dim == 768 ? launch_coarse<768>(x, a, mtc, s) : launch_coarse<1024>(x, a, mtc, s);
+        a.dbg = x->dbg;
+        // Product configuration of the coarse kernel: buffer_load...lds staging (256) + pinned
+        // read-ahead order (32). Other VAR values are timing ablations, built only with -DICD_ABLATE.
+        constexpr int PV = 256 | 32;
+        int rc;
+        if (x->dim == 1024) rc = launch_coarse<1024, PV>(x, a, mtc, s);
+        else {
+#ifdef ICD_ABLATE
+            int var = PV;
+            if (const char *e = getenv("ICD_COARSE_VAR")) var = atoi(e);
+            if (false) {}
+#define ICD_VAR_CASE(V) else if (var == V) rc = launch_coarse<768, V>(x, a, mtc, s);
+            ICD_VAR_CASE(0) ICD_VAR_CASE(1) ICD_VAR_CASE(8) ICD_VAR_CASE(16) ICD_VAR_CASE(32) ICD_VAR_CASE(33)
+            ICD_VAR_CASE(129) ICD_VAR_CASE(256) ICD_VAR_CASE(257) ICD_VAR_CASE(289) ICD_VAR_CASE(296)
+#undef ICD_VAR_CASE
+            else
+#endif
+            rc = launch_coarse<768, PV>(x, a, mtc, s);
+        }
         if (rc) return rc;
     }
     rec(x, 2, s);
@@ -380,6 +400,9 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     CR_TRY(wsalloc(&x->partx_s, x->partx_cap));
     CR_TRY(wsalloc(&x->partx_r, x->partx_cap));
     CR_TRY(wsalloc(&x->nflag, 4));
+    CR_TRY(hipMemset(x->nflag, 0, 4 * sizeof(int)));
+    CR_TRY(wsalloc(&x->dbg, (size_t)8192 * 16));
+    CR_TRY(hipMemset(x->dbg, 0, (size_t)8192 * 16 * 8));
     CR_TRY(wsalloc(&x->flagged, (size_t)x->max_nq_pad));
     const size_t no = (size_t)max_nq * max_k;
     CR_TRY(wsalloc(&x->o_scores, no)); CR_TRY(wsalloc(&x->o_ids, no)); CR_TRY(wsalloc(&x->o_adj, no));
@@ -519,6 +542,14 @@ int icd_index_set_chunks(icd_index *idx, int32_t chunks) {
     if (!valid(idx)) return fail(ICD_ERR_STATE, "invalid handle");
     if (chunks < 0 || chunks > COARSE_MAX_P) return fail(ICD_ERR_INVALID, "chunks=%d (0..%d)", chunks, COARSE_MAX_P);
     idx->chunks_override = chunks;
+    return ICD_OK;
+}
+
+int icd_index_debug_counters(icd_index *idx, unsigned long long *out, int32_t count) {
+    if (!valid(idx)) return fail(ICD_ERR_STATE, "invalid handle");
+    if (!out || count <= 0 || count > 8192 * 16) return fail(ICD_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(idx->device));
+    HIP_TRY(hipMemcpy(out, idx->dbg, (size_t)count * 8, hipMemcpyDeviceToHost));
     return ICD_OK;
 }
 

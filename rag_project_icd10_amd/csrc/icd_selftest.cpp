@@ -159,6 +159,14 @@ static void bench(int64_t n, int64_t nq, int dim, int k, int iters, int chunks, 
                acc.ms_exact / it, acc.ms_exact_finalize / it, nq / tot / 1e3, flop / (dom * 1e-3) / 1e12, st.last_chunks,
                (long long)st.last_fallback);
     }
+    if (getenv("ICD_COARSE_VAR") && (atoi(getenv("ICD_COARSE_VAR")) & 8)) {
+        std::vector<unsigned long long> c(237 * 16);
+        CHECK_RC(icd_index_debug_counters(idx, c.data(), (int)c.size()));
+        double w = 0, b = 0, e = 0, t = 0; int cnt = 0;
+        for (size_t i = 0; i + 3 < c.size(); i += 4) if (c[i + 3]) { w += c[i]; b += c[i + 1]; e += c[i + 2]; t += c[i + 3]; ++cnt; }
+        printf("   stamps (avg per wave over %d waves, cycles per tile): wait+barrier=%.0f body=%.0f select=%.0f tiles/wave=%.1f\n",
+               cnt, w / t, b / t, e / t, t / cnt);
+    }
     if (verify) {
         // parity of a query sample of the big run against the oracle (AUTO mode)
         const int ns = 128;
@@ -186,7 +194,7 @@ static void bench(int64_t n, int64_t nq, int dim, int k, int iters, int chunks, 
 
 int main(int argc, char **argv) {
     std::string opath = "oracle/libicd_oracle.so";
-    bool quick = false, do_bench = false;
+    bool quick = false, do_bench = false, skip_cases = false;
     int64_t bn = 37000, bnq = 10000;
     int iters = 20, chunks = 0;
     for (int i = 1; i < argc; ++i) {
@@ -194,6 +202,7 @@ int main(int argc, char **argv) {
         if (a == "--oracle" && i + 1 < argc) opath = argv[++i];
         else if (a == "--quick") quick = true;
         else if (a == "--bench") do_bench = true;
+        else if (a == "--skip-cases") skip_cases = true;
         else if (a == "--n" && i + 1 < argc) bn = atoll(argv[++i]);
         else if (a == "--nq" && i + 1 < argc) bnq = atoll(argv[++i]);
         else if (a == "--iters" && i + 1 < argc) iters = atoi(argv[++i]);
@@ -206,6 +215,7 @@ int main(int argc, char **argv) {
     if (!oracle_topk || !oracle_reweight) { printf("oracle symbols missing\n"); return 2; }
     printf("icd_selftest: abi=%d devices=%d\n", icd_abi_version(), icd_device_count());
 
+    if (!skip_cases) {
     // ---- exact path ----
     run_case("exact/tiny", make_data(100, 3, 768, 0, 1), 5, ICD_MODE_EXACT);
     run_case("exact/n<k", make_data(7, 2, 768, 0, 2), 10, ICD_MODE_EXACT);
@@ -234,7 +244,11 @@ int main(int argc, char **argv) {
         run_case("auto/37k-clustered", make_data(37000, 256, 768, 1, 23), 10, ICD_MODE_AUTO);
         run_case("auto/37k-k5", make_data(37000, 1, 768, 0, 24), 5, ICD_MODE_AUTO);
     }
-    if (do_bench) bench(bn, bnq, 768, 10, iters, chunks, true);
+    }
+    if (do_bench) {
+        const int var = getenv("ICD_COARSE_VAR") ? atoi(getenv("ICD_COARSE_VAR")) : 0;
+        bench(bn, bnq, 768, 10, iters, chunks, (var & 7) == 0);
+    }
     printf("icd_selftest: %d passed, %d failed\n", g_pass, g_fail);
     return g_fail ? 1 : 0;
 }

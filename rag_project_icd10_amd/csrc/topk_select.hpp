@@ -144,3 +144,106 @@ __device__ __forceinline__ void filter16(const f32x16 &acc, uint32_t row0, SelSt
 }
 
 }  // namespace icd
+
+// =====================================================================================================
+// Select v2 (coarse kernel): two-sided SoA candidate buffers and a fixed-trip rank compaction.
+//
+// Per query: score[64] f32 | row[64] u32 (512 B). Lane h=0 of the query's lane pair appends upward
+// from slot `kept`, lane h=1 downward from slot 63, so an append needs no cross-lane slot arithmetic:
+//     if (v > thr) { score[w] = v; row[w] = r; w += step; }
+// Compaction ranks the <= 64 entries by a unique 32-bit key = (ordered score with its 6 low bits
+// replaced by 63 - slot): 16 broadcast ds_read_b128 + 64 compare/add pairs, no dependent LDS latency.
+// The 6 dropped bits are a relative 2^-17 perturbation of the coarse score; finalize.hpp widens tau
+// by that much (COARSE_KEY_SLACK).
+// =====================================================================================================
+namespace icd {
+
+constexpr float COARSE_KEY_SLACK = 1.6e-5f;  // > 2^-17 * 2: relative slack of the truncated ranking key
+
+struct Sel2 {
+    float thr;      // current KP-th best score of the query (valid lower bound)
+    int kept;       // entries at the front after the last compaction (<= KP); query-level
+    uint32_t aw;    // LDS byte address of this lane's next score slot
+    uint32_t aw0;   // its value right after the last compaction
+    uint32_t inc;   // +4 (low lane, grows up) or -4 (high lane, grows down)
+};
+
+template <int KP>
+struct Sel2Ops {
+    static constexpr int CAP = 64;
+    // byte offsets inside a query buffer
+    static constexpr uint32_t ROW_OFF = CAP * 4;
+    static constexpr uint32_t QBYTES = CAP * 8;
+
+    __device__ static __forceinline__ void init(Sel2 &s, uint32_t qbase, int h, bool valid) {
+        s.thr = valid ? -INFINITY : INFINITY;
+        s.kept = 0;
+        s.aw0 = h ? qbase + (CAP - 1) * 4 : qbase;
+        s.aw = s.aw0;
+        s.inc = h ? (uint32_t)-4 : 4u;
+    }
+    __device__ static __forceinline__ int used(const Sel2 &s, int h) {
+        return h ? (int)(s.aw0 - s.aw) >> 2 : (int)(s.aw - s.aw0) >> 2;
+    }
+    // one score of the finished tile
+    __device__ static __forceinline__ void step(Sel2 &s, float v, uint32_t row, char *smem) {
+        if (v > s.thr) {
+            *reinterpret_cast<float *>(smem + s.aw) = v;
+            *reinterpret_cast<uint32_t *>(smem + s.aw + ROW_OFF) = row;
+            s.aw += s.inc;
+        }
+    }
+    // after a 16-register group: compact the queries that could overflow in the next group
+    __device__ static __forceinline__ void check(Sel2 &s, int lane, char *smem, uint32_t wave_qbase,
+                                                 uint32_t wave_scratch, bool force) {
+        const int h = lane >> 5;
+        const int mine = used(s, h);
+        const int other = __shfl_xor(mine, 32);
+        const int total = s.kept + mine + other;
+        uint32_t need = (uint32_t)__ballot(force ? (total > 0) : (total > CAP - 32));
+        while (need) {
+            const int b = __ffs((int)need) - 1;
+            need &= need - 1;
+            // counts of query b (lane b = low lane, lane b+32 = high lane)
+            const int kept_b = readlane<int>(s.kept, b);
+            const int nlo = kept_b + readlane<int>(mine, b);
+            const int nhi = readlane<int>(mine, b + 32);
+            const uint32_t qb = wave_qbase + (uint32_t)b * QBYTES;
+            const bool valid = (lane < nlo) || (lane >= CAP - nhi);
+            float v = 0.f;
+            uint32_t row = 0;
+            if (valid) {
+                v = *reinterpret_cast<const float *>(smem + qb + lane * 4);
+                row = *reinterpret_cast<const uint32_t *>(smem + qb + ROW_OFF + lane * 4);
+            }
+            const uint32_t key = valid ? ((order_f32(v) & ~63u) | (uint32_t)(63 - lane)) : 0u;
+            *reinterpret_cast<uint32_t *>(smem + wave_scratch + lane * 4) = key;
+            int rank = 0;
+            const uint4 *kp = reinterpret_cast<const uint4 *>(smem + wave_scratch);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint4 kk = kp[j];  // wave-uniform address: LDS broadcast
+                rank += (kk.x > key) ? 1 : 0;
+                rank += (kk.y > key) ? 1 : 0;
+                rank += (kk.z > key) ? 1 : 0;
+                rank += (kk.w > key) ? 1 : 0;
+            }
+            const int nvalid = nlo + nhi;
+            if (valid && rank < KP) {
+                *reinterpret_cast<float *>(smem + qb + rank * 4) = v;
+                *reinterpret_cast<uint32_t *>(smem + qb + ROW_OFF + rank * 4) = row;
+            }
+            const u64 mk = __ballot(valid && rank == KP - 1);
+            float nthr = 0.f;
+            if (mk) nthr = __builtin_bit_cast(float, readlane<uint32_t>(__float_as_uint(v), __ffsll((long long)mk) - 1));
+            if ((lane & 31) == b) {
+                if (nvalid >= KP) s.thr = nthr;
+                s.kept = min(nvalid, KP);
+                s.aw0 = h ? qb + (CAP - 1) * 4 : qb + (uint32_t)s.kept * 4;
+                s.aw = s.aw0;
+            }
+        }
+    }
+};
+
+}  // namespace icd
