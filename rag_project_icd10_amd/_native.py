@@ -1,0 +1,316 @@
+"""ctypes binding of libicdsearch.so (C ABI: include/icd_search.h).
+
+This is the only place the product touches native code. There is NO CPU fallback: if the shared
+library is missing or the device is not an MI355X (gfx950) the constructors raise.
+
+`IcdIndex` is the MI355X replacement for the Milvus Lite collection the reference opens in
+services/milvus_service.py:57-206 and searches at :280-285.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libicdsearch.so")
+
+MODE_AUTO = 0   # fp16-MFMA coarse pass + certified exact rescoring (+ exact fallback); same results as EXACT
+MODE_EXACT = 1  # fp32-MFMA kernel only
+MAX_K = 128
+
+EXPORTED_SYMBOLS = (
+    "icd_abi_version", "icd_last_error", "icd_device_count", "icd_index_create", "icd_index_destroy",
+    "icd_index_search", "icd_index_search_reweighted", "icd_merge_topk", "icd_index_lookup_levels",
+    "icd_index_stats", "icd_index_set_chunks", "icd_index_debug_counters", "icd_index_set_profiling",
+    "icd_index_last_profile",
+)
+
+
+class IcdError(RuntimeError):
+    """A libicdsearch call returned a negative icd_status."""
+
+    def __init__(self, code: int, text: str):
+        super().__init__(f"libicdsearch error {code}: {text}")
+        self.code = code
+
+
+class _Stats(C.Structure):
+    _fields_ = [("n", C.c_int64), ("dim", C.c_int32), ("device", C.c_int32), ("id_base", C.c_int64),
+                ("bytes_corpus_f32", C.c_int64), ("bytes_corpus_f16", C.c_int64), ("bytes_workspace", C.c_int64),
+                ("max_nq", C.c_int32), ("max_k", C.c_int32), ("fast_path", C.c_int32), ("rmax", C.c_float),
+                ("last_nq", C.c_int64), ("last_fallback", C.c_int64), ("last_chunks", C.c_int32),
+                ("last_mode", C.c_int32)]
+
+
+class _Profile(C.Structure):
+    _fields_ = [("ms_prep", C.c_float), ("ms_coarse", C.c_float), ("ms_finalize", C.c_float),
+                ("ms_exact", C.c_float), ("ms_exact_finalize", C.c_float), ("ms_total", C.c_float)]
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """Load libicdsearch.so and declare the prototypes. Raises if the library is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("ICD_SEARCH_LIB", LIB_PATH)
+    if not os.path.exists(p):
+        raise ImportError(
+            f"{p} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C rag_project_icd10_amd/csrc`. There is no CPU fallback for the search path.")
+    lib = C.CDLL(p)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    lib.icd_abi_version.restype = C.c_int
+    lib.icd_last_error.restype = C.c_char_p
+    lib.icd_device_count.restype = C.c_int
+    lib.icd_index_create.argtypes = [vp, i64, i32, vp, i64, i32, i32, i32, i32, C.POINTER(vp)]
+    lib.icd_index_destroy.argtypes = [vp]
+    lib.icd_index_search.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, i32, vp]
+    lib.icd_index_search_reweighted.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, i32, vp]
+    lib.icd_merge_topk.argtypes = [i32, vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, vp]
+    lib.icd_index_lookup_levels.argtypes = [vp, vp, i64, vp, vp]
+    lib.icd_index_stats.argtypes = [vp, C.POINTER(_Stats)]
+    lib.icd_index_set_chunks.argtypes = [vp, i32]
+    lib.icd_index_debug_counters.argtypes = [vp, vp, i32]
+    lib.icd_index_set_profiling.argtypes = [vp, i32]
+    lib.icd_index_last_profile.argtypes = [vp, C.POINTER(_Profile)]
+    for name in EXPORTED_SYMBOLS:
+        getattr(lib, name)  # AttributeError if the build is stale
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(lib, rc: int):
+    if rc != 0:
+        raise IcdError(rc, (lib.icd_last_error() or b"").decode("utf-8", "replace"))
+
+
+def device_count() -> int:
+    lib = load_library()
+    n = lib.icd_device_count()
+    if n < 0:
+        _check(lib, n)
+    return n
+
+
+def _is_torch_tensor(x) -> bool:
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+def _current_stream_ptr(device_index: int) -> int:
+    import torch
+    return int(torch.cuda.current_stream(device_index).cuda_stream)
+
+
+class IcdIndex:
+    """Exact inner-product index over a dense fp32 corpus resident in one GPU's HBM.
+
+    corpus : (n, dim) float32, C-contiguous numpy array, or a torch CUDA tensor on `device`.
+    levels : (n,) ICD hierarchy level per row (1/2/3) or None (all level 1, the reference default
+             services/milvus_service.py:247).
+    id_base: id of row 0 (row-sharded corpora).
+    """
+
+    def __init__(self, corpus, levels=None, *, device: int = 0, max_nq: int = 16384, max_k: int = 100,
+                 id_base: int = 0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        on_dev = 0
+        if _is_torch_tensor(corpus):
+            if not corpus.is_cuda:
+                corpus = corpus.detach().cpu().numpy()
+            else:
+                import torch
+                if corpus.dtype != torch.float32 or not corpus.is_contiguous():
+                    corpus = corpus.to(torch.float32).contiguous()
+                if corpus.device.index != device:
+                    raise ValueError(f"corpus is on cuda:{corpus.device.index}, index on device {device}")
+                on_dev = 1
+        if on_dev:
+            import torch
+            n, dim = int(corpus.shape[0]), int(corpus.shape[1])
+            cptr = corpus.data_ptr()
+            lv = None
+            if levels is not None:
+                lv = torch.as_tensor(levels).to(device=corpus.device, dtype=torch.int32).contiguous()
+            lptr = lv.data_ptr() if lv is not None else None
+            torch.cuda.synchronize(device)
+        else:
+            corpus = np.ascontiguousarray(corpus, dtype=np.float32)
+            if corpus.ndim != 2:
+                raise ValueError("corpus must be 2-D (n, dim)")
+            n, dim = corpus.shape
+            cptr = corpus.ctypes.data
+            lv = None if levels is None else np.ascontiguousarray(levels, dtype=np.int32)
+            if lv is not None and lv.shape != (n,):
+                raise ValueError("levels must have shape (n,)")
+            lptr = lv.ctypes.data if lv is not None else None
+        self.n, self.dim, self.device, self.max_nq, self.max_k = int(n), int(dim), int(device), int(max_nq), int(max_k)
+        self.id_base = int(id_base)
+        _check(self._lib, self._lib.icd_index_create(cptr, n, dim, lptr, id_base, device, max_nq, max_k, on_dev,
+                                                      C.byref(self._h)))
+
+    # -- lifecycle -----------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.icd_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def closed(self) -> bool:
+        return not self._h.value
+
+    # -- search --------------------------------------------------------------------------------------
+    def _prep_queries(self, queries):
+        if _is_torch_tensor(queries) and queries.is_cuda:
+            import torch
+            q = queries
+            if q.dim() == 1:
+                q = q.unsqueeze(0)
+            if q.dtype != torch.float32 or not q.is_contiguous():
+                q = q.to(torch.float32).contiguous()
+            if q.device.index != self.device:
+                raise ValueError(f"queries on cuda:{q.device.index}, index on device {self.device}")
+            return q, True
+        if _is_torch_tensor(queries):
+            queries = queries.detach().cpu().numpy()
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        return q, False
+
+    def _validate(self, q, k):
+        if self.closed:
+            raise IcdError(-5, "index is closed")
+        if q.shape[-1] != self.dim:
+            raise ValueError(f"query dim {q.shape[-1]} != index dim {self.dim}")
+        if not (1 <= k <= self.max_k):
+            raise ValueError(f"k={k} outside 1..{self.max_k}")
+
+    def search(self, queries, k: int = 10, mode: int = MODE_AUTO):
+        """Raw top-k by inner product -> (scores float32 [nq,k], ids int64 [nq,k]), best first.
+        Device tensors in -> device tensors out (enqueued on torch's current stream, no sync)."""
+        q, on_dev = self._prep_queries(queries)
+        self._validate(q, k)
+        nq = int(q.shape[0])
+        out_s, out_i = [], []
+        for s0 in range(0, max(nq, 1), self.max_nq):
+            qs = q[s0:s0 + self.max_nq]
+            m = int(qs.shape[0])
+            if on_dev:
+                import torch
+                sc = torch.empty((m, k), dtype=torch.float32, device=q.device)
+                ids = torch.empty((m, k), dtype=torch.int64, device=q.device)
+                if m:
+                    _check(self._lib, self._lib.icd_index_search(self._h, qs.data_ptr(), m, k, 1, mode, sc.data_ptr(),
+                                                                  ids.data_ptr(), 1, _current_stream_ptr(self.device)))
+            else:
+                sc = np.empty((m, k), dtype=np.float32)
+                ids = np.empty((m, k), dtype=np.int64)
+                if m:
+                    _check(self._lib, self._lib.icd_index_search(self._h, qs.ctypes.data, m, k, 0, mode, sc.ctypes.data,
+                                                                  ids.ctypes.data, 0, None))
+            out_s.append(sc)
+            out_i.append(ids)
+        if len(out_s) == 1:
+            return out_s[0], out_i[0]
+        if on_dev:
+            import torch
+            return torch.cat(out_s), torch.cat(out_i)
+        return np.concatenate(out_s), np.concatenate(out_i)
+
+    def search_reweighted(self, queries, k: int = 10, mode: int = MODE_AUTO):
+        """Raw top-k, then adj = float64(score) * w[level] and a stable descending re-sort of the k hits
+        (services/milvus_service.py:290-295,314). Returns (adj f64, raw f32, ids i64, levels i32), each [nq,k]."""
+        q, on_dev = self._prep_queries(queries)
+        self._validate(q, k)
+        nq = int(q.shape[0])
+        outs = []
+        for s0 in range(0, max(nq, 1), self.max_nq):
+            qs = q[s0:s0 + self.max_nq]
+            m = int(qs.shape[0])
+            if on_dev:
+                import torch
+                adj = torch.empty((m, k), dtype=torch.float64, device=q.device)
+                raw = torch.empty((m, k), dtype=torch.float32, device=q.device)
+                ids = torch.empty((m, k), dtype=torch.int64, device=q.device)
+                lv = torch.empty((m, k), dtype=torch.int32, device=q.device)
+                if m:
+                    _check(self._lib, self._lib.icd_index_search_reweighted(
+                        self._h, qs.data_ptr(), m, k, 1, mode, adj.data_ptr(), raw.data_ptr(), ids.data_ptr(),
+                        lv.data_ptr(), 1, _current_stream_ptr(self.device)))
+            else:
+                adj = np.empty((m, k), dtype=np.float64)
+                raw = np.empty((m, k), dtype=np.float32)
+                ids = np.empty((m, k), dtype=np.int64)
+                lv = np.empty((m, k), dtype=np.int32)
+                if m:
+                    _check(self._lib, self._lib.icd_index_search_reweighted(
+                        self._h, qs.ctypes.data, m, k, 0, mode, adj.ctypes.data, raw.ctypes.data, ids.ctypes.data,
+                        lv.ctypes.data, 0, None))
+            outs.append((adj, raw, ids, lv))
+        if len(outs) == 1:
+            return outs[0]
+        if on_dev:
+            import torch
+            return tuple(torch.cat([o[i] for o in outs]) for i in range(4))
+        return tuple(np.concatenate([o[i] for o in outs]) for i in range(4))
+
+    def lookup_levels(self, ids):
+        """Levels of hit ids (torch CUDA int64 tensor) -> int32 tensor; ids < 0 give 0."""
+        import torch
+        ids = ids.contiguous()
+        out = torch.empty(ids.shape, dtype=torch.int32, device=ids.device)
+        _check(self._lib, self._lib.icd_index_lookup_levels(self._h, ids.data_ptr(), ids.numel(), out.data_ptr(),
+                                                            _current_stream_ptr(self.device)))
+        return out
+
+    # -- introspection -------------------------------------------------------------------------------
+    def stats(self) -> dict:
+        st = _Stats()
+        _check(self._lib, self._lib.icd_index_stats(self._h, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in _Stats._fields_}
+
+    def set_chunks(self, chunks: int):
+        _check(self._lib, self._lib.icd_index_set_chunks(self._h, int(chunks)))
+
+    def set_profiling(self, enabled: bool):
+        _check(self._lib, self._lib.icd_index_set_profiling(self._h, 1 if enabled else 0))
+
+    def last_profile(self) -> dict:
+        p = _Profile()
+        _check(self._lib, self._lib.icd_index_last_profile(self._h, C.byref(p)))
+        return {f: float(getattr(p, f)) for f, _ in _Profile._fields_}
+
+
+def merge_topk(scores, ids, levels, k: int):
+    """Row-sharded search, step 2 (device tensors): scores/ids/levels are [G, nq, k] gathered from G
+    shards; returns (adj f64, raw f32, ids i64, levels i32), each [nq, k], reweighted and re-sorted."""
+    import torch
+    lib = load_library()
+    G, nq, kk = scores.shape
+    assert kk == k
+    dev = scores.device
+    scores = scores.to(torch.float32).contiguous()
+    ids = ids.to(torch.int64).contiguous()
+    levels = levels.to(torch.int32).contiguous()
+    adj = torch.empty((nq, k), dtype=torch.float64, device=dev)
+    raw = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    oid = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    olv = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    _check(lib, lib.icd_merge_topk(dev.index, scores.data_ptr(), ids.data_ptr(), levels.data_ptr(), G, nq, k,
+                                   adj.data_ptr(), raw.data_ptr(), oid.data_ptr(), olv.data_ptr(),
+                                   _current_stream_ptr(dev.index)))
+    return adj, raw, oid, olv

@@ -1,0 +1,220 @@
+"""Text -> unit vector. Drop-in for the reference's services/embedding_service.py.
+
+Same public surface (:75-149): encode_single, encode_batch, encode_icd_record, encode_query,
+get_model_info, test_embedding; attributes .config .model .device (read by main.py:168,266).
+Same text handling, byte for byte (:68-73,:119): `encode_query` prepends "query: " (used for corpus
+rows at build time AND for queries), everything else prepends "passage: " unless the text already
+starts with "query:" / "passage:".
+
+The arithmetic the reference delegates to sentence-transformers (un-vendored; `>=4.1.0`,
+requirements.txt:7) is restated on PyTorch-ROCm: BERT encoder forward -> mean pooling over the
+attention mask -> L2 normalisation -> float32 (the published SentenceTransformer.encode contract with
+normalize_embeddings=True). Differences by design: texts are really batched and length-bucketed, and
+batches can stay on the GPU (`encode_query_batch(..., to_device=True)`) so the search kernel reads
+them without a host round trip.
+
+Weights: `EMBEDDING_MODEL_NAME` is resolved locally only (no network in this deployment). If it
+cannot be resolved the constructor raises, exactly like the reference does on a failed model load
+(:64-66), unless synthetic weights are explicitly allowed (`allow_synthetic=True` or
+ICD_EMBEDDING_ALLOW_SYNTHETIC=1): then a seeded random-init BERT-base of text2vec-base-chinese's
+shape and a character-level tokenizer are used and `get_model_info()["synthetic"]` is True.
+Encoder NUMERICAL parity with the reference is unpinned.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+
+logger = logging.getLogger(__name__)
+
+DEFAULT_MODEL = "intfloat/multilingual-e5-large-instruct"  # reference default (:26)
+_PREFIXES = ("query:", "passage:")
+
+
+class _CharTokenizer:
+    """Stand-in for the WordPiece vocabulary when no tokenizer files are available: one token per
+    character (what bert-base-chinese does for CJK), deterministic ids in [1000, vocab)."""
+
+    cls_id, sep_id, pad_id = 101, 102, 0
+
+    def __init__(self, vocab_size: int, max_len: int):
+        self.vocab_size, self.max_len = vocab_size, max_len
+
+    def encode(self, text: str) -> List[int]:
+        ids = [1000 + (ord(ch) % (self.vocab_size - 1000)) for ch in text.lower() if not ch.isspace()]
+        return [self.cls_id] + ids[: self.max_len - 2] + [self.sep_id]
+
+
+class _Encoder(torch.nn.Module):
+    """HF BertModel + masked mean pooling + L2 normalisation."""
+
+    def __init__(self, bert):
+        super().__init__()
+        self.bert = bert
+
+    @torch.no_grad()
+    def forward(self, input_ids, attention_mask):
+        hidden = self.bert(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state
+        mask = attention_mask.unsqueeze(-1).to(hidden.dtype)
+        pooled = (hidden * mask).sum(1) / mask.sum(1).clamp(min=1e-9)
+        return torch.nn.functional.normalize(pooled.float(), p=2, dim=1)
+
+
+class EmbeddingService:
+    def __init__(self, allow_synthetic: Optional[bool] = None, device: Optional[str] = None):
+        self.config = self._load_config()
+        if device is not None:
+            self.config["embedding"]["device"] = device
+        if allow_synthetic is None:
+            allow_synthetic = os.getenv("ICD_EMBEDDING_ALLOW_SYNTHETIC", "0") == "1"
+        self._allow_synthetic = allow_synthetic
+        self.model = None
+        self.synthetic = False
+        self.device = self._get_device()
+        self._load_model()
+
+    # ---- configuration (reference :22-45) --------------------------------------------------------------
+    def _load_config(self) -> Dict[str, Any]:
+        return {"embedding": {
+            "model_name": os.getenv("EMBEDDING_MODEL_NAME", DEFAULT_MODEL),
+            "max_length": 512,
+            "batch_size": 32,
+            "device": os.getenv("EMBEDDING_DEVICE", "auto"),
+        }}
+
+    def _get_device(self) -> str:
+        dev = self.config.get("embedding", {}).get("device", "auto")
+        if dev != "auto":
+            return dev
+        if torch.cuda.is_available():
+            return "cuda"
+        if hasattr(torch.backends, "mps") and torch.backends.mps.is_available():
+            return "mps"
+        return "cpu"
+
+    def _load_model(self):
+        name = self.config.get("embedding", {}).get("model_name", DEFAULT_MODEL)
+        if not name:
+            raise ValueError("模型名称不能为空")
+        from transformers import BertConfig, BertModel
+        tok, bert = None, None
+        try:
+            from transformers import AutoModel, AutoTokenizer
+            tok = AutoTokenizer.from_pretrained(name, local_files_only=True)
+            bert = AutoModel.from_pretrained(name, local_files_only=True)
+            self.max_seq_length = int(min(getattr(tok, "model_max_length", 512), 512))
+        except Exception as exc:
+            if not self._allow_synthetic:
+                logger.error("模型加载失败: %s", exc)
+                raise
+            logger.warning("model %s not resolvable offline (%s): using SYNTHETIC weights", name, type(exc).__name__)
+            # shape of shibing624/text2vec-base-chinese (BERT-base, vocab 21128, max_seq_length 128)
+            cfg = BertConfig(vocab_size=21128, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                             intermediate_size=3072, max_position_embeddings=512)
+            gen_state = torch.random.get_rng_state()
+            torch.manual_seed(0)
+            bert = BertModel(cfg, add_pooling_layer=False)
+            torch.random.set_rng_state(gen_state)
+            tok = None
+            self.synthetic = True
+            self.max_seq_length = 128
+        self._tokenizer = tok
+        self._char_tok = _CharTokenizer(bert.config.vocab_size, self.max_seq_length) if tok is None else None
+        dtype = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[os.getenv("ICD_EMBEDDING_DTYPE", "fp32")]
+        self.model = _Encoder(bert).eval().to(self.device)
+        if dtype != torch.float32:
+            self.model.bert.to(dtype)
+        self._dim = int(bert.config.hidden_size)
+
+    # ---- text preparation (reference :68-73) ------------------------------------------------------------
+    def _prepare_text_for_embedding(self, text: str) -> str:
+        if not text.startswith(_PREFIXES):
+            text = f"passage: {text}"
+        return text
+
+    # ---- the forward pass --------------------------------------------------------------------------------
+    def _tokenize(self, texts: List[str]) -> List[List[int]]:
+        if self._tokenizer is not None:
+            enc = self._tokenizer(texts, add_special_tokens=True, truncation=True, max_length=self.max_seq_length)
+            return enc["input_ids"]
+        return [self._char_tok.encode(t) for t in texts]
+
+    def _encode_prepared(self, texts: List[str], batch_size: int, to_device: bool = False):
+        """texts already carry their prefix. Returns float32 [n, dim] (numpy, or a tensor on self.device)."""
+        n = len(texts)
+        out = torch.empty((n, self._dim), dtype=torch.float32, device=self.device)
+        if n == 0:
+            return out if to_device else out.cpu().numpy()
+        ids = self._tokenize(texts)
+        order = sorted(range(n), key=lambda i: -len(ids[i]))  # length buckets: least padding per batch
+        pad = self._tokenizer.pad_token_id if self._tokenizer is not None else _CharTokenizer.pad_id
+        for s in range(0, n, batch_size):
+            idx = order[s:s + batch_size]
+            width = len(ids[idx[0]])
+            tok = torch.full((len(idx), width), pad, dtype=torch.long)
+            mask = torch.zeros((len(idx), width), dtype=torch.long)
+            for r, i in enumerate(idx):
+                tok[r, : len(ids[i])] = torch.tensor(ids[i], dtype=torch.long)
+                mask[r, : len(ids[i])] = 1
+            emb = self.model(tok.to(self.device, non_blocking=True), mask.to(self.device, non_blocking=True))
+            out[torch.tensor(idx, device=self.device)] = emb
+        return out if to_device else out.cpu().numpy()
+
+    # ---- reference API -------------------------------------------------------------------------------------
+    def encode_single(self, text: str) -> np.ndarray:
+        if not self.model:
+            raise RuntimeError("嵌入模型未加载")
+        return self._encode_prepared([self._prepare_text_for_embedding(text)], 1)[0]
+
+    def encode_batch(self, texts: List[str], show_progress: bool = True) -> List[List[float]]:
+        if not self.model:
+            raise RuntimeError("嵌入模型未加载")
+        if not texts:
+            return []
+        prepared = [self._prepare_text_for_embedding(t) for t in texts]
+        bs = self.config.get("embedding", {}).get("batch_size", 32)
+        return self._encode_prepared(prepared, bs).tolist()
+
+    def encode_icd_record(self, icd_record: Dict[str, Any]) -> np.ndarray:
+        name = icd_record.get("preferred_zh", "")
+        if not name.strip():
+            name = f"ICD代码 {icd_record.get('code', 'unknown')}"
+        return self.encode_single(name)
+
+    def encode_query(self, query: str) -> np.ndarray:
+        if self.model is None:  # the reference has no guard here (:117-120): same AttributeError
+            raise AttributeError("'NoneType' object has no attribute 'encode'")
+        return self._encode_prepared([f"query: {query}"], 1)[0]
+
+    def get_model_info(self) -> Dict[str, Any]:
+        if not self.model:
+            return {"loaded": False}
+        return {
+            "loaded": True,
+            "model_name": self.config.get("embedding", {}).get("model_name"),
+            "device": self.device,
+            "max_seq_length": self.max_seq_length,
+            "embedding_dimension": self._dim,
+            "synthetic": self.synthetic,
+        }
+
+    def test_embedding(self, test_text: str = "测试文本") -> Dict[str, Any]:
+        try:
+            emb = self.encode_single(test_text)
+            return {"success": True, "embedding_shape": emb.shape, "embedding_type": str(type(emb)),
+                    "sample_values": emb[:5].tolist()}
+        except Exception as exc:
+            return {"success": False, "error": str(exc)}
+
+    # ---- additive batch entry points ---------------------------------------------------
+    def encode_query_batch(self, queries: List[str], batch_size: int = 256, to_device: bool = False):
+        """encode_query for many strings at once: float32 [n, dim]; with to_device=True the result
+        stays on the GPU for the search kernel."""
+        return self._encode_prepared([f"query: {q}" for q in queries], batch_size, to_device)
+
+    def encode_passage_batch(self, texts: List[str], batch_size: int = 256, to_device: bool = False):
+        return self._encode_prepared([self._prepare_text_for_embedding(t) for t in texts], batch_size, to_device)

@@ -1,0 +1,84 @@
+"""Per-diagnosis embed -> search(2k) -> hierarchical rescoring -> top_k: the serving-time caller of the
+hot path, reduced to the parts that are in scope.
+
+Follows the reference's services/multi_diagnosis_service.py: match_multiple_diagnoses (:51-125) and
+_match_single_diagnosis_enhanced steps 2-4 (:152-175); match confidence is the reference's own
+original formula _calculate_match_confidence (:276-304). NOT reproduced (out of scope, SURVEY.md
+section 2): the NER model (query_entities is {}), the semantic-boundary splitter (delimiter split
+only) and the 12-factor confidence service. Difference by design (row N2): all diagnoses of a
+request are embedded in ONE encoder batch and searched in ONE search_batch call.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Any, Dict, List
+
+from ..api.icd_models import Candidate, DiagnosisMatch
+from ..tools.text_processor import DiagnosisTextProcessor
+from .hierarchical_similarity_service import HierarchicalSimilarityService
+
+logger = logging.getLogger(__name__)
+
+
+class MultiDiagnosisService:
+    def __init__(self, embedding_service, milvus_service):
+        self.embedding_service = embedding_service
+        self.milvus_service = milvus_service
+        self.ner_service = None
+        self.hierarchical_similarity = HierarchicalSimilarityService(embedding_service=embedding_service,
+                                                                     ner_service=None)
+        self.text_processor = DiagnosisTextProcessor(embedding_service=embedding_service)
+
+    def match_multiple_diagnoses(self, text: str, top_k: int = 5) -> Dict[str, Any]:
+        enhanced = self.text_processor.extract_diagnoses_enhanced(text)
+        diagnoses = [d["text"] for d in enhanced]
+        mode = self.text_processor.get_processing_mode()
+        if not diagnoses:
+            return {"original_text": text, "extracted_diagnoses": [], "matches": [], "total_matches": 0,
+                    "processing_mode": mode,
+                    "extraction_metadata": {"enhanced_results_count": 0, "avg_extraction_confidence": 0.0}}
+        confs = [d.get("diagnosis_confidence", 0.5) for d in enhanced]
+        # one encoder batch + one search batch for the whole request
+        vectors = self.embedding_service.encode_query_batch(diagnoses)
+        try:
+            hit_lists = self.milvus_service.search_batch(vectors, top_k * 2, as_dicts=True)
+        except Exception as exc:
+            logger.error("batch search failed: %s", exc)
+            hit_lists = [[] for _ in diagnoses]
+        matches = [self._match_from_hits(d, hits, top_k) for d, hits in zip(diagnoses, hit_lists)]
+        return {"original_text": text, "extracted_diagnoses": diagnoses, "matches": matches,
+                "total_matches": sum(len(m.candidates) for m in matches), "processing_mode": mode,
+                "extraction_metadata": {"enhanced_results_count": len(enhanced),
+                                        "avg_extraction_confidence": sum(confs) / len(confs),
+                                        "extraction_method": "simple", "drug_filtering_enabled": False}}
+
+    def _match_from_hits(self, diagnosis: str, hits: List[Dict[str, Any]], top_k: int) -> DiagnosisMatch:
+        try:
+            rescored = self.hierarchical_similarity.batch_calculate_similarities(diagnosis, {}, hits)
+            candidates = []
+            for rec, score, factors in rescored[:top_k]:
+                cand = Candidate(code=rec.get("code", ""), title=rec.get("title", ""), score=float(score))
+                cand.level = rec.get("level", 1)
+                cand.parent_code = rec.get("parent_code", "")
+                cand.enhanced_score = float(score)
+                cand.original_score = float(rec.get("original_score", 0.0))
+                cand.similarity_factors = factors
+                candidates.append(cand)
+            return DiagnosisMatch(diagnosis_text=diagnosis, candidates=candidates,
+                                  match_confidence=self._calculate_match_confidence(candidates))
+        except Exception as exc:  # e.g. a negative score fails Candidate's ge=0 validator
+            logger.error("match failed for %s: %s", diagnosis, exc)
+            return DiagnosisMatch(diagnosis_text=diagnosis, candidates=[], match_confidence=0.0)
+
+    def _calculate_match_confidence(self, candidates: List[Candidate]) -> float:
+        if not candidates:
+            return 0.0
+        scores = [c.score for c in candidates]
+        best = max(scores)
+        if best > 0.9:
+            conf = min(best, 0.95)
+        elif len([s for s in scores if s > 0.7]) >= 2:
+            conf = best * 0.8
+        else:
+            conf = best * 0.6
+        return round(conf, 3)

@@ -1,0 +1,125 @@
+"""Multi-GPU search: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI).
+
+The reference is single-process (SURVEY.md section 5 "Distributed communication backend: none"); this
+is new functionality required by the scaling configs:
+
+  * query-sharded  (config 4): the corpus is replicated, rank r searches its slice of the queries.
+    No collective on the data path; `gather=True` adds one all-gather of the (small) results.
+  * row-sharded    (config 5): rank r owns rows [base_r, base_r + n_r) with global ids; every rank
+    scores ALL queries against its shard, then ONE all-gather moves the per-shard partial top-k
+    (16 B per hit: raw score f32 | id i64 | level i32) and every rank merges the G lists per query
+    (global top-k by (score desc, id asc)), applies the level reweight and the stable re-sort.
+    At Q = 100 000, k = 10 that is 16 MB per rank - microseconds over xGMI next to ~100 ms of MFMA
+    work, so no ring/all-reduce is involved.
+
+The local search and the merge are injected callables: by default the HIP index / HIP merge kernel;
+the CPU (gloo, world_size 2) tests inject the oracle so the sharding + collective logic is covered
+without a GPU.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+QUERY_SHARD = "query"
+ROW_SHARD = "row"
+
+
+def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous split of n items over `world` ranks (first n % world ranks get one more)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_hits(scores: torch.Tensor, ids: torch.Tensor, levels: torch.Tensor) -> torch.Tensor:
+    """[nq,k] f32 / i64 / i32 -> one int32 tensor [nq,k,4] (a single all-gather payload)."""
+    out = torch.empty(scores.shape + (4,), dtype=torch.int32, device=scores.device)
+    out[..., 0] = scores.contiguous().view(torch.int32)
+    out[..., 1:3] = ids.contiguous().view(torch.int32).view(ids.shape + (2,))
+    out[..., 3] = levels
+    return out
+
+
+def unpack_hits(buf: torch.Tensor):
+    scores = buf[..., 0].contiguous().view(torch.float32)
+    ids = buf[..., 1:3].contiguous().view(torch.int64).squeeze(-1)
+    levels = buf[..., 3].contiguous()
+    return scores, ids, levels
+
+
+class ShardedSearch:
+    """search_fn(queries, k)  -> (raw f32 [nq,k], global ids i64 [nq,k], levels i32 [nq,k])   local shard / replica
+       merge_fn(scores[G,nq,k], ids[G,nq,k], levels[G,nq,k], k) -> (adj f64, raw f32, ids i64, levels i32) [nq,k]
+       local_reweighted_fn(queries, k) -> (adj, raw, ids, levels)  (query-sharded mode)"""
+
+    def __init__(self, mode: str, search_fn: Optional[Callable] = None, merge_fn: Optional[Callable] = None,
+                 local_reweighted_fn: Optional[Callable] = None, group=None):
+        if mode not in (QUERY_SHARD, ROW_SHARD):
+            raise ValueError(f"mode must be '{QUERY_SHARD}' or '{ROW_SHARD}'")
+        self.mode = mode
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.search_fn = search_fn
+        self.merge_fn = merge_fn
+        self.local_reweighted_fn = local_reweighted_fn
+
+    # ---- construction over the HIP index ---------------------------------------------------------------
+    @classmethod
+    def from_index(cls, index, mode: str, group=None) -> "ShardedSearch":
+        """index: rag_project_icd10_amd._native.IcdIndex over this rank's shard (row mode, created with
+        id_base = first global row) or over the full corpus (query mode)."""
+        from . import _native
+
+        def search_fn(q, k):
+            raw, ids = index.search(q, k)
+            return raw, ids, index.lookup_levels(ids)
+
+        return cls(mode, search_fn=search_fn, merge_fn=_native.merge_topk,
+                   local_reweighted_fn=index.search_reweighted, group=group)
+
+    # ---- search ---------------------------------------------------------------------------------------------
+    def search_reweighted(self, queries: torch.Tensor, k: int, gather: bool = True):
+        """Row mode: `queries` is the full batch on every rank -> identical (adj, raw, ids, levels) on
+        every rank. Query mode: `queries` is the full batch on every rank; rank r searches its slice
+        and, with gather=True, all ranks receive the full result (else only the local slice)."""
+        if self.mode == ROW_SHARD:
+            raw, ids, levels = self.search_fn(queries, k)
+            payload = pack_hits(raw, ids, levels)
+            if self.world > 1:
+                payload = payload.contiguous()
+                flat = torch.empty((self.world * payload.shape[0],) + payload.shape[1:], dtype=payload.dtype,
+                                   device=payload.device)  # concatenated form: accepted by nccl and gloo
+                dist.all_gather_into_tensor(flat, payload, group=self.group)
+                gathered = flat.view((self.world,) + payload.shape)
+            else:
+                gathered = payload.unsqueeze(0)
+            s, i, l = unpack_hits(gathered)
+            return self.merge_fn(s, i, l, k)
+        # query-sharded
+        nq = queries.shape[0]
+        lo, hi = shard_bounds(nq, self.world, self.rank)
+        adj, raw, ids, levels = self.local_reweighted_fn(queries[lo:hi], k)
+        if not gather or self.world == 1:
+            return adj, raw, ids, levels
+        width = -(-nq // self.world)  # pad every slice to the same length for one all-gather
+        dev = adj.device
+        pay = torch.zeros((width, k, 6), dtype=torch.int32, device=dev)
+        m = hi - lo
+        pay[:m, :, 0:2] = adj.contiguous().view(torch.int32).view(m, k, 2)
+        pay[:m, :, 2] = raw.contiguous().view(torch.int32)
+        pay[:m, :, 3:5] = ids.contiguous().view(torch.int32).view(m, k, 2)
+        pay[:m, :, 5] = levels
+        flat = torch.empty((self.world * width, k, 6), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(flat, pay, group=self.group)
+        gathered = flat.view(self.world, width, k, 6)
+        parts = []
+        for r in range(self.world):
+            a, b = shard_bounds(nq, self.world, r)
+            parts.append(gathered[r, : b - a])
+        full = torch.cat(parts, 0)
+        return (full[..., 0:2].contiguous().view(torch.float64).squeeze(-1), full[..., 2].contiguous().view(torch.float32),
+                full[..., 3:5].contiguous().view(torch.int64).squeeze(-1), full[..., 5].contiguous())

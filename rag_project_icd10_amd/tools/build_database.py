@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Batch corpus build: CSV -> records with ICD hierarchy -> embeddings -> on-disk corpus -> HBM index.
+
+Drop-in for the reference's tools/build_database.py (same class, methods and CLI flags). CSV / hierarchy
+semantics follow :62-126 (load_csv_data), :128-154 (_parse_hierarchy), :156-171 (_build_semantic_text),
+:183-192 (batch-size rule) and are pinned by tests/golden/csv_records.json and csv_full_digest.json
+(outputs of the reference itself). Difference by design: the reference runs one
+batch-1 forward per record; here each insert batch is encoded in ONE bucketed forward on the GPU
+(`encode_query_batch`) - same text ("query: " + semantic_text, :220-221), same rows, same order.
+
+    python -m rag_project_icd10_amd.tools.build_database --input data/ICD_10v601.csv [--rebuild] [--verify-only]
+"""
+from __future__ import annotations
+
+import logging
+import os
+import sys
+from typing import Any, Dict, List
+
+import numpy as np
+
+logger = logging.getLogger(__name__)
+
+
+class DatabaseBuilder:
+    def __init__(self):
+        self.embedding_service = None
+        self.milvus_service = None
+
+    # ---- services (reference :30-60) -------------------------------------------------------------------
+    def initialize_services(self):
+        from ..services.embedding_service import EmbeddingService
+        from ..services.milvus_service import MilvusService
+        self.embedding_service = EmbeddingService()
+        test = self.embedding_service.test_embedding("测试")
+        if not test.get("success"):
+            raise Exception(f"向量化服务测试失败: {test.get('error')}")
+        self.milvus_service = MilvusService(embedding_service=self.embedding_service)
+        conn = self.milvus_service.test_connection()
+        if not conn.get("connected"):
+            raise Exception(f"Milvus连接失败: {conn.get('error')}")
+
+    # ---- CSV -> records ----------------------------------------------------------------------------------
+    def load_csv_data(self, input_file: str) -> List[Dict]:
+        import pandas as pd
+        df = pd.read_csv(input_file, encoding="utf-8")
+        codes = df["code"] if "code" in df.columns else [""] * len(df)
+        names = df["disease"] if "disease" in df.columns else [""] * len(df)
+        records: List[Dict[str, Any]] = []
+        seen_names: Dict[str, str] = {}  # code -> disease of every row streamed so far (order matters)
+        for raw_code, raw_name in zip(codes, names):
+            code, disease = str(raw_code).strip(), str(raw_name).strip()
+            if not code or not disease or code == "nan" or disease == "nan":
+                continue
+            main_code, secondary_code, has_complication = code, "", False
+            if "+" in code and "*" in code:
+                parts = code.split("+")
+                if len(parts) == 2:
+                    main_code = parts[0].strip()
+                    secondary_code = parts[1].replace("*", "").strip()
+                    has_complication = True
+            level, parent_code, category_path = self._parse_hierarchy(code, seen_names)
+            records.append({
+                "code": code,
+                "preferred_zh": disease,
+                "main_code": main_code,
+                "secondary_code": secondary_code,
+                "has_complication": has_complication,
+                "level": level,
+                "parent_code": parent_code,
+                "category_path": category_path,
+                "semantic_text": self._build_semantic_text(code, disease, category_path, seen_names),
+            })
+            seen_names[code] = disease
+        self._log_hierarchy_stats(records)
+        return records
+
+    def _parse_hierarchy(self, code: str, parent_info: Dict[str, str]) -> tuple:
+        if "." not in code:
+            return 1, "", code
+        head, _, tail = code.partition(".")
+        if code.count(".") == 1 and len(tail) <= 1:
+            return 2, head, f"{head} > {code}"
+        sub = code.split(".")[1]
+        if len(sub) >= 3:
+            parent = f"{head}.{sub[0]}"
+            return 3, parent, f"{head} > {parent} > {code}"
+        return 3, head, f"{head} > {code}"
+
+    def _build_semantic_text(self, code: str, disease: str, category_path: str, parent_info: Dict[str, str]) -> str:
+        parts = [disease]
+        for ancestor in category_path.split(" > ")[:-1]:
+            name = parent_info.get(ancestor)
+            if name is not None and name not in parts:
+                parts.append(name)
+        parts.append(f"ICD-10: {code}")
+        return " | ".join(parts)
+
+    def _log_hierarchy_stats(self, records: List[Dict]):
+        counts = {1: 0, 2: 0, 3: 0}
+        for r in records:
+            if r.get("level", 0) in counts:
+                counts[r["level"]] += 1
+        logger.info("层级统计 - 主类: %d, 亚类: %d, 细分类: %d", counts[1], counts[2], counts[3])
+
+    def _calculate_optimal_batch_size(self, total_records: int) -> int:
+        if total_records < 1000:
+            return 32
+        if total_records < 10000:
+            return 64
+        if total_records < 50000:
+            return 128
+        return 256
+
+    # ---- embed + insert -------------------------------------------------------------------------------------
+    def vectorize_and_index(self, records: List[Dict], encode_batch: int = 2048) -> bool:
+        try:
+            insert_batch = self._calculate_optimal_batch_size(len(records))
+            # encode in large bucketed batches, insert in the reference's batch size (:183-192,:240)
+            for start in range(0, len(records), encode_batch):
+                chunk = records[start:start + encode_batch]
+                texts = [r.get("semantic_text", r.get("preferred_zh", "")) for r in chunk]
+                vectors = self.embedding_service.encode_query_batch(texts)
+                for s in range(0, len(chunk), insert_batch):
+                    rows = chunk[s:s + insert_batch]
+                    ok = self.milvus_service.insert_records(rows, list(vectors[s:s + insert_batch]))
+                    if not ok:
+                        logger.error("批次 %d 插入失败", (start + s) // insert_batch + 1)
+                        return False
+            if not self.milvus_service.load_collection():
+                logger.warning("集合加载失败，但数据插入成功")
+            return True
+        except Exception as exc:
+            logger.error("向量化和索引失败: %s", exc)
+            return False
+
+    def verify_database(self) -> Dict[str, Any]:
+        try:
+            stats = self.milvus_service.get_collection_stats()
+            if not self.milvus_service.load_collection():
+                logger.warning("集合加载失败，可能影响搜索结果")
+            vec = self.embedding_service.encode_query("急性胃肠炎")
+            hits = self.milvus_service.search(vec, top_k=5)
+            return {"database_stats": stats,
+                    "search_test": {"query": "急性胃肠炎", "results_count": len(hits), "top_results": hits[:3] if hits else []}}
+        except Exception as exc:
+            logger.error("数据库验证失败: %s", exc)
+            return {"error": str(exc)}
+
+    def build_full_database(self, input_file: str = "data/ICD_10v601.csv", rebuild: bool = False) -> bool:
+        try:
+            self.initialize_services()
+            if rebuild:
+                self.milvus_service.clear_collection()
+            records = self.load_csv_data(input_file)
+            if not self.vectorize_and_index(records):
+                return False
+            verification = self.verify_database()
+            if "error" in verification:
+                logger.error("数据库验证失败: %s", verification["error"])
+                return False
+            logger.info("最终统计: %s", verification["database_stats"])
+            return True
+        except Exception as exc:
+            logger.error("数据库构建失败: %s", exc)
+            return False
+
+
+def main():
+    import argparse
+    parser = argparse.ArgumentParser(description="ICD数据库构建工具（MI355X）")
+    parser.add_argument("--input", default="data/ICD_10v601.csv", help="输入CSV文件路径")
+    parser.add_argument("--rebuild", action="store_true", help="重建数据库（清空现有数据）")
+    parser.add_argument("--verify-only", action="store_true", help="仅验证现有数据库")
+    args = parser.parse_args()
+    logging.basicConfig(level=logging.INFO)
+    builder = DatabaseBuilder()
+    try:
+        if args.verify_only:
+            builder.initialize_services()
+            verification = builder.verify_database()
+            if "error" not in verification:
+                print("数据库状态正常")
+                return True
+            return False
+        ok = builder.build_full_database(args.input, rebuild=args.rebuild)
+        print("数据库构建完成" if ok else "数据库构建失败")
+        return ok
+    except KeyboardInterrupt:
+        print("操作已中断")
+        return False
+    except Exception as exc:
+        print(f"错误: {exc}")
+        return False
+
+
+if __name__ == "__main__":
+    sys.exit(0 if main() else 1)

@@ -1,0 +1,41 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def unit_rows(n, dim, seed, kind="gauss"):
+    """Synthetic corpora/queries. gauss: iid N(0,1) rows L2-normalised (adversarial near-ties);
+    clustered: 64 centroids + noise (text-embedding-like, forces the exact fallback)."""
+    rng = np.random.default_rng(seed)
+    if kind == "clustered":
+        cent = rng.standard_normal((64, dim)).astype(np.float32)
+        x = cent[rng.integers(0, 64, n)] + 0.05 * rng.standard_normal((n, dim)).astype(np.float32)
+    else:
+        x = rng.standard_normal((n, dim)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def icd_levels(n, seed):
+    """levels drawn from the real CSV histogram 12.43 % / 29.91 % / 57.66 %."""
+    r = np.random.default_rng(seed).random(n)
+    return np.where(r < 0.1243, 1, np.where(r < 0.4234, 2, 3)).astype(np.int32)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc  # noqa
+    orc.build()
+    return orc

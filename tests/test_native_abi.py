@@ -1,0 +1,57 @@
+"""The C-ABI library loads and exports every symbol include/icd_search.h declares (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+from rag_project_icd10_amd import _native
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "icd_search.h"), encoding="utf-8").read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(icd_[a-z_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _native.load_library()
+    names = _declared_functions()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), n
+    assert set(names) == set(_native.EXPORTED_SYMBOLS)
+    assert lib.icd_abi_version() == 1
+
+
+def test_error_reporting_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this case checks the no-GPU error path")
+    lib = _native.load_library()
+    assert lib.icd_device_count() < 0
+    assert b"hipGetDeviceCount" in lib.icd_last_error()
+    with pytest.raises(_native.IcdError) as e:
+        _native.IcdIndex(np.zeros((4, 768), np.float32))
+    assert e.value.code < 0 and "libicdsearch error" in str(e.value)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(ImportError) as e:
+        _native.load_library(str(tmp_path / "nope.so"))
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_argument_validation_needs_no_gpu():
+    lib = _native.load_library()
+    out = ctypes.c_void_p()
+    buf = np.zeros((2, 64), np.float32)
+    assert lib.icd_index_create(None, 2, 64, None, 0, 0, 1, 1, 0, ctypes.byref(out)) == -1   # ICD_ERR_INVALID
+    assert lib.icd_index_create(buf.ctypes.data, 2, 50, None, 0, 0, 1, 1, 0, ctypes.byref(out)) == -4  # dim % 32
+    assert b"multiple of 32" in lib.icd_last_error()
+    assert lib.icd_index_create(buf.ctypes.data, 2, 64, None, 0, 0, 1, 500, 0, ctypes.byref(out)) == -1  # max_k
+    assert lib.icd_index_destroy(None) == -5 and lib.icd_index_stats(None, None) == -5
+    assert lib.icd_merge_topk(0, None, None, None, 1, 1, 1, None, None, None, None, None) == -1
