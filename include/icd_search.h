@@ -159,6 +159,10 @@ int icd_index_debug_counters(icd_index *idx, unsigned long long *out, int32_t co
 int icd_index_set_profiling(icd_index *idx, int32_t enabled);
 /* Synchronises the events of the most recent search and fills `out`. */
 int icd_index_last_profile(icd_index *idx, icd_profile *out);
+/* Mean per-kernel times over the profiled searches since the previous summary (at most the last 128),
+ * and how many were averaged; resets the window. The events are recorded on the search stream, so this
+ * measures the kernels inside a timed region without a synchronisation per search. */
+int icd_index_profile_summary(icd_index *idx, icd_profile *out_mean, int32_t *out_count);
 
 #ifdef __cplusplus
 }

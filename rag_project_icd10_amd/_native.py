@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = (
     "icd_abi_version", "icd_last_error", "icd_device_count", "icd_index_create", "icd_index_destroy",
     "icd_index_search", "icd_index_search_reweighted", "icd_merge_topk", "icd_index_lookup_levels",
     "icd_index_stats", "icd_index_set_chunks", "icd_index_debug_counters", "icd_index_set_profiling",
-    "icd_index_last_profile",
+    "icd_index_last_profile", "icd_index_profile_summary",
 )
 
 
@@ -79,6 +79,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.icd_index_debug_counters.argtypes = [vp, vp, i32]
     lib.icd_index_set_profiling.argtypes = [vp, i32]
     lib.icd_index_last_profile.argtypes = [vp, C.POINTER(_Profile)]
+    lib.icd_index_profile_summary.argtypes = [vp, C.POINTER(_Profile), C.POINTER(C.c_int32)]
     for name in EXPORTED_SYMBOLS:
         getattr(lib, name)  # AttributeError if the build is stale
     if path is None:
@@ -293,6 +294,18 @@ class IcdIndex:
         p = _Profile()
         _check(self._lib, self._lib.icd_index_last_profile(self._h, C.byref(p)))
         return {f: float(getattr(p, f)) for f, _ in _Profile._fields_}
+
+
+def _profile_summary(self) -> dict:
+    """Mean per-kernel ms over the profiled searches since the last summary (events on the search stream)."""
+    p, n = _Profile(), C.c_int32(0)
+    _check(self._lib, self._lib.icd_index_profile_summary(self._h, C.byref(p), C.byref(n)))
+    out = {f: float(getattr(p, f)) for f, _ in _Profile._fields_}
+    out["count"] = int(n.value)
+    return out
+
+
+IcdIndex.profile_summary = _profile_summary
 
 
 def merge_topk(scores, ids, levels, k: int):

@@ -44,6 +44,7 @@ constexpr float EPS_REL = 1.2e-3f;
 constexpr int FAST_MAX_K = 12;       // coarse lists hold KP = 16 candidates per chunk
 constexpr int COARSE_MAX_P = 32;     // P * KP <= FIN_MAX_CAND
 constexpr int NUM_EV = 6;
+constexpr int EV_RING = 128;         // profiled searches kept for icd_index_profile_summary
 
 template <typename T>
 hipError_t dmalloc(T **p, size_t count) {
@@ -82,8 +83,11 @@ struct icd_index {
     // knobs / counters
     int chunks_override = 0;
     bool profiling = false;
-    hipEvent_t ev[NUM_EV + 1] = {};
-    bool ev_valid[NUM_EV + 1] = {};
+    hipEvent_t evring[EV_RING][NUM_EV + 1] = {};
+    bool evring_valid[EV_RING][NUM_EV + 1] = {};
+    long prof_count = 0;           // profiled searches since the last summary
+    hipEvent_t *ev = evring[0];    // event set of the current / most recent search
+    bool *ev_valid = evring_valid[0];
     int64_t last_nq = 0;
     int last_chunks = 0, last_mode = 0;
     int *h_nflag = nullptr;  // pinned
@@ -103,8 +107,9 @@ void free_all(icd_index *x) {
     hipFree(x->o_adj_ids); hipFree(x->o_adj_lv);
     hipFree(x->dbg);
     if (x->h_nflag) hipHostFree(x->h_nflag);
-    for (int i = 0; i <= NUM_EV; ++i)
-        if (x->ev[i]) hipEventDestroy(x->ev[i]);
+    for (int r = 0; r < EV_RING; ++r)
+        for (int i = 0; i <= NUM_EV; ++i)
+            if (x->evring[r][i]) hipEventDestroy(x->evring[r][i]);
     x->magic = 0;
     delete x;
 }
@@ -190,6 +195,12 @@ struct Outs {
 int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const Outs &o, hipStream_t s) {
     const int row_tiles = (int)((x->n + 127) / 128);
     const bool use_fast = (mode == ICD_MODE_AUTO) && x->fast && k <= FAST_MAX_K && (x->dim == 768 || x->dim == 1024);
+    if (x->profiling) {
+        const int slot = (int)(x->prof_count % EV_RING);
+        x->ev = x->evring[slot];
+        x->ev_valid = x->evring_valid[slot];
+        ++x->prof_count;
+    }
     for (int i = 0; i <= NUM_EV; ++i) x->ev_valid[i] = false;
     x->last_nq = nq;
     x->last_mode = use_fast ? ICD_MODE_AUTO : ICD_MODE_EXACT;
@@ -409,7 +420,8 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     CR_TRY(wsalloc(&x->o_adj_raw, no)); CR_TRY(wsalloc(&x->o_adj_ids, no)); CR_TRY(wsalloc(&x->o_adj_lv, no));
     CR_TRY(hipHostMalloc(reinterpret_cast<void **>(&x->h_nflag), sizeof(int), hipHostMallocDefault));
     *x->h_nflag = 0;
-    for (int i = 0; i <= NUM_EV; ++i) CR_TRY(hipEventCreate(&x->ev[i]));
+    for (int r = 0; r < EV_RING; ++r)
+        for (int i = 0; i <= NUM_EV; ++i) CR_TRY(hipEventCreate(&x->evring[r][i]));
     CR_TRY(hipDeviceSynchronize());
     x->bytes_ws = ws;
 #undef CR_TRY
@@ -556,6 +568,42 @@ int icd_index_debug_counters(icd_index *idx, unsigned long long *out, int32_t co
 int icd_index_set_profiling(icd_index *idx, int32_t enabled) {
     if (!valid(idx)) return fail(ICD_ERR_STATE, "invalid handle");
     idx->profiling = enabled != 0;
+    return ICD_OK;
+}
+
+int icd_index_profile_summary(icd_index *idx, icd_profile *out_mean, int32_t *out_count) {
+    if (!valid(idx)) return fail(ICD_ERR_STATE, "invalid handle");
+    if (!out_mean || !out_count) return fail(ICD_ERR_INVALID, "out is NULL");
+    memset(out_mean, 0, sizeof *out_mean);
+    HIP_TRY(hipSetDevice(idx->device));
+    const long total = idx->prof_count;
+    const int n = (int)std::min<long>(total, EV_RING);
+    int used = 0;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < n; ++j) {
+        const int slot = (int)((total - 1 - j) % EV_RING);
+        hipEvent_t *ev = idx->evring[slot];
+        const bool *ok = idx->evring_valid[slot];
+        if (!ok[0] || !ok[NUM_EV]) continue;
+        HIP_TRY(hipEventSynchronize(ev[NUM_EV]));
+        auto span = [&](int a, int b) -> double {
+            float ms = 0.f;
+            if (ok[a] && ok[b]) hipEventElapsedTime(&ms, ev[a], ev[b]);
+            return ms;
+        };
+        acc[0] += span(0, 1); acc[1] += span(1, 2); acc[2] += span(2, 3); acc[3] += span(3, 4);
+        acc[4] += span(4, 5); acc[5] += span(0, NUM_EV);
+        ++used;
+    }
+    if (used) {
+        out_mean->ms_prep = (float)(acc[0] / used); out_mean->ms_coarse = (float)(acc[1] / used);
+        out_mean->ms_finalize = (float)(acc[2] / used); out_mean->ms_exact = (float)(acc[3] / used);
+        out_mean->ms_exact_finalize = (float)(acc[4] / used); out_mean->ms_total = (float)(acc[5] / used);
+    }
+    *out_count = used;
+    idx->prof_count = 0;
+    for (int r = 0; r < EV_RING; ++r)
+        for (int i = 0; i <= NUM_EV; ++i) idx->evring_valid[r][i] = false;
     return ICD_OK;
 }
 

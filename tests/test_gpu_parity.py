@@ -1,0 +1,238 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI
+(ctypes -> libicdsearch.so), against the CPU oracle on the same seeded inputs.
+
+Bar: ids bit-exact; scores bit-identical fp32 (tolerance 0 - stricter than the 1e-5 the north star
+allows, possible because kernels and oracle share one canonical summation order); reweighted scores
+bit-identical float64. At BASELINE.json's full sizes the oracle only checks a query sample and the
+rest is covered by size-independent properties (sortedness, idempotence, mode agreement, monotone
+prefix in k, shard-merge equivalence).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import icd_levels, unit_rows
+
+pytestmark = pytest.mark.gpu
+
+from rag_project_icd10_amd import _native  # noqa: E402
+from rag_project_icd10_amd._native import MODE_AUTO, MODE_EXACT, IcdIndex  # noqa: E402
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).tobytes()
+
+
+def _check(oracle, index, corpus, levels, queries, k, mode, id_base=0):
+    s, i = index.search(queries, k, mode)
+    os_, oi = oracle.flat_ip_topk(corpus, queries, k, id_base=id_base)
+    assert np.array_equal(i, oi), f"id mismatch rows {np.nonzero((i != oi).any(1))[0][:5]}"
+    assert _bits(s) == _bits(os_)
+    adj, raw, ids, lv = index.search_reweighted(queries, k, mode)
+    want = oracle.reweight(os_, oi, levels, id_base=id_base)
+    assert np.array_equal(ids, want[2]) and _bits(adj) == _bits(want[0]) and _bits(raw) == _bits(want[1])
+    assert np.array_equal(lv, want[3])
+    return index.stats()
+
+
+CASES = [  # n, nq, dim, k, kind
+    (100, 3, 768, 5, "gauss"), (7, 2, 768, 10, "gauss"), (1000, 37, 768, 10, "gauss"), (2049, 5, 768, 1, "gauss"),
+    (4000, 129, 768, 12, "gauss"), (1500, 20, 1024, 10, "gauss"), (6000, 200, 768, 10, "clustered"),
+    (128, 128, 768, 10, "gauss"), (129, 1, 768, 10, "gauss"),
+]
+
+
+@pytest.mark.parametrize("mode", [MODE_AUTO, MODE_EXACT])
+@pytest.mark.parametrize("n,nq,dim,k,kind", CASES)
+def test_parity_small(oracle, n, nq, dim, k, kind, mode):
+    corpus, levels, queries = unit_rows(n, dim, 1 + n, kind), icd_levels(n, 2 + n), unit_rows(nq, dim, 3 + n, kind)
+    idx = IcdIndex(corpus, levels, max_nq=max(nq, 1), max_k=max(k, 1))
+    st = _check(oracle, idx, corpus, levels, queries, k, mode)
+    assert st["n"] == n and st["dim"] == dim
+    if mode == MODE_AUTO:
+        assert st["last_mode"] == MODE_AUTO and st["fast_path"] == 1
+    idx.close()
+
+
+@pytest.mark.parametrize("k", [17, 64, 100])
+def test_large_k_uses_exact_kernel(oracle, k):
+    corpus, levels, queries = unit_rows(5000, 768, 40), icd_levels(5000, 41), unit_rows(9, 768, 42)
+    idx = IcdIndex(corpus, levels, max_nq=16, max_k=100)
+    st = _check(oracle, idx, corpus, levels, queries, k, MODE_AUTO)
+    assert st["last_mode"] == MODE_EXACT      # AUTO routes k > 12 to the fp32 kernel
+    idx.close()
+
+
+def test_exact_ties_and_id_base(oracle):
+    corpus = unit_rows(3001, 768, 50)
+    corpus[5::5] = corpus[np.arange(5, 3001, 5) // 2]       # duplicate rows: exact score ties, broken by id
+    levels, queries = icd_levels(3001, 51), unit_rows(70, 768, 52)
+    for mode in (MODE_AUTO, MODE_EXACT):
+        idx = IcdIndex(corpus, levels, max_nq=70, max_k=10, id_base=1_000_000)
+        _check(oracle, idx, corpus, levels, queries, 10, mode, id_base=1_000_000)
+        idx.close()
+
+
+def test_dim_other_than_fast_path(oracle):
+    corpus, levels, queries = unit_rows(900, 64, 60), icd_levels(900, 61), unit_rows(11, 64, 62)
+    idx = IcdIndex(corpus, levels, max_nq=16, max_k=10)
+    assert idx.stats()["fast_path"] == 0
+    _check(oracle, idx, corpus, levels, queries, 5, MODE_AUTO)
+    idx.close()
+    with pytest.raises(_native.IcdError):
+        IcdIndex(unit_rows(10, 50, 1))                          # dim % 32 != 0 -> ICD_ERR_UNSUPPORTED
+
+
+def test_unnormalised_and_nonfinite_inputs(oracle):
+    rng = np.random.default_rng(70)
+    corpus = (rng.standard_normal((2000, 768)) * rng.uniform(0.1, 30, (2000, 1))).astype(np.float32)
+    levels = icd_levels(2000, 71)
+    queries = (rng.standard_normal((33, 768)) * 5).astype(np.float32)
+    idx = IcdIndex(corpus, levels, max_nq=64, max_k=10)
+    _check(oracle, idx, corpus, levels, queries, 10, MODE_AUTO)   # error bound scales with ||q|| * rmax
+    queries[3, 10] = 1e6                                          # not representable in fp16 -> exact fallback
+    st = _check(oracle, idx, corpus, levels, queries, 10, MODE_AUTO)
+    assert st["last_fallback"] >= 1
+    idx.close()
+    corpus[17, 5] = 7e4                                           # corpus not representable in fp16
+    idx = IcdIndex(corpus, levels, max_nq=64, max_k=10)
+    assert idx.stats()["fast_path"] == 0
+    _check(oracle, idx, corpus, levels, queries[:8], 10, MODE_AUTO)
+    idx.close()
+
+
+def test_real_corpus_size_and_reference_call_shape(oracle):
+    """N = 40 474 (the real CSV's row count), nq = 1 per call - how MilvusService.search drives the engine."""
+    corpus, levels = unit_rows(40474, 768, 80), icd_levels(40474, 81)
+    queries = unit_rows(6, 768, 82)
+    idx = IcdIndex(corpus, levels, max_nq=256, max_k=100)
+    for r in range(3):
+        _check(oracle, idx, corpus, levels, queries[r:r + 1], 5, MODE_AUTO)
+    _check(oracle, idx, corpus, levels, queries, 10, MODE_AUTO)
+    _check(oracle, idx, corpus, levels, queries[:2], 100, MODE_AUTO)   # /query's top_k*2 upper bound (F7)
+    idx.close()
+
+
+def test_full_size_config2_properties(oracle):
+    """BASELINE configs[1]: 10 000 queries x 37 000 x 768, k = 10."""
+    n, nq, k = 37000, 10000, 10
+    corpus = unit_rows(n, 768, 1234)
+    levels = icd_levels(n, 1235)
+    queries = unit_rows(nq, 768, 4321)
+    idx = IcdIndex(corpus, levels, max_nq=nq, max_k=k)
+    s, i = idx.search(queries, k, MODE_AUTO)
+    st = idx.stats()
+    assert (i >= 0).all() and (i < n).all()
+    assert (np.diff(s, axis=1) <= 0).all()                                    # sorted best-first
+    assert all(len(set(r)) == k for r in i[::97])                              # no duplicate ids
+    s2, i2 = idx.search(queries, k, MODE_AUTO)
+    assert np.array_equal(i, i2) and _bits(s) == _bits(s2)                     # idempotent
+    sample = np.arange(0, nq, 53)
+    os_, oi = oracle.flat_ip_topk(corpus, queries[sample], k)                  # oracle on a sample
+    assert np.array_equal(i[sample], oi) and _bits(s[sample]) == _bits(os_)
+    recall = np.mean([len(set(a) & set(b)) / k for a, b in zip(i[sample], oi)])
+    assert recall == 1.0                                                       # recall@10 vs the exact reference
+    se, ie = idx.search(queries[:1024], k, MODE_EXACT)                         # fast path == exact kernel
+    assert np.array_equal(ie, i[:1024]) and _bits(se) == _bits(s[:1024])
+    s5, i5 = idx.search(queries[:512], 5, MODE_AUTO)                           # top-5 is a prefix of top-10
+    assert np.array_equal(i5, i[:512, :5]) and _bits(s5) == _bits(s[:512, :5])
+    assert st["last_fallback"] <= nq // 100                                    # certification rarely fails on this data
+    adj, raw, ids, lv = idx.search_reweighted(queries, k, MODE_AUTO)
+    want = oracle.reweight(s, i, levels)
+    assert np.array_equal(ids, want[2]) and _bits(adj) == _bits(want[0])
+    assert (np.diff(adj, axis=1) <= 0).all()
+    idx.close()
+
+
+def test_device_tensor_path_and_merge_kernel(oracle):
+    import torch
+    n, nq, k = 5000, 300, 10
+    corpus, levels, queries = unit_rows(n, 768, 90), icd_levels(n, 91), unit_rows(nq, 768, 92)
+    dq = torch.from_numpy(queries).cuda()
+    full = IcdIndex(torch.from_numpy(corpus).cuda(), levels, max_nq=nq, max_k=k)   # corpus handed over on device
+    s, i = full.search(dq, k)
+    os_, oi = oracle.flat_ip_topk(corpus, queries, k)
+    assert s.is_cuda and np.array_equal(i.cpu().numpy(), oi) and _bits(s.cpu().numpy()) == _bits(os_)
+    # row-sharded: 3 uneven shards with global ids -> gather -> merge kernel == single index
+    bounds = [(0, 1700), (1700, 1701), (1701, n)]
+    parts = []
+    for lo, hi in bounds:
+        sh = IcdIndex(corpus[lo:hi], levels[lo:hi], max_nq=nq, max_k=k, id_base=lo)
+        ps, pi = sh.search(dq, k)
+        parts.append((ps, pi, sh.lookup_levels(pi)))
+        sh.close()
+    adj, raw, ids, lv = _native.merge_topk(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]),
+                                           torch.stack([p[2] for p in parts]), k)
+    want = oracle.reweight(os_, oi, levels)
+    assert np.array_equal(ids.cpu().numpy(), want[2]) and _bits(adj.cpu().numpy()) == _bits(want[0])
+    assert _bits(raw.cpu().numpy()) == _bits(want[1]) and np.array_equal(lv.cpu().numpy(), want[3])
+    a2 = full.search_reweighted(dq, k)
+    assert torch.equal(a2[2], ids) and torch.equal(a2[0], adj)
+    full.close()
+
+
+def test_sharded_search_single_rank_nccl(oracle):
+    """ShardedSearch over the HIP index with a 1-rank RCCL group (the multi-rank logic is covered by the gloo tests)."""
+    import torch
+    import torch.distributed as dist
+    from rag_project_icd10_amd.sharded import ROW_SHARD, ShardedSearch
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29611")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        n, nq, k = 3000, 64, 10
+        corpus, levels, queries = unit_rows(n, 768, 95), icd_levels(n, 96), unit_rows(nq, 768, 97)
+        idx = IcdIndex(corpus, levels, max_nq=nq, max_k=k)
+        eng = ShardedSearch.from_index(idx, ROW_SHARD)
+        adj, raw, ids, lv = eng.search_reweighted(torch.from_numpy(queries).cuda(), k)
+        os_, oi = oracle.flat_ip_topk(corpus, queries, k)
+        want = oracle.reweight(os_, oi, levels)
+        assert np.array_equal(ids.cpu().numpy(), want[2]) and _bits(adj.cpu().numpy()) == _bits(want[0])
+        idx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_services_end_to_end_on_gpu(oracle, tmp_path, monkeypatch):
+    """csv slice -> DatabaseBuilder (batched encode on ROCm) -> MilvusService.search: every row retrieves itself,
+    and the hit dicts have the reference's shape and its level reweight."""
+    from conftest import GOLDEN
+    monkeypatch.setenv("MILVUS_DB_PATH", str(tmp_path / "db"))
+    monkeypatch.setenv("MILVUS_COLLECTION_NAME", "icd10_test")
+    monkeypatch.setenv("EMBEDDING_MODEL_NAME", "shibing624/text2vec-base-chinese")
+    monkeypatch.setenv("ICD_EMBEDDING_ALLOW_SYNTHETIC", "1")
+    from rag_project_icd10_amd.tools.build_database import DatabaseBuilder
+    b = DatabaseBuilder()
+    b.initialize_services()
+    recs = b.load_csv_data(os.path.join(GOLDEN, "csv_slice.csv"))
+    assert b.vectorize_and_index(recs) is True
+    ms, es = b.milvus_service, b.embedding_service
+    assert ms.get_collection_stats()["num_entities"] == len(recs) and ms.get_collection_load_state()["loaded"]
+    corpus, levels = ms.client.matrix(), ms.client.levels()
+    for r in (0, 2, 57, len(recs) - 1):
+        vec = es.encode_query(recs[r]["semantic_text"])
+        hits = ms.search(vec, top_k=5)
+        assert len(hits) == 5 and recs[r]["code"] in [h["code"] for h in hits]
+        assert set(hits[0]) == {"code", "title", "score", "original_score", "metadata"}
+        assert set(hits[0]["metadata"]) == {"has_complication", "main_code", "secondary_code", "level", "parent_code",
+                                            "category_path", "semantic_text"}
+        os_, oi = oracle.flat_ip_topk(corpus, vec[None], 5)
+        adj, raw, ids, _ = oracle.reweight(os_, oi, levels)
+        assert [h["code"] for h in hits] == [recs[i]["code"] for i in ids[0]]
+        assert [h["score"] for h in hits] == adj[0].tolist()                     # exact Python doubles
+        assert [h["original_score"] for h in hits] == [float(x) for x in raw[0]]
+        assert all(h["score"] == h["original_score"] * ms._calculate_level_weight(h["metadata"]["level"]) for h in hits)
+        best_raw = max(hits, key=lambda h: h["original_score"])
+        assert best_raw["code"] == recs[r]["code"] and best_raw["original_score"] > 0.9999
+    ver = b.verify_database()
+    assert ver["search_test"]["results_count"] == 5
+    # batched serving path == looping the reference-shaped call
+    from rag_project_icd10_amd.services.multi_diagnosis_service import MultiDiagnosisService
+    res = MultiDiagnosisService(es, ms).match_multiple_diagnoses("霍乱，伤寒；副伤寒", top_k=3)
+    assert res["extracted_diagnoses"] == ["霍乱", "伤寒", "副伤寒"] and res["total_matches"] == 9
+    for m in res["matches"]:
+        single = ms.search(es.encode_query(m.diagnosis_text), 6)
+        assert {c.code for c in m.candidates} <= {h["code"] for h in single}
+    assert ms.release_collection()["success"] and ms.get_collection_load_state()["loaded"] is False
+    assert ms.load_collection() is True and ms.disconnect()["success"]
