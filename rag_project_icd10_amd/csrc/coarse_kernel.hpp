@@ -40,6 +40,8 @@ constexpr int CO_S = 4;
 constexpr int CO_STAGE_BYTES = CO_BN * CO_BK * 2;  // 16384
 constexpr int CO_RING_BYTES = CO_S * CO_STAGE_BYTES;
 constexpr int CO_CAP = 64;
+constexpr int CO_CHECK_EVERY = 16;                      // registers between overflow checks (2 lanes append per register)
+constexpr int CO_LIMIT = CO_CAP - 2 * CO_CHECK_EVERY;    // compact a query once it holds more entries than this
 constexpr int CO_LDS_BYTES = CO_RING_BYTES + CO_BM * CO_CAP * 8 + 4 * 256;
 
 struct CoarseArgs {
@@ -55,22 +57,77 @@ struct CoarseArgs {
     unsigned long long *dbg; // diagnostic builds only: [block][wave][4] cycle sums
 };
 
-// VAR (diagnostic ablations, timing only; VAR = 0 is the product kernel):
-//   1 skip the fused select   2 skip the MFMAs   4 no vmcnt wait before the barrier   8 s_memtime stamps
+// VAR: build options of the kernel. Product = CO_PRODUCT_VAR; the ablation bits are timing-only.
+//   1    ablation: skip the fused select            8    diagnostic: s_memtime stamps
+//   128  ablation: no LDS-DMA at all                16   select of tile t inside the MFMA stream of t+1
+//   512  software-pipelined stage: the barrier that publishes stage g+1 sits in the middle of stage
+//        g and the first fragments of g+1 are read before g ends (no read-latency bubble per stage)
+//   1024 compact early at tile ends (all waves in step) in addition to the overflow guard
+//   2048 manually ordered stream: every MFMA is a one-instruction asm volatile and the select of the
+//        previous tile is a branch-free 6-instruction asm step placed between them (implies 512 + 16);
+//        the compiler still allocates registers and inserts the LDS waits
+//   4096 (with 2048) split select step: v_cmp into an SGPR mask in one MFMA gap, masked append one
+//        k-step later (no VALU -> SALU -> VALU dependency chain in the stream)
 #define ICD_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); \
     __builtin_amdgcn_sched_barrier(0); } while (0)
 
-#define ICD_GLDS16(gptr, lptr)                                                                      \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),       \
-                                     (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+// ---- one-instruction asm pieces of the manually ordered stream (VAR & 2048) --------------------------
+template <bool FIRST>
+__device__ __forceinline__ void mfma_asm(f32x16 &acc, const half8 &fa, const half8 &fb) {
+    // the query fragment is read straight from the AGPR half (acc 64 + Q 192 = 256 AGPRs): no
+    // v_accvgpr_read copy in front of the MFMA, which would be a VALU -> MFMA-operand hazard the
+    // compiler cannot see inside an asm statement
+    if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(acc) : "v"(fa), "a"(fb) : "memory");
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(fa), "a"(fb) : "memory");
+}
+// branch-free select step: if (v > thr) { score[aw] = v; row[aw] = rowbase + ROFF; aw += inc; }
+template <int ROFF>
+__device__ __forceinline__ void filter_asm(uint32_t &aw, float v, float thr, uint32_t rowbase, uint32_t inc) {
+    uint32_t row;
+    unsigned long long sv;
+    asm volatile("v_cmp_gt_f32 vcc, %[v], %[thr]\n\t"
+                 "s_and_saveexec_b64 %[sv], vcc\n\t"
+                 "v_add_u32 %[row], %[ro], %[rb]\n\t"
+                 "ds_write2st64_b32 %[aw], %[v], %[row] offset1:1\n\t"
+                 "v_add_u32 %[aw], %[aw], %[inc]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [aw] "+v"(aw), [row] "=&v"(row), [sv] "=&s"(sv)
+                 : [v] "v"(v), [thr] "v"(thr), [rb] "v"(rowbase), [ro] "i"(ROFF), [inc] "v"(inc)
+                 : "vcc", "memory");
+}
+
+// split select step (VAR & 4096): the compare writes a wave mask into an SGPR pair ...
+__device__ __forceinline__ unsigned long long fcmp_asm(float v, float thr) {
+    unsigned long long m;
+    asm volatile("v_cmp_gt_f32_e64 %[m], %[v], %[thr]" : [m] "=s"(m) : [v] "v"(v), [thr] "v"(thr) : "memory");
+    return m;
+}
+// ... and a later MFMA gap consumes it: nothing but a scalar test when no lane passed
+template <int ROFF>
+__device__ __forceinline__ void fapp_asm(uint32_t &aw, float v, unsigned long long m, uint32_t rowbase, uint32_t inc) {
+    uint32_t row;
+    asm volatile("s_cmp_lg_u64 %[m], 0\n\t"
+                 "s_cbranch_scc0 1f\n\t"
+                 "s_mov_b64 exec, %[m]\n\t"
+                 "v_add_u32 %[row], %[ro], %[rb]\n\t"
+                 "ds_write2st64_b32 %[aw], %[v], %[row] offset1:1\n\t"
+                 "v_add_u32 %[aw], %[aw], %[inc]\n\t"
+                 "s_mov_b64 exec, -1\n"
+                 "1:"
+                 : [aw] "+v"(aw), [row] "=&v"(row)
+                 : [m] "s"(m), [v] "v"(v), [rb] "v"(rowbase), [ro] "i"(ROFF), [inc] "v"(inc)
+                 : "scc", "memory");
+}
 
 template <int D, int VAR>
 __global__ __launch_bounds__(256, 1) void coarse_topk_kernel(CoarseArgs a) {
     constexpr int KS = D / CO_BK;      // stages per tile
     constexpr int NF = D / 16;         // query fragments per lane
     constexpr int NKSTEP = KS * 4;     // k16-steps per tile
-    constexpr bool OVERLAP = (VAR & 16) != 0;  // filter tile t inside the MFMA stream of tile t+1
+    constexpr bool NOSELECT = (VAR & 1) != 0, STAMPS = (VAR & 8) != 0, OVERLAP = (VAR & 16) != 0 || (VAR & 2048) != 0;
+    constexpr bool MANUAL = (VAR & 2048) != 0, SPLITSEL = (VAR & 4096) != 0;
+    constexpr bool NODMA = (VAR & 128) != 0, PIPE = MANUAL || (VAR & 512) != 0, TILE_END_COMPACT = (VAR & 1024) != 0;
     static_assert(KS % CO_S == 0, "ring slot must be a compile-time function of the stage");
     using Ops = Sel2Ops<CO_KP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -93,7 +150,8 @@ __global__ __launch_bounds__(256, 1) void coarse_topk_kernel(CoarseArgs a) {
         for (int s = 0; s < NF; ++s) qf[s] = *reinterpret_cast<const half8 *>(qrow + 16 * s);
     }
 
-    // ---- DMA source offsets (bytes from the tile's first row, k = 0) --------------------------------
+    // ---- LDS-DMA: per-lane source offsets (bytes from the tile's first row, k = 0) -------------------
+    // piece i of this wave = rows 8*(4*wave+i)..+7, one full 128-B line each; 16-B pieces XOR-swizzled
     uint32_t src_off[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -104,6 +162,21 @@ __global__ __launch_bounds__(256, 1) void coarse_topk_kernel(CoarseArgs a) {
     }
     const char *cbase = reinterpret_cast<const char *>(a.c16);
     const int last_tile_row0 = a.n_pad - CO_BN;
+    // buffer_load ... lds: per-lane part in voffset, tile/stage part in a scalar soffset
+    const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(cbase) + (size_t)row_begin * (size_t)(D * 2), 0,
+        (int)min((size_t)(a.n_pad - row_begin) * (size_t)(D * 2), (size_t)0x7FFFFFFF), 0x00020000);
+    auto issue_stage = [&](int g_tile, int g_ks, int ring_slot) {
+        if constexpr (NODMA) return;
+        int trow0 = row_begin + g_tile * CO_BN;
+        trow0 = min(trow0, last_tile_row0);  // stages past the sweep re-read valid memory, never consumed
+        char *dst = smem + ring_slot * CO_STAGE_BYTES + wave * 4096;
+        const uint32_t soff = (uint32_t)(trow0 - row_begin) * (uint32_t)(D * 2) + (uint32_t)g_ks * (CO_BK * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, (__attribute__((address_space(3))) void *)(dst + i * 1024),
+                                                     16, src_off[i], soff, 0, 0);
+    };
 
     // ---- A-fragment LDS read offsets ----------------------------------------------------------------
     uint32_t rd_off[4];
@@ -112,6 +185,11 @@ __global__ __launch_bounds__(256, 1) void coarse_topk_kernel(CoarseArgs a) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) rd_off[s] = (uint32_t)c * 128u + (uint32_t)(((2 * s + h) ^ sw) * 16);
     }
+    auto read_frags = [&](half8 (&f)[4], int ring_slot, int s) {
+        const char *sb = smem + ring_slot * CO_STAGE_BYTES + rd_off[s];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) f[t] = *reinterpret_cast<const half8 *>(sb + t * 4096);
+    };
 
     // ---- select state ---------------------------------------------------------------------------------
     const uint32_t wave_qbase = (uint32_t)CO_RING_BYTES + (uint32_t)(wave * 32) * Ops::QBYTES;
@@ -119,30 +197,7 @@ __global__ __launch_bounds__(256, 1) void coarse_topk_kernel(CoarseArgs a) {
     Sel2 st;
     Ops::init(st, wave_qbase + (uint32_t)c * Ops::QBYTES, h, (slot0 + wave * 32 + c) < a.nq);
 
-    // issue the 4 pieces of one stage
-    // VAR & 256: buffer_load ... lds with the per-lane part in voffset and the tile/stage part in a
-    // scalar soffset (no per-piece 64-bit VALU address arithmetic)
-    const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(cbase) + (size_t)row_begin * (size_t)(D * 2), 0,
-        (int)min((size_t)(a.n_pad - row_begin) * (size_t)(D * 2), (size_t)0x7FFFFFFF), 0x00020000);
-    auto issue_stage = [&](int g_tile, int g_ks, int ring_slot) {
-        if constexpr ((VAR & 128) != 0) return;  // timing-only ablation: no DMA at all
-        int trow0 = row_begin + g_tile * CO_BN;
-        trow0 = min(trow0, last_tile_row0);  // stages past the sweep re-read valid memory, never consumed
-        char *dst = smem + ring_slot * CO_STAGE_BYTES + wave * 4096;
-        if constexpr ((VAR & 256) != 0) {
-            const uint32_t soff = (uint32_t)(trow0 - row_begin) * (uint32_t)(D * 2) + (uint32_t)g_ks * (CO_BK * 2);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, (__attribute__((address_space(3))) void *)(dst + i * 1024),
-                                                         16, src_off[i], soff, 0, 0);
-        } else {
-            const char *src = cbase + (size_t)trow0 * (size_t)(D * 2) + (size_t)g_ks * (CO_BK * 2);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ICD_GLDS16(src + src_off[i], dst + i * 1024);
-        }
-    };
-
+    unsigned long long cprof[2] = {0, 0};  // STAMPS: compactions, cycles inside them
     // filter one register of a finished tile (flat index F = 16 t + r). GUARD: rows >= n never pass
     // (only the last tile of the corpus has such rows).
     auto filter_reg = [&](const f32x16 (&pa)[4], auto F, uint32_t rowbase, auto GUARD) {
@@ -158,87 +213,203 @@ __global__ __launch_bounds__(256, 1) void coarse_topk_kernel(CoarseArgs a) {
             *reinterpret_cast<uint32_t *>(smem + st.aw + Ops::ROW_OFF) = rowbase + roff;
             st.aw += st.inc;
         }
-        if constexpr (r == 15) Ops::check(st, lane, smem, wave_qbase, wave_scratch, false);
+        if constexpr (r % CO_CHECK_EVERY == CO_CHECK_EVERY - 1) Ops::check(st, lane, smem, wave_qbase, wave_scratch, false, CO_LIMIT, STAMPS ? cprof : nullptr);
     };
     auto filter_tile = [&](const f32x16 (&pa)[4], int tile_row0) {
         const uint32_t rowbase = (uint32_t)(tile_row0 + 4 * h);
         if (tile_row0 + CO_BN > a.n) static_for<0, 64>([&](auto F) { filter_reg(pa, F, rowbase, std::true_type{}); });
         else static_for<0, 64>([&](auto F) { filter_reg(pa, F, rowbase, std::false_type{}); });
+        if constexpr (TILE_END_COMPACT) Ops::check(st, lane, smem, wave_qbase, wave_scratch, false, CO_KP + 8);
     };
 
-    // prologue: stages 0..S-2
+    // prologue: stages 0..S-2 in flight
 #pragma unroll
     for (int p = 0; p < CO_S - 1; ++p) issue_stage(p / KS, p % KS, p % CO_S);
 
     unsigned long long t_wait = 0, t_body = 0, t_epi = 0, t0 = 0, t1 = 0, t2 = 0;
-    f32x16 pacc[4];  // previous tile's scores (OVERLAP)
+    f32x16 pacc[4];   // previous tile's scores (OVERLAP)
     if (OVERLAP) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) pacc[t][r] = -INFINITY;
     }
+    unsigned long long msk[4] = {0, 0, 0, 0};   // SPLITSEL: wave masks of the registers compared last
+    half8 afn[4];     // PIPE: fragments of (next stage, k-step 0), read before the stage begins
+    if constexpr (PIPE) {
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // stage 0 published
+        read_frags(afn, 0, 0);
+    }
+
     for (int tile = 0; tile < ntiles; ++tile) {
         f32x16 acc[4];
+        if constexpr (!MANUAL) {   // (the manual stream's first MFMA of a tile takes C = 0 instead)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        }
         const int tile_row0 = row_begin + tile * CO_BN;
 
         static_for<0, KS>([&](auto KSI) {
             constexpr int ks = decltype(KSI)::value;
-            constexpr int AHEAD = CO_S - 1;
-            if (VAR & 8) ICD_STAMP(t0);
-            // stage (tile,ks) landed for this wave when all but the youngest 2 stages are done
-            if (VAR & 4) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (VAR & 8) ICD_STAMP(t1);
-            {
-                constexpr int nks = ks + AHEAD;
-                const int ntile = tile + (nks >= KS ? 1 : 0);
-                issue_stage(ntile, nks % KS, nks % CO_S);
-            }
-            const char *sbase = smem + (ks % CO_S) * CO_STAGE_BYTES;
-            if constexpr ((VAR & 64) != 0) {
-                // whole-stage prefetch: all 16 A fragments in flight before the first MFMA
-                half8 af[16];
+            constexpr int slot = ks % CO_S;
+            auto mfma4 = [&](const half8 (&f)[4], int qi) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    af[i] = *reinterpret_cast<const half8 *>(sbase + (i & 3) * 4096 + rd_off[i >> 2]);
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], qf[ks * 4 + (i >> 2)], acc[i & 3], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-            } else {
-            // fragment reads run one k-step ahead of the MFMAs that consume them
-            half8 af[2][4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                af[0][t] = *reinterpret_cast<const half8 *>(sbase + t * 4096 + rd_off[0]);
-            static_for<0, 4>([&](auto SI) {
-                constexpr int s = decltype(SI)::value;
-                if constexpr (s + 1 < 4) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        af[(s + 1) & 1][t] = *reinterpret_cast<const half8 *>(sbase + t * 4096 + rd_off[s + 1]);
-                }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (VAR & 2) asm volatile("" ::"v"(af[s & 1][t]), "v"(qf[ks * 4 + s]));
-                    else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s & 1][t], qf[ks * 4 + s], acc[t], 0, 0, 0);
-                }
-                if constexpr (OVERLAP && !(VAR & 1)) {
-                    // the previous tile's select rides in the gaps of this tile's MFMAs
-                    constexpr int j = ks * 4 + s;
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[t], qf[qi], acc[t], 0, 0, 0);
+            };
+            auto overlap_filter = [&](auto SI) {
+                if constexpr (OVERLAP && !NOSELECT) {
+                    constexpr int j = ks * 4 + decltype(SI)::value;
                     constexpr int f0 = (j * 64) / NKSTEP, f1 = ((j + 1) * 64) / NKSTEP;
                     static_for<f0, f1>([&](auto F) { filter_reg(pacc, F, (uint32_t)(tile_row0 - CO_BN + 4 * h), std::true_type{}); });
                 }
-            });
-            if constexpr ((VAR & 32) != 0) {
+            };
+            if constexpr (MANUAL) {
+                // ---- manually ordered stream -------------------------------------------------------
+                // asm volatile statements keep their program order; "memory" clobbers pin the LDS reads
+                // and the DMA between them. One k-step = 4 MFMAs (128 cycles of matrix pipe) with the
+                // next k-step's 4 fragment reads ahead of it and 1-2 filter steps of the previous tile.
+                const uint32_t prev_rowbase = (uint32_t)(tile_row0 - CO_BN + 4 * h);
+                // the MFMA stays a compiler-visible builtin (the compiler pads its hazards and is free to
+                // park query fragments in AGPRs); sched_barrier(0) after every piece pins the order below
+                auto mfma1 = [&](auto T, const half8 &fa, auto QI) {
+                    constexpr int t = decltype(T)::value, qi = decltype(QI)::value;
+                    if constexpr (qi == 0) {
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, qf[qi], zero, 0, 0, 0);
+                    } else {
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, qf[qi], acc[t], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                auto fstep = [&](auto F) {   // branch-free select step for register F of the previous tile
+                    if constexpr (!NOSELECT) {
+                        constexpr int f = decltype(F)::value;
+                        constexpr int t = f >> 4, r = f & 15;
+                        filter_asm<t * 32 + (r & 3) + 8 * (r >> 2)>(st.aw, pacc[t][r], st.thr, prev_rowbase, st.inc);
+                    }
+                };
+                auto fcmp = [&](auto F) {
+                    constexpr int f = decltype(F)::value;
+                    if constexpr (!NOSELECT && f < 64) msk[f & 3] = fcmp_asm(pacc[f >> 4][f & 15], st.thr);
+                };
+                auto fapp = [&](auto F) {
+                    constexpr int f = decltype(F)::value;
+                    if constexpr (!NOSELECT && f >= 0 && f < 64) {
+                        constexpr int t = f >> 4, r = f & 15;
+                        fapp_asm<t * 32 + (r & 3) + 8 * (r >> 2)>(st.aw, pacc[t][r], msk[f & 3], prev_rowbase, st.inc);
+                        if constexpr (r % CO_CHECK_EVERY == CO_CHECK_EVERY - 1)
+                            Ops::check(st, lane, smem, wave_qbase, wave_scratch, false, CO_LIMIT, STAMPS ? cprof : nullptr);
+                    }
+                };
+                auto kstep = [&](const half8 (&f)[4], auto S) {
+                    constexpr int sidx = decltype(S)::value;
+                    constexpr int j = ks * 4 + sidx;
+                    constexpr int f0 = (j * 64) / NKSTEP, f1 = ((j + 1) * 64) / NKSTEP;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (SPLITSEL) {
+                        // registers compared in the previous k-step are appended now; this k-step's are compared
+                        constexpr int p0 = j > 0 ? ((j - 1) * 64) / NKSTEP : 0, p1 = j > 0 ? f0 : 0;
+                        mfma1(std::integral_constant<int, 0>{}, f[0], std::integral_constant<int, j>{});
+                        fcmp(std::integral_constant<int, f0>{});
+                        mfma1(std::integral_constant<int, 1>{}, f[1], std::integral_constant<int, j>{});
+                        if constexpr (p1 > p0) fapp(std::integral_constant<int, p0>{});
+                        mfma1(std::integral_constant<int, 2>{}, f[2], std::integral_constant<int, j>{});
+                        if constexpr (f1 > f0 + 1) fcmp(std::integral_constant<int, f0 + 1>{});
+                        mfma1(std::integral_constant<int, 3>{}, f[3], std::integral_constant<int, j>{});
+                        if constexpr (p1 > p0 + 1) fapp(std::integral_constant<int, p0 + 1>{});
+                        if constexpr (j == NKSTEP - 1) {   // last k-step: its own registers cannot wait for a next one
+                            fapp(std::integral_constant<int, f0>{});
+                            if constexpr (f1 > f0 + 1) fapp(std::integral_constant<int, f0 + 1>{});
+                        }
+                    } else {
+                        mfma1(std::integral_constant<int, 0>{}, f[0], std::integral_constant<int, j>{});
+                        if constexpr (f1 > f0) fstep(std::integral_constant<int, f0>{});
+                        mfma1(std::integral_constant<int, 1>{}, f[1], std::integral_constant<int, j>{});
+                        mfma1(std::integral_constant<int, 2>{}, f[2], std::integral_constant<int, j>{});
+                        if constexpr (f1 > f0 + 1) fstep(std::integral_constant<int, f0 + 1>{});
+                        mfma1(std::integral_constant<int, 3>{}, f[3], std::integral_constant<int, j>{});
+                        if constexpr (!NOSELECT && ((f1 - 1) % CO_CHECK_EVERY) == CO_CHECK_EVERY - 1 && f1 > f0)
+                            Ops::check(st, lane, smem, wave_qbase, wave_scratch, false, CO_LIMIT, STAMPS ? cprof : nullptr);
+                    }
+                };
+                half8 f1[4], f2[4], f3[4];
+                if (STAMPS) ICD_STAMP(t1);
+                read_frags(f1, slot, 1);
+                kstep(afn, std::integral_constant<int, 0>{});
+                read_frags(f2, slot, 2);
+                kstep(f1, std::integral_constant<int, 1>{});
+                if (STAMPS) { ICD_STAMP(t2); t_body += t2 - t1; }
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (STAMPS) { ICD_STAMP(t1); t_wait += t1 - t2; }
+                {
+                    constexpr int nks = ks + CO_S - 1;
+                    issue_stage(tile + (nks >= KS ? 1 : 0), nks % KS, nks % CO_S);
+                }
+                read_frags(f3, slot, 3);
+                kstep(f2, std::integral_constant<int, 2>{});
+                read_frags(afn, (ks + 1) % CO_S, 0);
+                kstep(f3, std::integral_constant<int, 3>{});
+                if (STAMPS) { ICD_STAMP(t2); t_body += t2 - t1; }
+            } else if constexpr (PIPE) {
+                // stage g = (tile, ks) was published by the previous mid-stage barrier; afn holds its k-step 0
+                half8 f1[4], f2[4], f3[4];
+                if (STAMPS) ICD_STAMP(t1);
+                read_frags(f1, slot, 1);
+                mfma4(afn, ks * 4 + 0);
+                overlap_filter(std::integral_constant<int, 0>{});
+                read_frags(f2, slot, 2);
+                mfma4(f1, ks * 4 + 1);
+                overlap_filter(std::integral_constant<int, 1>{});
+                // pin: reads of k-step s+1 go out before the MFMAs of k-step s
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                if (STAMPS) { ICD_STAMP(t2); t_body += t2 - t1; }
+                // publish stage g+1: this wave's pieces of g+1 have landed when only g+2 is outstanding
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (STAMPS) { ICD_STAMP(t1); t_wait += t1 - t2; }
+                {   // every wave is past stage g-1: its slot takes stage g+3
+                    constexpr int nks = ks + CO_S - 1;
+                    issue_stage(tile + (nks >= KS ? 1 : 0), nks % KS, nks % CO_S);
+                }
+                read_frags(f3, slot, 3);
+                mfma4(f2, ks * 4 + 2);
+                overlap_filter(std::integral_constant<int, 2>{});
+                read_frags(afn, (ks + 1) % CO_S, 0);
+                mfma4(f3, ks * 4 + 3);
+                overlap_filter(std::integral_constant<int, 3>{});
+                __builtin_amdgcn_sched_group_barrier(0x020, 4, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (STAMPS) { ICD_STAMP(t2); t_body += t2 - t1; }
+            } else {
+                if (STAMPS) ICD_STAMP(t0);
+                // stage (tile,ks) landed for this wave when all but the youngest 2 stages are done
+                asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (STAMPS) ICD_STAMP(t1);
+                {
+                    constexpr int nks = ks + CO_S - 1;
+                    issue_stage(tile + (nks >= KS ? 1 : 0), nks % KS, nks % CO_S);
+                }
+                // fragment reads run one k-step ahead of the MFMAs that consume them
+                half8 af[2][4];
+                read_frags(af[0], slot, 0);
+                static_for<0, 4>([&](auto SI) {
+                    constexpr int s = decltype(SI)::value;
+                    if constexpr (s + 1 < 4) read_frags(af[(s + 1) & 1], slot, s + 1);
+                    mfma4(af[s & 1], ks * 4 + s);
+                    overlap_filter(SI);
+                });
                 // pin the order: reads of k-step s+1 are issued before the MFMAs of k-step s
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
@@ -250,32 +421,36 @@ __global__ __launch_bounds__(256, 1) void coarse_topk_kernel(CoarseArgs a) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                if (STAMPS) { ICD_STAMP(t2); t_wait += t1 - t0; t_body += t2 - t1; }
             }
-            }
-            if (VAR & 8) { ICD_STAMP(t2); t_wait += t1 - t0; t_body += t2 - t1; }
         });
-        if (VAR & 8) ICD_STAMP(t0);
+        if (STAMPS) ICD_STAMP(t0);
 
-        if (VAR & 1) {
+        if constexpr (NOSELECT) {
             float sum = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sum += acc[t][r];
             if (sum == 1.2345e30f) st.kept = 1;  // keeps the MFMAs live, never true
-        } else if (OVERLAP) {
+        } else if constexpr (OVERLAP) {
+            // an asm MFMA's result needs its wait states before any non-MFMA reader (compiler cannot see it)
 #pragma unroll
             for (int t = 0; t < 4; ++t) pacc[t] = acc[t];
+            if constexpr (TILE_END_COMPACT) Ops::check(st, lane, smem, wave_qbase, wave_scratch, false, CO_KP + 8);
         } else {
             filter_tile(acc, tile_row0);
         }
-        if (VAR & 8) { ICD_STAMP(t1); t_epi += t1 - t0; }
+        if (STAMPS) { ICD_STAMP(t1); t_epi += t1 - t0; }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead stages
-    if (OVERLAP && !(VAR & 1)) filter_tile(pacc, row_begin + (ntiles - 1) * CO_BN);
-    if ((VAR & 8) && a.dbg && lane == 0) {
+    if constexpr (PIPE) asm volatile("" ::"v"(afn[0]), "v"(afn[1]), "v"(afn[2]), "v"(afn[3]));
+    if constexpr (OVERLAP && !NOSELECT) filter_tile(pacc, row_begin + (ntiles - 1) * CO_BN);
+    if (STAMPS && a.dbg && lane == 0) {
         unsigned long long *d = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 4;
         d[0] = t_wait; d[1] = t_body; d[2] = t_epi; d[3] = (unsigned long long)ntiles;
+        unsigned long long *e = a.dbg + (size_t)8192 * 16 / 2 + ((size_t)blockIdx.x * 4 + wave) * 2;
+        e[0] = cprof[0]; e[1] = cprof[1];
     }
 
     // ---- final: sorted top-KP of every query of this wave -> partial list ---------------------------
@@ -298,6 +473,8 @@ __global__ __launch_bounds__(256, 1) void coarse_topk_kernel(CoarseArgs a) {
         }
     }
 }
+
+constexpr int CO_PRODUCT_VAR = 512;   // software-pipelined stage; select after the tile (best measured, profiles/r01_ablate*.log)
 
 // ---- fp32 -> fp16 images ---------------------------------------------------------------------------
 // One wave per row: converts with round-to-nearest-even, accumulates the row's squared norm in fp32,

@@ -12,6 +12,7 @@
 #include <string>
 
 #include "../../include/icd_search.h"
+#include "coarse8_kernel.hpp"
 #include "coarse_kernel.hpp"
 #include "exact_kernel.hpp"
 #include "finalize.hpp"
@@ -165,6 +166,19 @@ int launch_coarse(icd_index *x, const CoarseArgs &a, int mtiles, hipStream_t s) 
     return ICD_OK;
 }
 
+template <int D, int VAR>
+int launch_coarse8(icd_index *x, const CoarseArgs &a, int mtiles, hipStream_t s) {
+    auto kern = coarse8_topk_kernel<D, VAR>;
+    static thread_local int configured_dev = -1;
+    if (configured_dev != x->device) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C8_LDS_BYTES));
+        configured_dev = x->device;
+    }
+    hipLaunchKernelGGL(kern, dim3(mtiles * a.P), dim3(512), C8_LDS_BYTES, s, a);
+    HIP_TRY(hipGetLastError());
+    return ICD_OK;
+}
+
 template <bool RESCORE>
 int launch_finalize(icd_index *x, const FinArgs &a, hipStream_t s) {
     auto kern = finalize_kernel<RESCORE>;
@@ -282,9 +296,9 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         a.part_scores = x->partc_s; a.part_rows = x->partc_r;
         x->last_chunks = pc;
         a.dbg = x->dbg;
-        // Product configuration of the coarse kernel: buffer_load...lds staging (256) + pinned
-        // read-ahead order (32). Other VAR values are timing ablations, built only with -DICD_ABLATE.
-        constexpr int PV = 256 | 32;
+        // Product configuration = CO_PRODUCT_VAR (coarse_kernel.hpp). Other VAR values are A/B variants
+        // and timing ablations, built only with -DICD_ABLATE and selected by env ICD_COARSE_VAR.
+        constexpr int PV = CO_PRODUCT_VAR;
         int rc;
         if (x->dim == 1024) rc = launch_coarse<1024, PV>(x, a, mtc, s);
         else {
@@ -292,9 +306,11 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             int var = PV;
             if (const char *e = getenv("ICD_COARSE_VAR")) var = atoi(e);
             if (false) {}
+            else if (var == 10000) rc = launch_coarse8<768, 0>(x, a, mtc, s);
+            else if (var == 10001) rc = launch_coarse8<768, 1>(x, a, mtc, s);
 #define ICD_VAR_CASE(V) else if (var == V) rc = launch_coarse<768, V>(x, a, mtc, s);
-            ICD_VAR_CASE(0) ICD_VAR_CASE(1) ICD_VAR_CASE(8) ICD_VAR_CASE(16) ICD_VAR_CASE(32) ICD_VAR_CASE(33)
-            ICD_VAR_CASE(129) ICD_VAR_CASE(256) ICD_VAR_CASE(257) ICD_VAR_CASE(289) ICD_VAR_CASE(296)
+            ICD_VAR_CASE(0) ICD_VAR_CASE(1) ICD_VAR_CASE(8) ICD_VAR_CASE(129) ICD_VAR_CASE(512) ICD_VAR_CASE(513)
+            ICD_VAR_CASE(520) ICD_VAR_CASE(528) ICD_VAR_CASE(2048) ICD_VAR_CASE(6144)
 #undef ICD_VAR_CASE
             else
 #endif

@@ -160,12 +160,13 @@ static void bench(int64_t n, int64_t nq, int dim, int k, int iters, int chunks, 
                (long long)st.last_fallback);
     }
     if (getenv("ICD_COARSE_VAR") && (atoi(getenv("ICD_COARSE_VAR")) & 8)) {
-        std::vector<unsigned long long> c(237 * 16);
+        std::vector<unsigned long long> c(8192 * 16);
         CHECK_RC(icd_index_debug_counters(idx, c.data(), (int)c.size()));
-        double w = 0, b = 0, e = 0, t = 0; int cnt = 0;
-        for (size_t i = 0; i + 3 < c.size(); i += 4) if (c[i + 3]) { w += c[i]; b += c[i + 1]; e += c[i + 2]; t += c[i + 3]; ++cnt; }
-        printf("   stamps (avg per wave over %d waves, cycles per tile): wait+barrier=%.0f body=%.0f select=%.0f tiles/wave=%.1f\n",
-               cnt, w / t, b / t, e / t, t / cnt);
+        double w = 0, b = 0, e = 0, t = 0, nc = 0, tc = 0; int cnt = 0;
+        for (size_t i = 0; i + 3 < 8192 * 8; i += 4) if (c[i + 3]) { w += c[i]; b += c[i + 1]; e += c[i + 2]; t += c[i + 3]; ++cnt; }
+        for (size_t i = 8192 * 8; i + 1 < c.size(); i += 2) { nc += c[i]; tc += c[i + 1]; }
+        printf("   stamps (avg per wave over %d waves, cycles per tile): wait+barrier=%.0f body=%.0f select=%.0f tiles/wave=%.1f | compactions/tile/wave=%.2f cycles/compaction=%.0f compaction cycles/tile=%.0f\n",
+               cnt, w / t, b / t, e / t, t / cnt, nc / t, nc ? tc / nc : 0.0, tc / t);
     }
     if (verify) {
         // parity of a query sample of the big run against the oracle (AUTO mode)
@@ -247,7 +248,7 @@ int main(int argc, char **argv) {
     }
     if (do_bench) {
         const int var = getenv("ICD_COARSE_VAR") ? atoi(getenv("ICD_COARSE_VAR")) : 0;
-        bench(bn, bnq, 768, 10, iters, chunks, (var & 7) == 0);
+        bench(bn, bnq, 768, 10, iters, chunks, (var & 7) == 0 || var == 10000);
     }
     printf("icd_selftest: %d passed, %d failed\n", g_pass, g_fail);
     return g_fail ? 1 : 0;

@@ -194,13 +194,23 @@ struct Sel2Ops {
         }
     }
     // after a 16-register group: compact the queries that could overflow in the next group
+    // limit: compact the queries whose entry count exceeds it (CAP - 32 = overflow guard for the next
+    // 16-register group; a lower value at tile ends compacts early, while all waves are in step)
     __device__ static __forceinline__ void check(Sel2 &s, int lane, char *smem, uint32_t wave_qbase,
-                                                 uint32_t wave_scratch, bool force) {
+                                                 uint32_t wave_scratch, bool force, int limit = CAP - 32,
+                                                 unsigned long long *prof = nullptr) {
         const int h = lane >> 5;
         const int mine = used(s, h);
-        const int other = __shfl_xor(mine, 32);
+        // partner lane's count without touching LDS: v_permlane32_swap exchanges the two wave halves
+        const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)mine, (unsigned)mine, false, false);
+        const int other = (int)(h ? sw[0] : sw[1]);
         const int total = s.kept + mine + other;
-        uint32_t need = (uint32_t)__ballot(force ? (total > 0) : (total > CAP - 32));
+        uint32_t need = (uint32_t)__ballot(force ? (total > 0) : (total > limit));
+        unsigned long long pt0 = 0;
+        if (prof && need) {
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pt0)::"memory");
+            prof[0] += (unsigned long long)__popc(need);
+        }
         while (need) {
             const int b = __ffs((int)need) - 1;
             need &= need - 1;
@@ -219,14 +229,29 @@ struct Sel2Ops {
             const uint32_t key = valid ? ((order_f32(v) & ~63u) | (uint32_t)(63 - lane)) : 0u;
             *reinterpret_cast<uint32_t *>(smem + wave_scratch + lane * 4) = key;
             int rank = 0;
-            const uint4 *kp = reinterpret_cast<const uint4 *>(smem + wave_scratch);
+            // Rank against the keys in 16-key chunks, only the chunks that hold entries ([0, nlo) at the
+            // front, [64 - nhi, 64) at the back; empty slots carry key 0 and never count). The reads are
+            // an asm block on purpose: for a compiler-visible ds_read in this loop hipcc emits
+            // s_waitcnt vmcnt(0) (it cannot tell the scratch from the LDS-DMA ring), which drains the
+            // whole prefetch pipeline of the caller on every compaction.
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const uint4 kk = kp[j];  // wave-uniform address: LDS broadcast
-                rank += (kk.x > key) ? 1 : 0;
-                rank += (kk.y > key) ? 1 : 0;
-                rank += (kk.z > key) ? 1 : 0;
-                rank += (kk.w > key) ? 1 : 0;
+            for (int ch = 0; ch < 4; ++ch) {
+                if (ch * 16 < nlo || (ch + 1) * 16 > CAP - nhi) {   // wave-uniform
+                    uint4 k0, k1, k2, k3;
+                    const uint32_t addr = wave_scratch + (uint32_t)ch * 64u;
+                    asm volatile("ds_read_b128 %0, %4\n\t"
+                                 "ds_read_b128 %1, %4 offset:16\n\t"
+                                 "ds_read_b128 %2, %4 offset:32\n\t"
+                                 "ds_read_b128 %3, %4 offset:48\n\t"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : "=&v"(k0), "=&v"(k1), "=&v"(k2), "=&v"(k3)
+                                 : "v"(addr)
+                                 : "memory");
+                    rank += (k0.x > key) + (k0.y > key) + (k0.z > key) + (k0.w > key);
+                    rank += (k1.x > key) + (k1.y > key) + (k1.z > key) + (k1.w > key);
+                    rank += (k2.x > key) + (k2.y > key) + (k2.z > key) + (k2.w > key);
+                    rank += (k3.x > key) + (k3.y > key) + (k3.z > key) + (k3.w > key);
+                }
             }
             const int nvalid = nlo + nhi;
             if (valid && rank < KP) {
@@ -242,6 +267,11 @@ struct Sel2Ops {
                 s.aw0 = h ? qb + (CAP - 1) * 4 : qb + (uint32_t)s.kept * 4;
                 s.aw = s.aw0;
             }
+        }
+        if (prof && pt0) {
+            unsigned long long pt1;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pt1)::"memory");
+            prof[1] += pt1 - pt0;
         }
     }
 };
