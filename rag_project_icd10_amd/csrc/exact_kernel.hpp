@@ -18,6 +18,7 @@ struct ExactArgs {
     const int *qlist;      // nullable: slot -> query index
     const int *nq_ptr;     // nullable: device-side query count (fallback list length)
     int nq;                // query slots (upper bound when nq_ptr is given)
+    int min_active;        // with nq_ptr: run only if the device-side count exceeds this (else the streaming kernel runs)
     int n;                 // rows
     int dim;               // multiple of 32
     int P;                 // corpus chunks
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(NW * 64) void exact_topk_kernel(ExactArgs a) {
     u64 *bufs = reinterpret_cast<u64 *>(smem + (((size_t)(2 * BMQ * LDT + 2 * BN * LDT) * 4 + 15) & ~(size_t)15));
 
     const int nq = a.nq_ptr ? min(*a.nq_ptr, a.nq) : a.nq;
+    if (a.nq_ptr && nq <= a.min_active) return;
     const int mtile = blockIdx.x / a.P, chunk = blockIdx.x % a.P;
     const int slot0 = mtile * BMQ;
     if (slot0 >= nq) return;

@@ -16,6 +16,7 @@
 #include "coarse_kernel.hpp"
 #include "exact_kernel.hpp"
 #include "finalize.hpp"
+#include "stream_kernel.hpp"
 
 using namespace icd;
 
@@ -75,6 +76,7 @@ struct icd_index {
     unsigned char *qbad = nullptr;
     float *partc_s = nullptr; int *partc_r = nullptr; size_t partc_cap = 0;
     float *partx_s = nullptr; int *partx_r = nullptr; size_t partx_cap = 0;
+    float *lists_s = nullptr; int *lists_r = nullptr; size_t lists_cap = 0;   // streaming kernel: [slot][4 nwg][KP]
     int *nflag = nullptr; int *flagged = nullptr;
     unsigned int *scratch_u32 = nullptr;  // [0]=rmax bits, [1]=any_bad
     // output staging (used when the caller's buffers are host memory)
@@ -103,7 +105,7 @@ void free_all(icd_index *x) {
     if (!x) return;
     hipFree(x->corpus); hipFree(x->c16); hipFree(x->levels); hipFree(x->qdev); hipFree(x->q16);
     hipFree(x->qnorm); hipFree(x->qbad); hipFree(x->partc_s); hipFree(x->partc_r); hipFree(x->partx_s);
-    hipFree(x->partx_r); hipFree(x->nflag); hipFree(x->flagged); hipFree(x->scratch_u32);
+    hipFree(x->partx_r); hipFree(x->lists_s); hipFree(x->lists_r); hipFree(x->nflag); hipFree(x->flagged); hipFree(x->scratch_u32);
     hipFree(x->o_scores); hipFree(x->o_ids); hipFree(x->o_adj); hipFree(x->o_adj_raw);
     hipFree(x->o_adj_ids); hipFree(x->o_adj_lv);
     hipFree(x->dbg);
@@ -179,6 +181,42 @@ int launch_coarse8(icd_index *x, const CoarseArgs &a, int mtiles, hipStream_t s)
     return ICD_OK;
 }
 
+// streaming exact kernel + list reduction for a sparse query set (device-side gated when nq_ptr is given)
+// streaming exact kernel + list reduction for a sparse query set (device-side gated when nq_ptr is given).
+// p_out = 0: choose the smallest number of output lists (direct tiny-batch path); returns it in *p_used.
+template <int KP, int E, int QB>
+int launch_stream(icd_index *x, const float *dq, const int *qlist, const int *nq_ptr, int nq, int max_active,
+                  int p_out, int *p_used, hipStream_t s) {
+    const int n = (int)x->n;
+    const int per_max = FIN_MAX_CAND / KP;                       // lists one reduce wave can merge
+    const int p_cap = FIN_MAX_CAND / KP;                         // lists finalize<false> can merge
+    const int nwg_max = std::max(1, std::min(256, per_max * (p_out > 0 ? p_out : p_cap) / 4));
+    int rows_per_wg = ((n + nwg_max - 1) / nwg_max + 255) / 256 * 256;
+    const int nwg = (n + rows_per_wg - 1) / rows_per_wg;
+    if (p_out <= 0) p_out = std::max(1, (4 * nwg + per_max - 1) / per_max);
+    if (p_used) *p_used = p_out;
+    StreamArgs a{};
+    a.corpus = x->corpus; a.queries = dq; a.qlist = qlist; a.nq_ptr = nq_ptr; a.nq = std::min(nq, max_active);
+    a.max_active = max_active; a.n = n; a.dim = x->dim; a.rows_per_wg = rows_per_wg; a.nwg = nwg;
+    a.list_scores = x->lists_s; a.list_rows = x->lists_r;
+    if ((size_t)a.nq * 4 * nwg * KP > x->lists_cap) return fail(ICD_ERR_INVALID, "stream workspace too small");
+    auto kern = stream_topk_kernel<KP, E, QB>;
+    const size_t lds = stream_lds_bytes<KP, E, QB>(x->dim);
+    static thread_local int configured_dev = -1;
+    if (configured_dev != x->device) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured_dev = x->device;
+    }
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, s, a);
+    HIP_TRY(hipGetLastError());
+    ReduceArgs r{};
+    r.list_scores = x->lists_s; r.list_rows = x->lists_r; r.nlists = 4 * nwg; r.KP = KP; r.P_out = p_out;
+    r.nq_ptr = nq_ptr; r.nq = a.nq; r.max_active = max_active; r.part_scores = x->partx_s; r.part_rows = x->partx_r;
+    hipLaunchKernelGGL(reduce_lists_kernel, dim3((a.nq * p_out + 3) / 4), dim3(256), 4 * 512 * 8, s, r);
+    HIP_TRY(hipGetLastError());
+    return ICD_OK;
+}
+
 template <bool RESCORE>
 int launch_finalize(icd_index *x, const FinArgs &a, hipStream_t s) {
     auto kern = finalize_kernel<RESCORE>;
@@ -235,17 +273,41 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     const int bmq = nwx * 32;
     const int mtx = (nq + bmq - 1) / bmq;
     const int pmax_x = std::min(16, FIN_MAX_CAND / kpx);
-    auto run_exact = [&](const int *qlist, const int *nq_ptr, int px) -> int {
-        ExactArgs a{};
-        a.corpus = x->corpus; a.queries = dq; a.qlist = qlist; a.nq_ptr = nq_ptr; a.nq = nq;
-        a.n = (int)x->n; a.dim = x->dim; a.P = px;
-        a.rows_per_chunk = ((row_tiles + px - 1) / px) * 128;
-        a.part_scores = x->partx_s; a.part_rows = x->partx_r;
-        int rc;
-        if (kpx == 16) rc = launch_exact<16, 1, 4>(x, a, mtx, s);
-        else if (kpx == 64) rc = launch_exact<64, 2, 2>(x, a, mtx, s);
-        else rc = launch_exact<128, 3, 1>(x, a, mtx, s);
-        if (rc) return rc;
+    // sparse: streaming kernel (+ list reduction) instead of / next to the MFMA exact kernel
+    // queries per pass: host-known for direct calls (1, 2, 4 or 8), 8 for the device-gated fallback
+    auto run_stream = [&](const int *qlist, const int *nq_ptr, int nqs, int p_out, int *p_used) -> int {
+        const int qb = nq_ptr ? 8 : (nqs <= 1 ? 1 : (nqs <= 2 ? 2 : (nqs <= 4 ? 4 : 8)));
+#define ICD_ST(KPV, EV) \
+        (qb == 1 ? launch_stream<KPV, EV, 1>(x, dq, qlist, nq_ptr, nqs, ST_MAX_ACTIVE, p_out, p_used, s) : \
+         qb == 2 ? launch_stream<KPV, EV, 2>(x, dq, qlist, nq_ptr, nqs, ST_MAX_ACTIVE, p_out, p_used, s) : \
+         qb == 4 ? launch_stream<KPV, EV, 4>(x, dq, qlist, nq_ptr, nqs, ST_MAX_ACTIVE, p_out, p_used, s) : \
+                   launch_stream<KPV, EV, 8>(x, dq, qlist, nq_ptr, nqs, ST_MAX_ACTIVE, p_out, p_used, s))
+        if (kpx == 16) return ICD_ST(16, 2);
+        if (kpx == 64) return ICD_ST(64, 3);
+        return ICD_ST(128, 4);
+#undef ICD_ST
+    };
+    auto run_exact = [&](const int *qlist, const int *nq_ptr, int px, bool mfma, bool stream) -> int {
+        x->last_chunks = px;
+        int rc = ICD_OK;
+        if (stream) {
+            int used = px;
+            rc = run_stream(qlist, nq_ptr, nq, mfma ? px : 0, &used);   // alone: fewest output lists
+            if (rc) return rc;
+            px = used;
+        }
+        if (mfma) {
+            ExactArgs a{};
+            a.corpus = x->corpus; a.queries = dq; a.qlist = qlist; a.nq_ptr = nq_ptr; a.nq = nq;
+            a.min_active = stream ? ST_MAX_ACTIVE : 0;
+            a.n = (int)x->n; a.dim = x->dim; a.P = px;
+            a.rows_per_chunk = ((row_tiles + px - 1) / px) * 128;
+            a.part_scores = x->partx_s; a.part_rows = x->partx_r;
+            if (kpx == 16) rc = launch_exact<16, 1, 4>(x, a, mtx, s);
+            else if (kpx == 64) rc = launch_exact<64, 2, 2>(x, a, mtx, s);
+            else rc = launch_exact<128, 3, 1>(x, a, mtx, s);
+            if (rc) return rc;
+        }
         rec(x, 4, s);
         FinArgs g = f;
         g.part_scores = x->partx_s; g.part_rows = x->partx_r; g.P = px; g.KP = kpx;
@@ -260,6 +322,16 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         return p;
     };
 
+    const int p_sparse = FIN_MAX_CAND / kpx;   // lists per slot that finalize<false> merges (32 / 8 / 4)
+    // small batches (the reference's one-query-per-call shape): stream the corpus once, exact, no coarse pass
+    const bool stream_ok = x->dim % (32 * ST_PF) == 0;
+    const bool tiny = stream_ok && nq <= (use_fast ? 16 : ST_MAX_ACTIVE);
+    if (tiny) {
+        x->last_mode = ICD_MODE_EXACT;
+        x->last_chunks = p_sparse;
+        rec(x, 3, s);
+        return run_exact(nullptr, nullptr, p_sparse, false, true);
+    }
     if (!use_fast) {
         int px = pick_chunks(mtx, row_tiles, pmax_x, 2 * x->num_cu);
         px = fit_p(px, x->partx_cap, kpx);
@@ -270,7 +342,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         }
         x->last_chunks = px;
         rec(x, 3, s);
-        return run_exact(nullptr, nullptr, px);
+        return run_exact(nullptr, nullptr, px, true, false);
     }
 
     // ---- AUTO: prep -> coarse -> finalize(certify + rescore) -> exact fallback ------------------
@@ -284,7 +356,11 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
 
     const int mtc = nq_pad / 128;
     const int ctiles = x->n_pad / 128;
-    int pc = x->chunks_override > 0 ? x->chunks_override : pick_chunks(mtc, ctiles, COARSE_MAX_P, x->num_cu);
+    // At least two chunks: with one list per query the "largest dropped score" tau is the query's own
+    // 16th best and ~8 % of Gaussian queries fail the certificate (measured, profiles/r01_sizes.log);
+    // with two or more independent lists tau falls to about rank 32 and certification practically
+    // always succeeds.
+    int pc = x->chunks_override > 0 ? x->chunks_override : std::max(2, pick_chunks(mtc, ctiles, COARSE_MAX_P, x->num_cu));
     pc = std::min(pc, std::min(COARSE_MAX_P, ctiles));
     pc = fit_p(pc, x->partc_cap, CO_KP);
     {
@@ -326,14 +402,12 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         if (rc) return rc;
     }
     rec(x, 3, s);
-    // fallback: exact kernel over the flagged list; work-groups beyond the list exit at once
-    int px = fit_p(pmax_x, x->partx_cap, kpx);
-    px = std::min(px, row_tiles);
-    {
-        const int tiles_per = (row_tiles + px - 1) / px;
-        px = (row_tiles + tiles_per - 1) / tiles_per;
-    }
-    return run_exact(x->flagged, x->nflag, px);
+    // fallback over the flagged list, both device-side gated on its length: the streaming kernel for
+    // a sparse list (<= ST_MAX_ACTIVE queries), the fp32-MFMA kernel for a dense one. Both leave
+    // [slot][p_sparse][KP] lists for the same finalize launch.
+    int px = std::min(p_sparse, row_tiles);
+    if (px < p_sparse) return run_exact(x->flagged, x->nflag, px, true, false);   // tiny corpus: MFMA kernel only
+    return run_exact(x->flagged, x->nflag, p_sparse, true, stream_ok);
 }
 
 }  // namespace
@@ -426,6 +500,9 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     x->partx_cap = std::max<size_t>((size_t)x->max_nq_pad * 2 * exact_kp_for(max_k), (size_t)1 << 21);
     CR_TRY(wsalloc(&x->partx_s, x->partx_cap));
     CR_TRY(wsalloc(&x->partx_r, x->partx_cap));
+    x->lists_cap = (size_t)ST_MAX_ACTIVE * 1024 * exact_kp_for(max_k);
+    CR_TRY(wsalloc(&x->lists_s, x->lists_cap));
+    CR_TRY(wsalloc(&x->lists_r, x->lists_cap));
     CR_TRY(wsalloc(&x->nflag, 4));
     CR_TRY(hipMemset(x->nflag, 0, 4 * sizeof(int)));
     CR_TRY(wsalloc(&x->dbg, (size_t)8192 * 16));
