@@ -184,6 +184,14 @@ int launch_coarse8(icd_index *x, const CoarseArgs &a, int mtiles, hipStream_t s)
 // streaming exact kernel + list reduction for a sparse query set (device-side gated when nq_ptr is given)
 // streaming exact kernel + list reduction for a sparse query set (device-side gated when nq_ptr is given).
 // p_out = 0: choose the smallest number of output lists (direct tiny-batch path); returns it in *p_used.
+constexpr int LDS_LIMIT = 160 * 1024;   // LDS per CU (MI355X_MICROARCH.md)
+
+// does a pass of qb queries fit LDS with the minimum ring of two stages per wave?
+inline bool stream_fits(int kp, int qb, int dim) {
+    const int e = kp == 16 ? 2 : (kp == 64 ? 3 : 4);
+    return (size_t)qb * dim * 4 + (size_t)4 * 2 * ST_STAGE_BYTES + (size_t)4 * qb * 64 * e * 8 <= (size_t)LDS_LIMIT;
+}
+
 template <int KP, int E, int QB>
 int launch_stream(icd_index *x, const float *dq, const int *qlist, const int *nq_ptr, int nq, int max_active,
                   int p_out, int *p_used, hipStream_t s) {
@@ -199,9 +207,14 @@ int launch_stream(icd_index *x, const float *dq, const int *qlist, const int *nq
     a.corpus = x->corpus; a.queries = dq; a.qlist = qlist; a.nq_ptr = nq_ptr; a.nq = std::min(nq, max_active);
     a.max_active = max_active; a.n = n; a.dim = x->dim; a.rows_per_wg = rows_per_wg; a.nwg = nwg;
     a.list_scores = x->lists_s; a.list_rows = x->lists_r;
+    // wave-private LDS ring: as many 8-KB stages per wave as fit next to the queries and candidate buffers
+    int stages = 4;
+    while (stages > 2 && stream_lds_bytes<KP, E, QB>(x->dim, stages) > (size_t)LDS_LIMIT) --stages;
+    a.ring_stages = stages;
     if ((size_t)a.nq * 4 * nwg * KP > x->lists_cap) return fail(ICD_ERR_INVALID, "stream workspace too small");
     auto kern = stream_topk_kernel<KP, E, QB>;
-    const size_t lds = stream_lds_bytes<KP, E, QB>(x->dim);
+    const size_t lds = stream_lds_bytes<KP, E, QB>(x->dim, stages);
+    if (lds > (size_t)LDS_LIMIT) return fail(ICD_ERR_INVALID, "stream kernel: dim=%d does not fit LDS with %d queries per pass", x->dim, QB);
     static thread_local int configured_dev = -1;
     if (configured_dev != x->device) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -276,7 +289,8 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     // sparse: streaming kernel (+ list reduction) instead of / next to the MFMA exact kernel
     // queries per pass: host-known for direct calls (1, 2, 4 or 8), 8 for the device-gated fallback
     auto run_stream = [&](const int *qlist, const int *nq_ptr, int nqs, int p_out, int *p_used) -> int {
-        const int qb = nq_ptr ? 8 : (nqs <= 1 ? 1 : (nqs <= 2 ? 2 : (nqs <= 4 ? 4 : 8)));
+        int qb = nq_ptr ? 8 : (nqs <= 1 ? 1 : (nqs <= 2 ? 2 : (nqs <= 4 ? 4 : 8)));
+        while (qb > 1 && !stream_fits(kpx, qb, x->dim)) qb >>= 1;
 #define ICD_ST(KPV, EV) \
         (qb == 1 ? launch_stream<KPV, EV, 1>(x, dq, qlist, nq_ptr, nqs, ST_MAX_ACTIVE, p_out, p_used, s) : \
          qb == 2 ? launch_stream<KPV, EV, 2>(x, dq, qlist, nq_ptr, nqs, ST_MAX_ACTIVE, p_out, p_used, s) : \
@@ -295,6 +309,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             rc = run_stream(qlist, nq_ptr, nq, mfma ? px : 0, &used);   // alone: fewest output lists
             if (rc) return rc;
             px = used;
+            x->last_chunks = px;
         }
         if (mfma) {
             ExactArgs a{};
@@ -324,7 +339,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
 
     const int p_sparse = FIN_MAX_CAND / kpx;   // lists per slot that finalize<false> merges (32 / 8 / 4)
     // small batches (the reference's one-query-per-call shape): stream the corpus once, exact, no coarse pass
-    const bool stream_ok = x->dim % (32 * ST_PF) == 0;
+    const bool stream_ok = x->dim % (32 * ST_PF) == 0 && stream_fits(kpx, 1, x->dim);
     const bool tiny = stream_ok && nq <= (use_fast ? 16 : ST_MAX_ACTIVE);
     if (tiny) {
         x->last_mode = ICD_MODE_EXACT;
@@ -461,7 +476,9 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     } while (0)
 
     const size_t nelem = (size_t)n * dim;
-    CR_TRY(dmalloc(&x->corpus, nelem));
+    // ST_PAD_ROWS zero rows behind the corpus: the streaming kernel's stages run to the next 256-row boundary
+    CR_TRY(dmalloc(&x->corpus, nelem + (size_t)ST_PAD_ROWS * dim));
+    CR_TRY(hipMemset(x->corpus + nelem, 0, (size_t)ST_PAD_ROWS * dim * sizeof(float)));
     CR_TRY(hipMemcpy(x->corpus, corpus, nelem * sizeof(float), corpus_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     if (levels) {
         CR_TRY(dmalloc(&x->levels, (size_t)n));

@@ -8,10 +8,11 @@
 //   * the reference's own call shape, one query per call (services/milvus_service.py:280-285),
 //     and any small batch / large k.
 //
-// Work-group = 4 waves over a contiguous row range; a wave takes 64 rows at a time (lane = row),
-// 32-float slices are loaded as full 128-B lines (8 lanes per row), staged in a wave-private LDS
-// tile (row stride 36 floats: conflict-free ds_read_b128) and consumed d-ascending, so each
-// (row, query) score is bit-identical to oracle/icd_oracle.c chain_score(). Selection is the exact
+// Work-group = 4 waves over a contiguous row range; a wave takes 64 rows at a time (lane = row).
+// 32-float slices (full 128-B lines) go HBM -> LDS by buffer_load ... lds into a wave-private ring of
+// 2-4 stages (no VGPR staging, no barriers, counted vmcnt), 16-B pieces XOR-swizzled on the source side;
+// each lane reads its row back with ds_read_b128 and consumes it d-ascending, so each (row, query)
+// score is bit-identical to oracle/icd_oracle.c chain_score(). Bound: HBM (one corpus sweep per pass). Selection is the exact
 // rule (score desc, row asc) with a per-query threshold and the u64-key compaction of topk_select.hpp.
 // The candidate buffer of a (wave, query) holds 64 E entries with E one larger than the exact MFMA
 // kernel uses for the same KP: a 64-row step can append 64 entries at once.
@@ -22,12 +23,13 @@
 namespace icd {
 
 constexpr int ST_QB = 8;          // queries per pass (template QB <= ST_QB: fewer for tiny batches)
-constexpr int ST_TS = 36;         // tile row stride in floats (32 + 4)
-constexpr int ST_PF = 1;          // 32-float slices prefetched per lane
+constexpr int ST_PF = 1;          // dim must be a multiple of 32 * ST_PF
 constexpr int ST_MAX_ACTIVE = 64; // the sparse path is taken for at most this many queries
+constexpr int ST_STAGE_BYTES = 8192;   // one wave stage: 64 rows x 32 floats
+constexpr int ST_PAD_ROWS = 512;       // zero rows the index keeps behind the corpus (stages may run past n)
 
 struct StreamArgs {
-    const float *corpus;
+    const float *corpus;  // [n + ST_PAD_ROWS][dim], the tail zero-filled
     const float *queries;
     const int *qlist;     // nullable: slot -> query index
     const int *nq_ptr;    // nullable: device-side number of slots
@@ -36,98 +38,161 @@ struct StreamArgs {
     int n, dim;           // dim multiple of 32
     int rows_per_wg;      // multiple of 256
     int nwg;              // work-groups = row ranges
+    int ring_stages;      // 2..4 wave-private LDS stages
     float *list_scores;   // [slot][4 * nwg][KP]
     int *list_rows;
 };
 
 template <int KP, int E, int QB>
-__host__ __device__ constexpr size_t stream_lds_bytes(int dim) {
-    return (size_t)QB * dim * 4 + (size_t)4 * 64 * ST_TS * 4 + (size_t)4 * QB * 64 * E * 8;
+__host__ __device__ constexpr size_t stream_lds_bytes(int dim, int ring_stages) {
+    return (size_t)QB * dim * 4 + (size_t)4 * ring_stages * ST_STAGE_BYTES + (size_t)4 * QB * 64 * E * 8;
 }
+
+typedef float st_f32x4 __attribute__((ext_vector_type(4)));
+
+// acc[qi] = fma(q[qi][d], c[d], acc[qi]) for the four d of one 16-B piece, d ascending, as QB independent
+// chains. The query values live one per lane (lane & 15 = d & 15, replicated in the four DPP rows), and
+// row_newbcast:n hands lane n's value to every lane of the row: no LDS broadcast reads, no SGPR traffic.
+// v_fmac_f32 is the fused multiply-add of the canonical chain. The leading s_nop covers the
+// VALU-write -> DPP-read hazard should the compiler have placed a copy right before the block.
+#define ICD_F(a, q, c, n) "v_fmac_f32_dpp %" #a ", %" #q ", %" #c " row_newbcast:%" #n " row_mask:0xf bank_mask:0xf\n\t"
+template <int QB, int N0>
+__device__ __forceinline__ void stream_fma4(float (&acc)[QB], const float (&q)[QB], const st_f32x4 &c) {
+    if constexpr (QB == 1) {
+        asm volatile("s_nop 1\n\t" ICD_F(0, 1, 2, 6) ICD_F(0, 1, 3, 7) ICD_F(0, 1, 4, 8) ICD_F(0, 1, 5, 9)
+                     : "+v"(acc[0]) : "v"(q[0]), "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w),
+                       "n"(N0), "n"(N0 + 1), "n"(N0 + 2), "n"(N0 + 3));
+    } else if constexpr (QB == 2) {
+#define ICD_R2(c, n) ICD_F(0, 2, c, n) ICD_F(1, 3, c, n)
+        asm volatile("s_nop 1\n\t" ICD_R2(4, 8) ICD_R2(5, 9) ICD_R2(6, 10) ICD_R2(7, 11)
+                     : "+v"(acc[0]), "+v"(acc[1]) : "v"(q[0]), "v"(q[1]), "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w),
+                       "n"(N0), "n"(N0 + 1), "n"(N0 + 2), "n"(N0 + 3));
+#undef ICD_R2
+    } else if constexpr (QB == 4) {
+#define ICD_R4(c, n) ICD_F(0, 4, c, n) ICD_F(1, 5, c, n) ICD_F(2, 6, c, n) ICD_F(3, 7, c, n)
+        asm volatile("s_nop 1\n\t" ICD_R4(8, 12) ICD_R4(9, 13) ICD_R4(10, 14) ICD_R4(11, 15)
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+                     : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w),
+                       "n"(N0), "n"(N0 + 1), "n"(N0 + 2), "n"(N0 + 3));
+#undef ICD_R4
+    } else {
+        static_assert(QB == 8, "queries per pass: 1, 2, 4 or 8");
+#define ICD_R8(c, n) ICD_F(0, 8, c, n) ICD_F(1, 9, c, n) ICD_F(2, 10, c, n) ICD_F(3, 11, c, n) \
+                     ICD_F(4, 12, c, n) ICD_F(5, 13, c, n) ICD_F(6, 14, c, n) ICD_F(7, 15, c, n)
+        asm volatile("s_nop 1\n\t" ICD_R8(16, 20) ICD_R8(17, 21) ICD_R8(18, 22) ICD_R8(19, 23)
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                     : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]),
+                       "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w), "n"(N0), "n"(N0 + 1), "n"(N0 + 2), "n"(N0 + 3));
+#undef ICD_R8
+    }
+}
+#undef ICD_F
 
 template <int KP, int E, int QB>
 __global__ __launch_bounds__(256) void stream_topk_kernel(StreamArgs a) {
-    constexpr int ST_QB = QB;   // shadows the namespace constant inside the kernel
     constexpr int CAP = 64 * E;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nq = a.nq_ptr ? min(*a.nq_ptr, a.nq) : a.nq;
     if (nq <= 0 || nq > a.max_active) return;   // work-group-uniform
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int dim = a.dim, nsl = dim >> 5;
-    float *qs = reinterpret_cast<float *>(smem);                                   // [ST_QB][dim]
-    float *tile = qs + (size_t)ST_QB * dim + (size_t)wave * 64 * ST_TS;            // wave-private
-    u64 *bufs = reinterpret_cast<u64 *>(smem + (size_t)ST_QB * dim * 4 + (size_t)4 * 64 * ST_TS * 4) +
-                (size_t)wave * ST_QB * CAP;                                        // [ST_QB][CAP]
+    const int dim = a.dim, nsl = dim >> 5, D = a.ring_stages;
+    float *qs = reinterpret_cast<float *>(smem);                                   // [QB][dim]
+    const uint32_t ring_off = (uint32_t)QB * dim * 4 + (uint32_t)(wave * D) * ST_STAGE_BYTES;   // wave-private ring
+    u64 *bufs = reinterpret_cast<u64 *>(smem + (size_t)QB * dim * 4 + (size_t)4 * D * ST_STAGE_BYTES) +
+                (size_t)wave * QB * CAP;                                           // [QB][CAP]
     const int row_begin = blockIdx.x * a.rows_per_wg;
     const int row_end = min(a.n, row_begin + a.rows_per_wg);
+    const int nsteps = (row_end - row_begin + 255) >> 8;   // 256-row steps of the work-group, 64 rows per wave
     const int nlists = 4 * a.nwg;
 
-    for (int q0 = 0; q0 < nq; q0 += ST_QB) {
-        const int nqp = min(ST_QB, nq - q0);
+    // LDS-DMA source: lane L of piece i brings 16 B of row 8 i + (L >> 3); the 16-B pieces of a row are
+    // XOR-swizzled with (row >> 1) & 7 so that the row-per-lane ds_read_b128 below is conflict-free.
+    // The swizzle of piece i depends on i only through its parity: two per-lane offsets.
+    const uint32_t row_bytes = (uint32_t)dim * 4u;
+    const uint32_t voff_even = (uint32_t)(lane >> 3) * row_bytes + (uint32_t)(((lane & 7) ^ (lane >> 4)) * 16);
+    const uint32_t voff_odd = (uint32_t)(lane >> 3) * row_bytes + (uint32_t)(((lane & 7) ^ (4 + (lane >> 4))) * 16);
+    const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.corpus) + (size_t)row_begin * dim, 0, (int)((size_t)nsteps * 256 * row_bytes), 0x00020000);
+    const uint32_t rd_base = (uint32_t)lane * 128u + (uint32_t)(((lane >> 1) & 7) * 16);
+    const uint32_t q_lane = (uint32_t)(lane & 15) * 4u;
+
+    for (int q0 = 0; q0 < nq; q0 += QB) {
+        const int nqp = min(QB, nq - q0);
         __syncthreads();   // previous pass is done with qs
-        for (int i = tid * 4; i < ST_QB * dim; i += 1024) {
+        for (int i = tid * 4; i < QB * dim; i += 1024) {
             const int qi = i / dim, d = i - qi * dim;
             const int slot = q0 + min(qi, nqp - 1);   // unused slots repeat the last query (never emitted)
             const int gq = a.qlist ? a.qlist[slot] : slot;
             *reinterpret_cast<float4 *>(qs + i) = *reinterpret_cast<const float4 *>(a.queries + (size_t)gq * dim + d);
         }
         __syncthreads();
-        float thr[ST_QB];
-        uint32_t thr_row[ST_QB];
-        int cnt[ST_QB];
+        float thr[QB];
+        uint32_t thr_row[QB];
+        int cnt[QB];
 #pragma unroll
-        for (int qi = 0; qi < ST_QB; ++qi) { thr[qi] = -INFINITY; thr_row[qi] = 0u; cnt[qi] = 0; }
+        for (int qi = 0; qi < QB; ++qi) { thr[qi] = -INFINITY; thr_row[qi] = 0u; cnt[qi] = 0; }
 
-        for (int r0 = row_begin + wave * 64; r0 < row_end; r0 += 256) {
-            float acc[ST_QB];
+        // stage cursor of the DMA stream: (step, slice) -> ring slot; runs D - 1 stages ahead of the reader.
+        // Past the last stage it re-reads the last step (valid memory, never consumed).
+        int is_t = 0, is_s = 0, is_slot = 0;
+        auto issue = [&]() {
+            const uint32_t soff = (uint32_t)(wave * 64 + 256 * min(is_t, nsteps - 1)) * row_bytes + (uint32_t)is_s * 128u;
+            const uint32_t dst = ring_off + (uint32_t)is_slot * ST_STAGE_BYTES;
 #pragma unroll
-            for (int qi = 0; qi < ST_QB; ++qi) acc[qi] = 0.0f;
-            // this lane fetches piece (lane & 7) of rows r0 + 8 i + (lane >> 3), i = 0..7. Named scalars,
-            // not arrays: hipcc keeps arrays of float4 / pointers in scratch here, and a scratch round
-            // trip per slice is slower than the HBM stream this kernel is meant to be bound by.
-#define ICD_ROWPTR(i) (a.corpus + (size_t)min(r0 + (i) * 8 + (lane >> 3), a.n - 1) * dim + (lane & 7) * 4)
-            const float *s0 = ICD_ROWPTR(0), *s1 = ICD_ROWPTR(1), *s2 = ICD_ROWPTR(2), *s3 = ICD_ROWPTR(3);
-            const float *s4 = ICD_ROWPTR(4), *s5 = ICD_ROWPTR(5), *s6 = ICD_ROWPTR(6), *s7 = ICD_ROWPTR(7);
-#undef ICD_ROWPTR
-#define ICD_LD(p, o) (*reinterpret_cast<const float4 *>((p) + (o)))
-            float4 p0 = ICD_LD(s0, 0), p1 = ICD_LD(s1, 0), p2 = ICD_LD(s2, 0), p3 = ICD_LD(s3, 0);
-            float4 p4 = ICD_LD(s4, 0), p5 = ICD_LD(s5, 0), p6 = ICD_LD(s6, 0), p7 = ICD_LD(s7, 0);
-            float *wdst = tile + (lane >> 3) * ST_TS + (lane & 7) * 4;
+            for (int i = 0; i < 8; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, (__attribute__((address_space(3))) void *)(smem + dst + i * 1024),
+                                                         16, (i & 1) ? voff_odd : voff_even, soff + (uint32_t)i * 8u * row_bytes, 0, 0);
+            if (++is_s == nsl) { is_s = 0; ++is_t; }
+            if (++is_slot == D) is_slot = 0;
+        };
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the vmcnt accounting below starts from zero
+        for (int p = 0; p < D - 1; ++p) issue();
+        int rslot = 0;
+
+        for (int t = 0; t < nsteps; ++t) {
+            const int r0 = row_begin + wave * 64 + 256 * t;
+            float acc[QB];
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi) acc[qi] = 0.0f;
             for (int s = 0; s < nsl; ++s) {
-                *reinterpret_cast<float4 *>(wdst + 0 * 8 * ST_TS) = p0;
-                *reinterpret_cast<float4 *>(wdst + 1 * 8 * ST_TS) = p1;
-                *reinterpret_cast<float4 *>(wdst + 2 * 8 * ST_TS) = p2;
-                *reinterpret_cast<float4 *>(wdst + 3 * 8 * ST_TS) = p3;
-                *reinterpret_cast<float4 *>(wdst + 4 * 8 * ST_TS) = p4;
-                *reinterpret_cast<float4 *>(wdst + 5 * 8 * ST_TS) = p5;
-                *reinterpret_cast<float4 *>(wdst + 6 * 8 * ST_TS) = p6;
-                *reinterpret_cast<float4 *>(wdst + 7 * 8 * ST_TS) = p7;
-                if (s + 1 < nsl) {
-                    const int o = (s + 1) * 32;
-                    p0 = ICD_LD(s0, o); p1 = ICD_LD(s1, o); p2 = ICD_LD(s2, o); p3 = ICD_LD(s3, o);
-                    p4 = ICD_LD(s4, o); p5 = ICD_LD(s5, o); p6 = ICD_LD(s6, o); p7 = ICD_LD(s7, o);
-                }
-                const float4 *c4 = reinterpret_cast<const float4 *>(tile + lane * ST_TS);
+                // stage (t, s) has landed when at most D - 2 younger stages are outstanding
+                if (D == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (D == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                issue();   // into the slot read one slice ago (those reads completed before its fmas)
+                const uint32_t ad = ring_off + (uint32_t)rslot * ST_STAGE_BYTES + rd_base;
+                if (++rslot == D) rslot = 0;
+                st_f32x4 c0, c1, c2, c3, c4, c5, c6, c7;
+                asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"
+                             "ds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\tds_read_b128 %6, %14\n\tds_read_b128 %7, %15"
+                             : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&v"(c4), "=&v"(c5), "=&v"(c6), "=&v"(c7)
+                             : "v"(ad), "v"(ad ^ 16u), "v"(ad ^ 32u), "v"(ad ^ 48u), "v"(ad ^ 64u), "v"(ad ^ 80u), "v"(ad ^ 96u), "v"(ad ^ 112u)
+                             : "memory");
+                float qlo[QB], qhi[QB];   // q[qi][32 s + (lane & 15)], q[qi][32 s + 16 + (lane & 15)]
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float4 cv = c4[j];
-#pragma unroll
-                    for (int qi = 0; qi < ST_QB; ++qi) {
-                        const float4 qv = *reinterpret_cast<const float4 *>(qs + qi * dim + s * 32 + j * 4);  // broadcast
-                        acc[qi] = __builtin_fmaf(qv.x, cv.x, acc[qi]);
-                        acc[qi] = __builtin_fmaf(qv.y, cv.y, acc[qi]);
-                        acc[qi] = __builtin_fmaf(qv.z, cv.z, acc[qi]);
-                        acc[qi] = __builtin_fmaf(qv.w, cv.w, acc[qi]);
-                    }
+                for (int qi = 0; qi < QB; ++qi) {
+                    const uint32_t qa = q_lane + (uint32_t)s * 128u + (uint32_t)qi * row_bytes;
+                    asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:64" : "=&v"(qlo[qi]), "=&v"(qhi[qi]) : "v"(qa) : "memory");
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) :: "memory");
+#pragma unroll
+                for (int qi = 0; qi < QB; ++qi) asm volatile("" : "+v"(qlo[qi]), "+v"(qhi[qi]));
+                stream_fma4<QB, 0>(acc, qlo, c0);
+                stream_fma4<QB, 4>(acc, qlo, c1);
+                stream_fma4<QB, 8>(acc, qlo, c2);
+                stream_fma4<QB, 12>(acc, qlo, c3);
+                stream_fma4<QB, 0>(acc, qhi, c4);
+                stream_fma4<QB, 4>(acc, qhi, c5);
+                stream_fma4<QB, 8>(acc, qhi, c6);
+                stream_fma4<QB, 12>(acc, qhi, c7);
             }
-#undef ICD_LD
             // exact select: (score desc, row asc); NaN and -inf never enter
             const uint32_t row = (uint32_t)(r0 + lane);
             const bool rvalid = (int)row < row_end;
 #pragma unroll
-            for (int qi = 0; qi < ST_QB; ++qi) {
+            for (int qi = 0; qi < QB; ++qi) {
                 const float v = acc[qi];
                 const bool pass = rvalid && (v > thr[qi] || (v == thr[qi] && row < thr_row[qi])) && v != -INFINITY;
                 const u64 m = __ballot(pass);
@@ -147,9 +212,10 @@ __global__ __launch_bounds__(256) void stream_topk_kernel(StreamArgs a) {
                 }
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the run-ahead stages before the ring is reused
         // this wave's best-first list of every query of the pass
 #pragma unroll
-        for (int qi = 0; qi < ST_QB; ++qi) {
+        for (int qi = 0; qi < QB; ++qi) {
             if (qi < nqp) {
                 u64 *qb = bufs + (size_t)qi * CAP;
                 u64 kth;
