@@ -151,15 +151,6 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
     // 2. rank all candidates; keep the best T sorted
     const int T = RESCORE ? 64 : k;
     int rank[FIN_EF];
-#pragma unroll
-    for (int e = 0; e < FIN_EF; ++e) rank[e] = 0;
-    const int ef = (ncand + 63) >> 6;
-    for (int j = 0; j < ncand; ++j) {
-        const u64 kj = keys[j];
-#pragma unroll
-        for (int e = 0; e < FIN_EF; ++e)
-            if (e < ef) rank[e] += (kj > key[e]) ? 1 : 0;
-    }
     float tau = -INFINITY;  // largest coarse score that may have been dropped anywhere
     if (RESCORE) {
         // chunk lists that are full may have dropped rows scoring up to their last entry
@@ -173,6 +164,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
             }
         }
     }
+    rank_top<FIN_EF>(key, rank, ncand, T, keys, lane);   // (may replace keys[] by the survivor list)
 #pragma unroll
     for (int e = 0; e < FIN_EF; ++e) {
         if (key[e] != 0ull) {

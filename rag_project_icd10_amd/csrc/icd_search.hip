@@ -302,14 +302,14 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
 #undef ICD_ST
     };
     auto run_exact = [&](const int *qlist, const int *nq_ptr, int px, bool mfma, bool stream) -> int {
-        x->last_chunks = px;
+        if (!nq_ptr) x->last_chunks = px;   // (the fallback keeps the coarse pass's chunk count)
         int rc = ICD_OK;
         if (stream) {
             int used = px;
             rc = run_stream(qlist, nq_ptr, nq, mfma ? px : 0, &used);   // alone: fewest output lists
             if (rc) return rc;
             px = used;
-            x->last_chunks = px;
+            if (!nq_ptr) x->last_chunks = px;
         }
         if (mfma) {
             ExactArgs a{};

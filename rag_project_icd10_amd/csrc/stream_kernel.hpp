@@ -273,14 +273,8 @@ __global__ __launch_bounds__(256) void reduce_lists_kernel(ReduceArgs a) {
             keys[i] = key[e];
         }
     }
-    int rank[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int ef = (ncand + 63) >> 6;
-    for (int j = 0; j < ncand; ++j) {
-        const u64 kj = keys[j];
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (e < ef) rank[e] += (kj > key[e]) ? 1 : 0;
-    }
+    int rank[8];
+    rank_top<8>(key, rank, ncand, a.KP, keys, lane);
     int nvalid = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) nvalid += __popcll(__ballot(key[e] != 0ull));

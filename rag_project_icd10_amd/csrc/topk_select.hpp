@@ -47,6 +47,48 @@ __device__ __forceinline__ u64 readlane_u64(u64 v, int l) {
     return ((u64)hi << 32) | lo;
 }
 
+// Rank the wave's candidates for a top-T selection. key[e] = candidate lane + 64 e (0 = empty), also staged
+// at keys_lds[0..ncand). On return rank[e] is EXACT for every key whose true rank is below T, and >= T for
+// every other key (a key of true rank T keeps rank == T or ties with others at the survivor count).
+// Small sets: plain rank-by-counting over all candidates. Large sets with T <= 64: first bound the T-th
+// best from below by the T-th largest of the 64 lane maxima (T distinct keys are >= it), keep only the
+// keys >= that bound (at most T lanes hold any: <= T * NE survivors, typically ~T), and count over the
+// survivors only. keys_lds is overwritten by the survivor list in that case.
+template <int NE>
+__device__ __forceinline__ void rank_top(const u64 (&key)[NE], int (&rank)[NE], int ncand, int T, u64 *keys_lds, int lane) {
+    const int ef = (ncand + 63) >> 6;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) rank[e] = 0;
+    int nlist = ncand;
+    if (T <= 64 && ncand > 128) {
+        u64 lmax = 0ull;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) lmax = key[e] > lmax ? key[e] : lmax;
+        int above = 0;   // lanes whose maximum beats this lane's (keys are unique; empty lanes hold 0)
+        for (int l = 0; l < 64; ++l) above += (readlane_u64(lmax, l) > lmax) ? 1 : 0;
+        const u64 hit = __ballot(lmax != 0ull && above == T - 1);
+        const u64 bound = hit ? readlane_u64(lmax, __ffsll((long long)hit) - 1) : 0ull;   // < T non-empty lanes: keep all
+        const u64 lt = (1ull << lane) - 1ull;
+        int ns = 0;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            if (e < ef) {
+                const bool keep = key[e] != 0ull && key[e] >= bound;
+                const u64 m = __ballot(keep);
+                if (keep) keys_lds[ns + __popcll(m & lt)] = key[e];
+                ns += __popcll(m);
+            }
+        }
+        nlist = ns;
+    }
+    for (int j = 0; j < nlist; ++j) {
+        const u64 kj = keys_lds[j];
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+            if (e < ef) rank[e] += (kj > key[e]) ? 1 : 0;
+    }
+}
+
 // Per-lane select state (query-level values are duplicated in lanes l and l+32).
 struct SelState {
     float thr;         // score of the query's current KP-th best (−inf until KP candidates exist)
