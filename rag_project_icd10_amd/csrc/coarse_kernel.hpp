@@ -40,7 +40,7 @@ constexpr int CO_S = 4;
 constexpr int CO_STAGE_BYTES = CO_BN * CO_BK * 2;  // 16384
 constexpr int CO_RING_BYTES = CO_S * CO_STAGE_BYTES;
 constexpr int CO_CAP = 64;
-constexpr int CO_CHECK_EVERY = 16;                      // registers between overflow checks (2 lanes append per register)
+constexpr int CO_CHECK_EVERY = 8;                       // registers between overflow checks (2 lanes append per register)
 constexpr int CO_LIMIT = CO_CAP - 2 * CO_CHECK_EVERY;    // compact a query once it holds more entries than this
 constexpr int CO_LDS_BYTES = CO_RING_BYTES + CO_BM * CO_CAP * 8 + 4 * 256;
 
@@ -127,6 +127,9 @@ __global__ __launch_bounds__(256, 1) void coarse_topk_kernel(CoarseArgs a) {
     constexpr int NKSTEP = KS * 4;     // k16-steps per tile
     constexpr bool NOSELECT = (VAR & 1) != 0, STAMPS = (VAR & 8) != 0, OVERLAP = (VAR & 16) != 0 || (VAR & 2048) != 0;
     constexpr bool MANUAL = (VAR & 2048) != 0, SPLITSEL = (VAR & 4096) != 0;
+    constexpr int CHK = (VAR & 32) ? 4 : ((VAR & 64) ? 16 : CO_CHECK_EVERY);  // registers between overflow checks (A/B: 4, 16)
+    constexpr int LIM = CO_CAP - 2 * CHK;                                        // compact above this many entries
+    constexpr bool NOBAR = (VAR & 8192) != 0, NOREAD = (VAR & 16384) != 0;   // timing ablations only (results invalid)
     constexpr bool NODMA = (VAR & 128) != 0, PIPE = MANUAL || (VAR & 512) != 0, TILE_END_COMPACT = (VAR & 1024) != 0;
     static_assert(KS % CO_S == 0, "ring slot must be a compile-time function of the stage");
     using Ops = Sel2Ops<CO_KP>;
@@ -186,6 +189,11 @@ __global__ __launch_bounds__(256, 1) void coarse_topk_kernel(CoarseArgs a) {
         for (int s = 0; s < 4; ++s) rd_off[s] = (uint32_t)c * 128u + (uint32_t)(((2 * s + h) ^ sw) * 16);
     }
     auto read_frags = [&](half8 (&f)[4], int ring_slot, int s) {
+        if constexpr (NOREAD) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(f[t]));
+            return;
+        }
         const char *sb = smem + ring_slot * CO_STAGE_BYTES + rd_off[s];
 #pragma unroll
         for (int t = 0; t < 4; ++t) f[t] = *reinterpret_cast<const half8 *>(sb + t * 4096);
@@ -208,12 +216,18 @@ __global__ __launch_bounds__(256, 1) void coarse_topk_kernel(CoarseArgs a) {
         if constexpr (decltype(GUARD)::value) {
             if ((int)(rowbase + roff) >= a.n) v = -INFINITY;
         }
-        if (v > st.thr) {
-            *reinterpret_cast<float *>(smem + st.aw) = v;
-            *reinterpret_cast<uint32_t *>(smem + st.aw + Ops::ROW_OFF) = rowbase + roff;
-            st.aw += st.inc;
+        // wave-uniform skip first (v_cmp + one scalar branch when no lane passes: the common case once the
+        // thresholds have warmed up), the per-lane append only behind it
+        const bool pass = v > st.thr;
+        if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
+            asm volatile("" ::: "memory");   // keeps the scalar branch: without it the two conditions are merged into a predicate
+            if (pass) {
+                *reinterpret_cast<float *>(smem + st.aw) = v;
+                *reinterpret_cast<uint32_t *>(smem + st.aw + Ops::ROW_OFF) = rowbase + roff;
+                st.aw += st.inc;
+            }
         }
-        if constexpr (r % CO_CHECK_EVERY == CO_CHECK_EVERY - 1) Ops::check(st, lane, smem, wave_qbase, wave_scratch, false, CO_LIMIT, STAMPS ? cprof : nullptr);
+        if constexpr (r % CHK == CHK - 1) Ops::check(st, lane, smem, wave_qbase, wave_scratch, false, LIM, STAMPS ? cprof : nullptr);
     };
     auto filter_tile = [&](const f32x16 (&pa)[4], int tile_row0) {
         const uint32_t rowbase = (uint32_t)(tile_row0 + 4 * h);
@@ -299,8 +313,8 @@ __global__ __launch_bounds__(256, 1) void coarse_topk_kernel(CoarseArgs a) {
                     if constexpr (!NOSELECT && f >= 0 && f < 64) {
                         constexpr int t = f >> 4, r = f & 15;
                         fapp_asm<t * 32 + (r & 3) + 8 * (r >> 2)>(st.aw, pacc[t][r], msk[f & 3], prev_rowbase, st.inc);
-                        if constexpr (r % CO_CHECK_EVERY == CO_CHECK_EVERY - 1)
-                            Ops::check(st, lane, smem, wave_qbase, wave_scratch, false, CO_LIMIT, STAMPS ? cprof : nullptr);
+                        if constexpr (r % CHK == CHK - 1)
+                            Ops::check(st, lane, smem, wave_qbase, wave_scratch, false, LIM, STAMPS ? cprof : nullptr);
                     }
                 };
                 auto kstep = [&](const half8 (&f)[4], auto S) {
@@ -330,8 +344,8 @@ __global__ __launch_bounds__(256, 1) void coarse_topk_kernel(CoarseArgs a) {
                         mfma1(std::integral_constant<int, 2>{}, f[2], std::integral_constant<int, j>{});
                         if constexpr (f1 > f0 + 1) fstep(std::integral_constant<int, f0 + 1>{});
                         mfma1(std::integral_constant<int, 3>{}, f[3], std::integral_constant<int, j>{});
-                        if constexpr (!NOSELECT && ((f1 - 1) % CO_CHECK_EVERY) == CO_CHECK_EVERY - 1 && f1 > f0)
-                            Ops::check(st, lane, smem, wave_qbase, wave_scratch, false, CO_LIMIT, STAMPS ? cprof : nullptr);
+                        if constexpr (!NOSELECT && ((f1 - 1) % CHK) == CHK - 1 && f1 > f0)
+                            Ops::check(st, lane, smem, wave_qbase, wave_scratch, false, LIM, STAMPS ? cprof : nullptr);
                     }
                 };
                 half8 f1[4], f2[4], f3[4];
@@ -372,7 +386,8 @@ __global__ __launch_bounds__(256, 1) void coarse_topk_kernel(CoarseArgs a) {
                 if (STAMPS) { ICD_STAMP(t2); t_body += t2 - t1; }
                 // publish stage g+1: this wave's pieces of g+1 have landed when only g+2 is outstanding
                 __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if constexpr (NOBAR) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 if (STAMPS) { ICD_STAMP(t1); t_wait += t1 - t2; }
                 {   // every wave is past stage g-1: its slot takes stage g+3

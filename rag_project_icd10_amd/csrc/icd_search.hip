@@ -401,7 +401,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             else if (var == 10001) rc = launch_coarse8<768, 1>(x, a, mtc, s);
 #define ICD_VAR_CASE(V) else if (var == V) rc = launch_coarse<768, V>(x, a, mtc, s);
             ICD_VAR_CASE(0) ICD_VAR_CASE(1) ICD_VAR_CASE(8) ICD_VAR_CASE(129) ICD_VAR_CASE(512) ICD_VAR_CASE(513)
-            ICD_VAR_CASE(520) ICD_VAR_CASE(528) ICD_VAR_CASE(2048) ICD_VAR_CASE(6144)
+            ICD_VAR_CASE(520) ICD_VAR_CASE(528) ICD_VAR_CASE(576) ICD_VAR_CASE(584) ICD_VAR_CASE(6144) ICD_VAR_CASE(6208) ICD_VAR_CASE(2048) ICD_VAR_CASE(2112) ICD_VAR_CASE(641) ICD_VAR_CASE(8833) ICD_VAR_CASE(17025) ICD_VAR_CASE(25217)
 #undef ICD_VAR_CASE
             else
 #endif

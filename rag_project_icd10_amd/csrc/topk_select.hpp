@@ -193,10 +193,13 @@ __device__ __forceinline__ void filter16(const f32x16 &acc, uint32_t row0, SelSt
 // Per query: score[64] f32 | row[64] u32 (512 B). Lane h=0 of the query's lane pair appends upward
 // from slot `kept`, lane h=1 downward from slot 63, so an append needs no cross-lane slot arithmetic:
 //     if (v > thr) { score[w] = v; row[w] = r; w += step; }
-// Compaction ranks the <= 64 entries by a unique 32-bit key = (ordered score with its 6 low bits
-// replaced by 63 - slot): 16 broadcast ds_read_b128 + 64 compare/add pairs, no dependent LDS latency.
-// The 6 dropped bits are a relative 2^-17 perturbation of the coarse score; finalize.hpp widens tau
-// by that much (COARSE_KEY_SLACK).
+// Compaction during the sweep: one entry per lane, the KP-th best score is bisected with wave ballots
+// (v_cmp + s_bcnt1 per probe, no LDS traffic), the KP entries above it move to the front (unsorted)
+// and the probe becomes the new threshold. The final compaction (and score ties) rank the <= 64
+// entries by a unique 32-bit key = (ordered score with its 6 low bits replaced by 63 - slot):
+// 16 broadcast ds_read_b128 + 64 compare/add pairs; it leaves the list sorted best-first. The 6 dropped
+// bits are a relative 2^-17 perturbation of the coarse score; finalize.hpp widens tau by that much
+// (COARSE_KEY_SLACK).
 // =====================================================================================================
 namespace icd {
 
@@ -268,6 +271,46 @@ struct Sel2Ops {
                 v = *reinterpret_cast<const float *>(smem + qb + lane * 4);
                 row = *reinterpret_cast<const uint32_t *>(smem + qb + ROW_OFF + lane * 4);
             }
+            const int nvalid = nlo + nhi;
+            if (!force && nvalid > KP) {
+                // ---- fast path: bisect the KP-th best score with wave ballots (no LDS traffic) -----------
+                // Invariant: count(okey > lo) >= KP > count(okey > hi). Every entry beats the query's
+                // current threshold, so lo starts there; hi starts at the largest entry. Ends when a probe
+                // leaves exactly KP entries above it; score ties that make that impossible fall through
+                // to the ranking path below (unique keys).
+                const uint32_t okey = valid ? order_f32(v) : 0u;
+                uint32_t mx = okey;
+                mx = max(mx, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mx, 0x111, 0xf, 0xf, false));   // row_shr:1
+                mx = max(mx, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mx, 0x112, 0xf, 0xf, false));   // row_shr:2
+                mx = max(mx, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mx, 0x114, 0xf, 0xf, false));   // row_shr:4
+                mx = max(mx, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mx, 0x118, 0xf, 0xf, false));   // row_shr:8
+                mx = max(mx, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mx, 0x142, 0xa, 0xf, false));   // row_bcast:15
+                mx = max(mx, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mx, 0x143, 0xc, 0xf, false));   // row_bcast:31
+                uint32_t hi_s = readlane<uint32_t>(mx, 63);
+                uint32_t lo_s = order_f32(__builtin_bit_cast(float, readlane<uint32_t>(__float_as_uint(s.thr), b)));
+                int c = nvalid;
+                while (c != KP && hi_s - lo_s > 1u) {
+                    const uint32_t mid = lo_s + ((hi_s - lo_s) >> 1);
+                    const int cm = __popcll(__ballot(okey > mid));
+                    if (cm >= KP) { lo_s = mid; c = cm; } else hi_s = mid;
+                }
+                if (c == KP) {
+                    const bool keep = okey > lo_s;
+                    const u64 km = __ballot(keep);
+                    const int dest = __popcll(km & ((1ull << lane) - 1ull));
+                    if (keep) {
+                        *reinterpret_cast<float *>(smem + qb + dest * 4) = v;
+                        *reinterpret_cast<uint32_t *>(smem + qb + ROW_OFF + dest * 4) = row;
+                    }
+                    if ((lane & 31) == b) {
+                        s.thr = unorder_f32(lo_s);   // every kept entry is above it, every dropped one at or below
+                        s.kept = KP;
+                        s.aw0 = h ? qb + (CAP - 1) * 4 : qb + (uint32_t)KP * 4;
+                        s.aw = s.aw0;
+                    }
+                    continue;
+                }
+            }
             const uint32_t key = valid ? ((order_f32(v) & ~63u) | (uint32_t)(63 - lane)) : 0u;
             *reinterpret_cast<uint32_t *>(smem + wave_scratch + lane * 4) = key;
             int rank = 0;
@@ -295,7 +338,6 @@ struct Sel2Ops {
                     rank += (k3.x > key) + (k3.y > key) + (k3.z > key) + (k3.w > key);
                 }
             }
-            const int nvalid = nlo + nhi;
             if (valid && rank < KP) {
                 *reinterpret_cast<float *>(smem + qb + rank * 4) = v;
                 *reinterpret_cast<uint32_t *>(smem + qb + ROW_OFF + rank * 4) = row;
