@@ -75,6 +75,49 @@ def test_exact_ties_and_id_base(oracle):
         idx.close()
 
 
+def test_heavy_duplicates_through_the_coarse_path(oracle):
+    """40 identical corpus rows that are every query's best hits: all coarse scores tie, the ballot bisection
+    of the select cannot split them and must fall back to the unique-key ranking; ids come out row-ascending."""
+    corpus = unit_rows(5000, 768, 55)
+    corpus[100:140] = corpus[100]
+    rng = np.random.default_rng(56)
+    queries = corpus[100][None, :] + 0.03 * rng.standard_normal((150, 768)).astype(np.float32)
+    queries = (queries / np.linalg.norm(queries, axis=1, keepdims=True)).astype(np.float32)
+    levels = icd_levels(5000, 57)
+    idx = IcdIndex(corpus, levels, max_nq=150, max_k=10)
+    st = _check(oracle, idx, corpus, levels, queries, 10, MODE_AUTO)
+    assert st["last_mode"] == MODE_AUTO
+    s, i = idx.search(queries, 10, MODE_AUTO)
+    assert np.array_equal(i, np.tile(np.arange(100, 110), (150, 1)))
+    idx.close()
+
+
+@pytest.mark.parametrize("n,nq,dim,k,mode", [
+    (3000, 1, 1024, 10, MODE_AUTO), (3000, 3, 1024, 64, MODE_AUTO), (2500, 2, 96, 7, MODE_AUTO),
+    (9000, 40, 768, 10, MODE_EXACT), (9000, 64, 768, 100, MODE_EXACT), (700, 16, 768, 128, MODE_AUTO),
+    (257, 7, 2048, 10, MODE_EXACT),
+])
+def test_streaming_kernel_variants(oracle, n, nq, dim, k, mode):
+    """small batches take stream_topk: every (queries-per-pass, list length) instantiation, several passes,
+    dims other than 768, k up to the ABI maximum"""
+    corpus, levels, queries = unit_rows(n, dim, 90 + n), icd_levels(n, 91 + n), unit_rows(nq, dim, 92 + n)
+    idx = IcdIndex(corpus, levels, max_nq=64, max_k=128)
+    st = _check(oracle, idx, corpus, levels, queries, k, mode)
+    assert st["last_mode"] == MODE_EXACT
+    idx.close()
+
+
+def test_dense_fallback_list_takes_the_mfma_exact_kernel(oracle):
+    """more than 64 uncertified queries: the device-side gate routes the fallback to exact_topk, not stream_topk"""
+    corpus, levels = unit_rows(3000, 768, 95), icd_levels(3000, 96)
+    queries = unit_rows(300, 768, 97)
+    queries[::3, 11] = 1e6        # 100 queries whose fp16 image overflows
+    idx = IcdIndex(corpus, levels, max_nq=300, max_k=10)
+    st = _check(oracle, idx, corpus, levels, queries, 10, MODE_AUTO)
+    assert st["last_fallback"] == 100
+    idx.close()
+
+
 def test_dim_other_than_fast_path(oracle):
     corpus, levels, queries = unit_rows(900, 64, 60), icd_levels(900, 61), unit_rows(11, 64, 62)
     idx = IcdIndex(corpus, levels, max_nq=16, max_k=10)
