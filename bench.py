@@ -16,7 +16,7 @@ With N > 1 every rank holds a corpus replica and its own query batch (data-paral
 the data path: weak scaling); `value` is the whole-job rate = N * nq * K / max-over-ranks time.
 
 The JSON line also carries
-    roofline      dominant kernel (coarse_topk): algorithmic FLOPs 2*nq*n*dim per launch / its mean
+    roofline      dominant kernel (coarse_flat_kernel): algorithmic FLOPs 2*nq*n*dim per launch / its mean
                   duration over the timed steps (hipEvents recorded by the library on the search
                   stream), against the dense fp16/bf16 MFMA peak (2.5 PFLOP/s);
     cpu_baseline  the reference's call shape on the host CPU (one query per call: fp32 scan + top-k +
@@ -161,7 +161,7 @@ def main():
             "recall_at_10": recall, "ids_exact": ids_exact, "max_abs_dscore": max_dscore,
             "fallback_queries": int(stats["last_fallback"]), "coarse_chunks": int(stats["last_chunks"]),
             "kernel_ms": {kname: round(v, 5) for kname, v in prof.items() if kname != "count"},
-            "roofline": {"bound": "mfma", "kernel": "coarse_topk_kernel" if stats["last_mode"] == MODE_AUTO else "exact_topk_kernel",
+            "roofline": {"bound": "mfma", "kernel": "coarse_flat_kernel" if stats["last_mode"] == MODE_AUTO else "exact_topk_kernel",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": None, "flops_per_launch": flops, "launch_ms": dom_ms, "launches_averaged": prof["count"]},
         }

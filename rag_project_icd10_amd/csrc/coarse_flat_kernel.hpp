@@ -1,0 +1,284 @@
+// coarse_flat_kernel.hpp — the product form of the fp16-MFMA coarse pass: coarse_kernel.hpp's
+// software-pipelined stage (VAR 512) over a FLAT partition of the (query tile x corpus tile) grid.
+//
+// Replaces the scoring + k-selection inside MilvusClient.search on the FLAT/IP index
+// (services/milvus_service.py:280-285) for batches; exactness is restored by finalize.hpp.
+//
+// Work unit = one 128-query x 128-row tile. Units are numbered u = mtile * ctiles + tile and work-group w
+// takes the contiguous range [w U, (w+1) U): with U = ceil(units / CUs) every CU gets the same number of
+// tiles whatever the ratio of query tiles to CUs is (the (mtile, chunk) grid of coarse_kernel.hpp left 19 of
+// 256 CUs idle at 79 query tiles x 3 chunks). A work-group's run inside one query tile is cut into lists of at
+// most `list_tiles` tiles; every list is one top-KP candidate list of that query tile:
+//     part[query][ordinal][KP] (unsorted, -1 rows = empty) and bounds[query][ordinal]
+// where bounds = the list's final threshold = an upper bound on every score the list dropped (-inf if it
+// dropped nothing). Ordinals count the lists of a query tile in row order; the work-group that reaches the end
+// of a query tile also writes the unused ordinals as empty.
+#pragma once
+#include "coarse_kernel.hpp"
+
+namespace icd {
+
+struct CoarseFlatArgs {
+    const _Float16 *q16;     // [nq_pad][D], rows >= nq are zero
+    const _Float16 *c16;     // [n_pad][D], rows >= n are zero
+    int nq;
+    int n;                   // valid rows
+    int n_pad;               // multiple of 128
+    int ctiles;              // n_pad / 128
+    int total_units;         // query tiles * ctiles
+    int units_per_wg;        // U
+    int list_tiles;          // a list covers at most this many tiles
+    int P;                   // list slots per query (>= the largest number of lists of any query tile)
+    float *part_scores;      // [nq][P][KP]
+    int *part_rows;
+    float *bounds;           // [nq][P]
+    unsigned int *shared_thr; // [nq_pad] order_f32 keys, cleared before the launch: max over a query's lists of their thresholds
+};
+
+constexpr int CO_BOOT_MIN_TILES = 8;   // lists at least this long start from a bootstrapped threshold
+
+// number of lists a run of `len` tiles is cut into
+__host__ __device__ inline int flat_lists_of_run(int len, int list_tiles) { return (len + list_tiles - 1) / list_tiles; }
+
+// ordinal (within query tile m) of the first list of work-group w's run: the lists of the earlier work-groups
+__host__ __device__ inline int flat_first_ordinal(int m, int w, int ctiles, int U, int list_tiles) {
+    const long long m0 = (long long)m * ctiles, m1 = m0 + ctiles;
+    int ord = 0;
+    for (long long wp = m0 / U; wp < w; ++wp) {
+        const long long r0 = wp * U > m0 ? wp * U : m0;
+        const long long r1 = (wp + 1) * U < m1 ? (wp + 1) * U : m1;
+        if (r1 > r0) ord += flat_lists_of_run((int)(r1 - r0), list_tiles);
+    }
+    return ord;
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
+    constexpr int KS = D / CO_BK;      // stages per tile
+    constexpr int NF = D / 16;         // query fragments per lane
+    static_assert(KS % CO_S == 0, "ring slot must be a compile-time function of the stage");
+    using Ops = Sel2Ops<CO_KP>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int u_begin = blockIdx.x * a.units_per_wg;
+    const int u_end = min(a.total_units, u_begin + a.units_per_wg);
+    if (u_begin >= u_end) return;
+
+    // LDS-DMA: per-lane source offsets (bytes from the tile's first row, k = 0); piece i of this wave =
+    // rows 8 (4 wave + i) .. +7, one full 128-B line each, 16-B pieces XOR-swizzled on the source side
+    uint32_t src_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row_local = (wave * 4 + i) * 8 + (lane >> 3);
+        const int piece = (lane & 7) ^ ((row_local >> 1) & 7);
+        src_off[i] = (uint32_t)row_local * (uint32_t)(D * 2) + (uint32_t)piece * 16u;
+    }
+    uint32_t rd_off[4];
+    {
+        const int sw = (c >> 1) & 7;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) rd_off[s] = (uint32_t)c * 128u + (uint32_t)(((2 * s + h) ^ sw) * 16);
+    }
+    auto read_frags = [&](half8 (&f)[4], int ring_slot, int s) {
+        const char *sb = smem + ring_slot * CO_STAGE_BYTES + rd_off[s];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) f[t] = *reinterpret_cast<const half8 *>(sb + t * 4096);
+    };
+    const uint32_t wave_qbase = (uint32_t)CO_RING_BYTES + (uint32_t)(wave * 32) * Ops::QBYTES;
+    const uint32_t wave_scratch = (uint32_t)CO_RING_BYTES + (uint32_t)CO_BM * Ops::QBYTES + (uint32_t)wave * 256u;
+    const int last_tile = a.ctiles - 1;
+
+    half8 qf[NF];
+    int cur_mtile = -1;
+    int u = u_begin;
+    while (u < u_end) {
+        // ---- the list [t0, t1) of query tile mtile, and its ordinal ---------------------------------------
+        const int mtile = u / a.ctiles;
+        const int t0 = u - mtile * a.ctiles;
+        const int run0 = max(u_begin - mtile * a.ctiles, 0);                 // this work-group's run in the query tile
+        const int run1 = min(u_end - mtile * a.ctiles, a.ctiles);
+        const int j = (t0 - run0) / a.list_tiles;
+        const int t1 = min(run1, run0 + (j + 1) * a.list_tiles);
+        const int ntiles = t1 - t0;
+        const int ord = flat_first_ordinal(mtile, (int)blockIdx.x, a.ctiles, a.units_per_wg, a.list_tiles) + j;
+        const int slot0 = mtile * CO_BM;
+
+        if (mtile != cur_mtile) {   // query fragments -> registers (B operand: lane holds Q[query c][16 s + 8 h + j])
+            const _Float16 *qrow = a.q16 + (size_t)(slot0 + wave * 32 + c) * D + 8 * h;
+#pragma unroll
+            for (int s = 0; s < NF; ++s) qf[s] = *reinterpret_cast<const half8 *>(qrow + 16 * s);
+            cur_mtile = mtile;
+        }
+        // buffer_load ... lds: per-lane part in voffset, tile/stage part in a scalar soffset, base = the list's first row
+        const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<_Float16 *>(a.c16) + (size_t)t0 * CO_BN * D, 0,
+            (int)min((size_t)(a.ctiles - t0) * CO_BN * (size_t)(D * 2), (size_t)0x7FFFFFFF), 0x00020000);
+        auto issue_stage = [&](int g_tile, int g_ks, int ring_slot) {
+            const int trow = min(g_tile, last_tile - t0);   // stages past the sweep re-read valid memory, never consumed
+            char *dst = smem + ring_slot * CO_STAGE_BYTES + wave * 4096;
+            const uint32_t soff = (uint32_t)trow * (uint32_t)(CO_BN * D * 2) + (uint32_t)g_ks * (CO_BK * 2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, (__attribute__((address_space(3))) void *)(dst + i * 1024),
+                                                         16, src_off[i], soff, 0, 0);
+        };
+
+        Sel2 st;
+        Ops::init(st, wave_qbase + (uint32_t)c * Ops::QBYTES, h, (slot0 + wave * 32 + c) < a.nq);
+        unsigned int *my_shared = a.shared_thr + (slot0 + wave * 32 + c);
+        const bool publish = (slot0 + wave * 32 + c) < a.nq;   // (padding queries sit at +inf and never publish)
+        uint32_t published = 0u;
+        auto filter_reg = [&](const f32x16 (&pa)[4], auto F, uint32_t rowbase, auto GUARD) {
+            constexpr int f = decltype(F)::value;
+            constexpr int t = f >> 4, r = f & 15;
+            constexpr uint32_t roff = (uint32_t)(t * 32 + (r & 3) + 8 * (r >> 2));
+            float v = pa[t][r];
+            if constexpr (decltype(GUARD)::value) {
+                if ((int)(rowbase + roff) >= a.n) v = -INFINITY;
+            }
+            // wave-uniform skip first (v_cmp + one scalar branch when no lane passes), the per-lane append behind it
+            const bool pass = v > st.thr;
+            if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
+                asm volatile("" ::: "memory");   // keeps the scalar branch: without it the two conditions merge into a predicate
+                if (pass) {
+                    *reinterpret_cast<float *>(smem + st.aw) = v;
+                    *reinterpret_cast<uint32_t *>(smem + st.aw + Ops::ROW_OFF) = rowbase + roff;
+                    st.aw += st.inc;
+                }
+            }
+            if constexpr (r % CO_CHECK_EVERY == CO_CHECK_EVERY - 1) Ops::check(st, lane, smem, wave_qbase, wave_scratch, false, CO_LIMIT);
+        };
+
+        // prologue: stages 0..S-2 in flight, stage 0 published, its first fragments read
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (query fragment loads: the vmcnt accounting starts from zero)
+#pragma unroll
+        for (int p = 0; p < CO_S - 1; ++p) issue_stage(p / KS, p % KS, p % CO_S);
+        half8 afn[4];
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        read_frags(afn, 0, 0);
+
+        for (int tile = 0; tile < ntiles; ++tile) {
+            f32x16 acc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+            static_for<0, KS>([&](auto KSI) {
+                constexpr int ks = decltype(KSI)::value;
+                constexpr int slot = ks % CO_S;
+                auto mfma4 = [&](const half8 (&f)[4], int qi) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[t], qf[qi], acc[t], 0, 0, 0);
+                };
+                // stage g = (tile, ks) was published by the previous mid-stage barrier; afn holds its k-step 0
+                half8 f1[4], f2[4], f3[4];
+                read_frags(f1, slot, 1);
+                mfma4(afn, ks * 4 + 0);
+                read_frags(f2, slot, 2);
+                mfma4(f1, ks * 4 + 1);
+                // pin: reads of k-step s+1 go out before the MFMAs of k-step s
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                // publish stage g+1: this wave's pieces of g+1 have landed when only g+2 is outstanding
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                {   // every wave is past stage g-1: its slot takes stage g+3
+                    constexpr int nks = ks + CO_S - 1;
+                    issue_stage(tile + (nks >= KS ? 1 : 0), nks % KS, nks % CO_S);
+                }
+                read_frags(f3, slot, 3);
+                mfma4(f2, ks * 4 + 2);
+                read_frags(afn, (ks + 1) % CO_S, 0);
+                mfma4(f3, ks * 4 + 3);
+                __builtin_amdgcn_sched_group_barrier(0x020, 4, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // Threshold sharing between the lists of a query (they are swept by different work-groups at the same
+            // time): adopt the largest threshold any of them has published, publish this list's when it is larger.
+            // A list still reports the threshold it ends on as its bound, and the largest bound over the lists - what
+            // finalize certifies against - is the largest of the lists' OWN k'-th best scores with or without sharing;
+            // the weaker lists just stop collecting rows that could never matter. Stale reads are harmless.
+            {
+                const uint32_t seen = __hip_atomic_load(my_shared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t mine_key = order_f32(st.thr);
+                if (seen > mine_key) st.thr = unorder_f32(seen);
+                else if (h == 0 && publish && mine_key > seen && mine_key > published) {
+                    __hip_atomic_fetch_max(my_shared, mine_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    published = mine_key;
+                }
+            }
+            // fused select of the finished tile (rows >= n exist only in the corpus's last tile)
+            const int tile_row0 = (t0 + tile) * CO_BN;
+            const uint32_t rowbase = (uint32_t)(tile_row0 + 4 * h);
+            if (tile == 0 && ntiles >= CO_BOOT_MIN_TILES && tile_row0 + CO_BN <= a.n) {
+                // Threshold bootstrap. A list that starts at -inf appends all 128 rows of its first tile and the
+                // next few hundred, and compacts 5-8 times per query before its threshold means anything (~60 us
+                // per list and wave). Any starting threshold is VALID - the list reports its final threshold as the
+                // bound on what it dropped, and finalize certifies against the bounds - so start from the smaller of
+                // the two lanes' second-best score of this tile (about the 4th best of its 128 rows): in a list of
+                // >= 8 tiles more than KP rows beat it, so the list ends exactly as it would have.
+                float m1 = -INFINITY, m2 = -INFINITY;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[t][r];
+                        const float lo = fminf(m1, v);
+                        m1 = fmaxf(m1, v);
+                        m2 = fmaxf(m2, lo);
+                    }
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m2), __float_as_uint(m2), false, false);
+                const float thr0 = fminf(m2, __uint_as_float(h ? sw[0] : sw[1]));
+                if (thr0 > st.thr) st.thr = thr0;   // (padding queries keep +inf)
+            }
+            if (tile_row0 + CO_BN > a.n) static_for<0, 64>([&](auto F) { filter_reg(acc, F, rowbase, std::true_type{}); });
+            else static_for<0, 64>([&](auto F) { filter_reg(acc, F, rowbase, std::false_type{}); });
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead stages
+        asm volatile("" ::"v"(afn[0]), "v"(afn[1]), "v"(afn[2]), "v"(afn[3]));
+
+        // ---- end of the list: pack every query's entries to the front (top-KP if it holds more) and emit ----
+        Ops::check(st, lane, smem, wave_qbase, wave_scratch, true);
+        const bool last_of_mtile = (t1 == a.ctiles);
+        for (int b = 0; b < 32; ++b) {
+            const int slot = slot0 + wave * 32 + b;
+            if (slot >= a.nq) break;
+            const int nb = readlane<int>(st.kept, b);
+            const float thr_b = __builtin_bit_cast(float, readlane<uint32_t>(__float_as_uint(st.thr), b));
+            const uint32_t qb = wave_qbase + (uint32_t)b * Ops::QBYTES;
+            const size_t o = ((size_t)slot * a.P + ord) * CO_KP;
+            if (lane < CO_KP) {
+                float s = -INFINITY;
+                int row = -1;
+                if (lane < nb) {
+                    s = *reinterpret_cast<const float *>(smem + qb + lane * 4);
+                    row = (int)*reinterpret_cast<const uint32_t *>(smem + qb + Ops::ROW_OFF + lane * 4);
+                }
+                a.part_scores[o + lane] = s;
+                a.part_rows[o + lane] = row;
+            }
+            if (lane == 0) a.bounds[(size_t)slot * a.P + ord] = thr_b;
+            if (last_of_mtile) {
+                for (int e = ord + 1; e < a.P; ++e) {
+                    const size_t oe = ((size_t)slot * a.P + e) * CO_KP;
+                    if (lane < CO_KP) { a.part_scores[oe + lane] = -INFINITY; a.part_rows[oe + lane] = -1; }
+                    if (lane == 0) a.bounds[(size_t)slot * a.P + e] = -INFINITY;
+                }
+            }
+        }
+        __syncthreads();   // every wave is done with the ring and its buffers before the next list's prologue
+        u += ntiles;
+    }
+}
+
+}  // namespace icd

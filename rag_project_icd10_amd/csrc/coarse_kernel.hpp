@@ -489,6 +489,13 @@ __global__ __launch_bounds__(256, 1) void coarse_topk_kernel(CoarseArgs a) {
     }
 }
 
+// A/B builds only: the kernels of this file leave sorted lists; a full list's last entry bounds what it dropped
+__global__ void bounds_from_sorted_lists_kernel(const float *scores, const int *rows, float *bounds, int nlists, int kp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nlists) return;
+    bounds[i] = rows[(size_t)i * kp + kp - 1] >= 0 ? scores[(size_t)i * kp + kp - 1] : -INFINITY;
+}
+
 constexpr int CO_PRODUCT_VAR = 512;   // software-pipelined stage; select after the tile (best measured, profiles/r01_ablate*.log)
 
 // ---- fp32 -> fp16 images ---------------------------------------------------------------------------
@@ -502,12 +509,14 @@ struct ConvertArgs {
     unsigned char *bad;      // nullable [rows]
     unsigned int *rmax_bits; // nullable: atomicMax of norm bits (norm >= 0)
     unsigned int *any_bad;   // nullable: set to 1 if any row is bad
+    unsigned int *zero_u32;  // nullable [rows_pad]: cleared (the coarse pass's shared per-query thresholds)
 };
 
 __global__ __launch_bounds__(256) void convert_rows_kernel(ConvertArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= a.rows_pad) return;
+    if (a.zero_u32 && lane == 0) a.zero_u32[row] = 0u;
     _Float16 *d = a.dst + (size_t)row * a.dim;
     if (row >= a.rows) {
         for (int i = lane * 4; i < a.dim; i += 256) {

@@ -19,6 +19,7 @@ constexpr int FIN_EF = FIN_MAX_CAND / 64;
 struct FinArgs {
     const float *part_scores;  // [slot][P][KP]
     const int *part_rows;
+    const float *bounds;       // fast path: [slot][P] largest score each list may have dropped (-inf: none)
     int P, KP;
     int nq;             // slots (upper bound if nq_ptr)
     const int *nq_ptr;  // nullable
@@ -50,9 +51,17 @@ __device__ __forceinline__ double level_weight(int level) {
 }
 
 __device__ __forceinline__ float wave_max_f32(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-    return v;
+    // DPP reduction (no LDS crossbar round trips): row scans, then the two cross-row broadcasts; lane 63 holds the max
+    const int ninf = (int)0xff800000u;
+#define ICD_DPP_MAX(ctrl, rmask) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), ctrl, rmask, 0xf, false)))
+    ICD_DPP_MAX(0x111, 0xf);   // row_shr:1
+    ICD_DPP_MAX(0x112, 0xf);   // row_shr:2
+    ICD_DPP_MAX(0x114, 0xf);   // row_shr:4
+    ICD_DPP_MAX(0x118, 0xf);   // row_shr:8
+    ICD_DPP_MAX(0x142, 0xa);   // row_bcast:15
+    ICD_DPP_MAX(0x143, 0xc);   // row_bcast:31
+#undef ICD_DPP_MAX
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // Writes the final raw + re-sorted outputs for one query from sorted[0..nres) (best first).
@@ -110,9 +119,10 @@ __device__ __forceinline__ void emit_outputs(const FinArgs &a, int qidx, const u
     }
 }
 
-// LDS per wave: keys[512] u64 | sorted[128] u64 | adjbuf[128] double | qvec[dim] float (RESCORE)
-__host__ __device__ inline size_t fin_wave_lds_bytes(bool rescore, int dim) {
-    return (size_t)FIN_MAX_CAND * 8 + FIN_MAX_K * 8 + FIN_MAX_K * 8 + (rescore ? (size_t)dim * 4 : 0);
+// LDS per wave: keys[max(ncand, 64) rounded to 64] u64 | sorted[128] u64 | adjbuf[128] double | qvec[dim] float (RESCORE)
+__host__ __device__ inline int fin_key_slots(int ncand) { return ncand <= 64 ? 64 : ((ncand + 63) & ~63); }
+__host__ __device__ inline size_t fin_wave_lds_bytes(bool rescore, int dim, int ncand) {
+    return (size_t)fin_key_slots(ncand) * 8 + FIN_MAX_K * 8 + FIN_MAX_K * 8 + (rescore ? (size_t)dim * 4 : 0);
 }
 
 template <bool RESCORE>
@@ -124,44 +134,50 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
     if (slot >= nq) return;  // wave-uniform; no work-group barriers below
     const int qidx = a.qlist ? a.qlist[slot] : slot;
 
-    char *wbase = smem + (size_t)wave * fin_wave_lds_bytes(RESCORE, a.dim);
+    const int ncand = a.P * a.KP;
+    char *wbase = smem + (size_t)wave * fin_wave_lds_bytes(RESCORE, a.dim, ncand);
     u64 *keys = reinterpret_cast<u64 *>(wbase);
-    u64 *sorted = keys + FIN_MAX_CAND;
+    u64 *sorted = keys + fin_key_slots(ncand);
     double *adjbuf = reinterpret_cast<double *>(sorted + FIN_MAX_K);
     float *qvec = reinterpret_cast<float *>(adjbuf + FIN_MAX_K);
 
-    const int ncand = a.P * a.KP;
     const int k = a.k;
     const size_t pbase = (size_t)slot * ncand;
 
-    // 1. load candidates, stage keys
+    // 1. load candidates (rows and scores as independent loads: one round trip, not two per element), stage keys
     u64 key[FIN_EF];
     int nvalid = 0;
+    {
+        int crow[FIN_EF];
+        float cscore[FIN_EF];
 #pragma unroll
-    for (int e = 0; e < FIN_EF; ++e) {
-        const int i = lane + 64 * e;
-        key[e] = 0ull;
-        if (i < ncand) {
-            const int row = a.part_rows[pbase + i];
-            if (row >= 0) key[e] = make_key(a.part_scores[pbase + i], (uint32_t)row);
-            keys[i] = key[e];
+        for (int e = 0; e < FIN_EF; ++e) {
+            const int i = lane + 64 * e;
+            crow[e] = -1;
+            cscore[e] = 0.0f;
+            if (i < ncand) {
+                crow[e] = a.part_rows[pbase + i];
+                cscore[e] = a.part_scores[pbase + i];
+            }
         }
-        nvalid += __popcll(__ballot(key[e] != 0ull));
+#pragma unroll
+        for (int e = 0; e < FIN_EF; ++e) {
+            const int i = lane + 64 * e;
+            key[e] = crow[e] >= 0 ? make_key(cscore[e], (uint32_t)crow[e]) : 0ull;
+            if (i < ncand) keys[i] = key[e];
+            nvalid += __popcll(__ballot(key[e] != 0ull));
+        }
     }
     // 2. rank all candidates; keep the best T sorted
     const int T = RESCORE ? 64 : k;
     int rank[FIN_EF];
     float tau = -INFINITY;  // largest coarse score that may have been dropped anywhere
     if (RESCORE) {
-        // chunk lists that are full may have dropped rows scoring up to their last entry
+        // every list comes with the threshold it ended on: nothing it dropped scores above that. The lists
+        // are ranked by a key with 6 low score bits dropped when scores tie (Sel2), hence the relative slack.
         if (lane < a.P) {
-            const u64 last = keys[lane * a.KP + a.KP - 1];
-            if (last != 0ull) {
-                // the coarse kernel ranks by a key with 6 low score bits dropped (Sel2): a dropped row
-                // may exceed the list's last entry by that relative slack
-                const float sl = key_score(last);
-                tau = sl + fabsf(sl) * COARSE_KEY_SLACK;
-            }
+            const float bd = a.bounds[(size_t)slot * a.P + lane];
+            if (bd > -INFINITY) tau = bd + fabsf(bd) * COARSE_KEY_SLACK;
         }
     }
     rank_top<FIN_EF>(key, rank, ncand, T, keys, lane);   // (may replace keys[] by the survivor list)
@@ -211,6 +227,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
             const float4 *q4 = reinterpret_cast<const float4 *>(qvec);
             float acc = 0.0f;
             const int n4 = a.dim >> 2;
+            // (deeper software prefetch of the row costs registers and with them resident waves: measured slower)
 #pragma unroll 8
             for (int i = 0; i < n4; ++i) {
                 const float4 cv = c4[i];

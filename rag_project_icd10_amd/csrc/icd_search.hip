@@ -13,6 +13,7 @@
 
 #include "../../include/icd_search.h"
 #include "coarse8_kernel.hpp"
+#include "coarse_flat_kernel.hpp"
 #include "coarse_kernel.hpp"
 #include "exact_kernel.hpp"
 #include "finalize.hpp"
@@ -74,7 +75,8 @@ struct icd_index {
     _Float16 *q16 = nullptr;
     float *qnorm = nullptr;
     unsigned char *qbad = nullptr;
-    float *partc_s = nullptr; int *partc_r = nullptr; size_t partc_cap = 0;
+    unsigned int *shared_thr = nullptr;   // [max_nq_pad] coarse pass: per-query threshold shared by its lists
+    float *partc_s = nullptr; int *partc_r = nullptr; float *partc_b = nullptr; size_t partc_cap = 0;   // coarse lists + bounds
     float *partx_s = nullptr; int *partx_r = nullptr; size_t partx_cap = 0;
     float *lists_s = nullptr; int *lists_r = nullptr; size_t lists_cap = 0;   // streaming kernel: [slot][4 nwg][KP]
     int *nflag = nullptr; int *flagged = nullptr;
@@ -104,7 +106,7 @@ bool valid(icd_index *idx) { return idx && idx->magic == 0x1CD10A3Du; }
 void free_all(icd_index *x) {
     if (!x) return;
     hipFree(x->corpus); hipFree(x->c16); hipFree(x->levels); hipFree(x->qdev); hipFree(x->q16);
-    hipFree(x->qnorm); hipFree(x->qbad); hipFree(x->partc_s); hipFree(x->partc_r); hipFree(x->partx_s);
+    hipFree(x->qnorm); hipFree(x->qbad); hipFree(x->shared_thr); hipFree(x->partc_s); hipFree(x->partc_r); hipFree(x->partc_b); hipFree(x->partx_s);
     hipFree(x->partx_r); hipFree(x->lists_s); hipFree(x->lists_r); hipFree(x->nflag); hipFree(x->flagged); hipFree(x->scratch_u32);
     hipFree(x->o_scores); hipFree(x->o_ids); hipFree(x->o_adj); hipFree(x->o_adj_raw);
     hipFree(x->o_adj_ids); hipFree(x->o_adj_lv);
@@ -164,6 +166,19 @@ int launch_coarse(icd_index *x, const CoarseArgs &a, int mtiles, hipStream_t s) 
         configured_dev = x->device;
     }
     hipLaunchKernelGGL(kern, dim3(mtiles * a.P), dim3(256), CO_LDS_BYTES, s, a);
+    HIP_TRY(hipGetLastError());
+    return ICD_OK;
+}
+
+template <int D>
+int launch_coarse_flat(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream_t s) {
+    auto kern = coarse_flat_kernel<D>;
+    static thread_local int configured_dev = -1;
+    if (configured_dev != x->device) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CO_LDS_BYTES));
+        configured_dev = x->device;
+    }
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), CO_LDS_BYTES, s, a);
     HIP_TRY(hipGetLastError());
     return ICD_OK;
 }
@@ -233,10 +248,11 @@ int launch_stream(icd_index *x, const float *dq, const int *qlist, const int *nq
 template <bool RESCORE>
 int launch_finalize(icd_index *x, const FinArgs &a, hipStream_t s) {
     auto kern = finalize_kernel<RESCORE>;
-    const size_t lds = 4 * fin_wave_lds_bytes(RESCORE, x->dim);
+    const size_t lds = 4 * fin_wave_lds_bytes(RESCORE, x->dim, a.P * a.KP);
     static thread_local int configured_dev = -1;
     if (configured_dev != x->device) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(4 * fin_wave_lds_bytes(RESCORE, x->dim, FIN_MAX_CAND))));
         configured_dev = x->device;
     }
     hipLaunchKernelGGL(kern, dim3((a.nq + 3) / 4), dim3(256), lds, s, a);
@@ -364,21 +380,67 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     const int nq_pad = ((nq + 127) / 128) * 128;
     ConvertArgs cv{};
     cv.src = dq; cv.dst = x->q16; cv.rows = nq; cv.rows_pad = nq_pad; cv.dim = x->dim;
-    cv.norm = x->qnorm; cv.bad = x->qbad;
+    cv.norm = x->qnorm; cv.bad = x->qbad; cv.zero_u32 = x->shared_thr;
     hipLaunchKernelGGL(convert_rows_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, s, cv);
     HIP_TRY(hipGetLastError());
     rec(x, 1, s);
 
     const int mtc = nq_pad / 128;
     const int ctiles = x->n_pad / 128;
-    // At least two chunks: with one list per query the "largest dropped score" tau is the query's own
-    // 16th best and ~8 % of Gaussian queries fail the certificate (measured, profiles/r01_sizes.log);
-    // with two or more independent lists tau falls to about rank 32 and certification practically
-    // always succeeds.
-    int pc = x->chunks_override > 0 ? x->chunks_override : std::max(2, pick_chunks(mtc, ctiles, COARSE_MAX_P, x->num_cu));
-    pc = std::min(pc, std::min(COARSE_MAX_P, ctiles));
-    pc = fit_p(pc, x->partc_cap, CO_KP);
-    {
+    int pc = 0;
+#ifdef ICD_ABLATE
+    const char *var_env = getenv("ICD_COARSE_VAR");
+#else
+    const char *var_env = nullptr;
+#endif
+    if (!var_env) {
+        // ---- product: flat partition of the (query tile x corpus tile) grid over the CUs (coarse_flat_kernel.hpp) ----
+        CoarseFlatArgs a{};
+        a.q16 = x->q16; a.c16 = x->c16; a.nq = nq; a.n = (int)x->n; a.n_pad = x->n_pad; a.ctiles = ctiles;
+        a.total_units = mtc * ctiles;
+        // A query's lists should number at least two of comparable length: the certificate compares against the
+        // largest score any list may have dropped, and with one list that is the query's own 16th best (8 % of
+        // Gaussian queries then fail, profiles/r01_sizes_before_pmin2.log); with two or more it is about rank 32.
+        a.list_tiles = std::max(1, (ctiles + 1) / 2);
+        int U = std::max(1, (a.total_units + x->num_cu - 1) / x->num_cu);
+        if (x->chunks_override > 0) {   // test hook: about `chunks` lists per query
+            U = std::max(1, (ctiles + x->chunks_override - 1) / x->chunks_override);
+            a.list_tiles = ctiles;
+        }
+        auto lists_needed = [&](int u) {   // the largest number of lists of any query tile (same rule as the kernel)
+            int worst = 0;
+            for (int m = 0; m < mtc; ++m) {
+                const long long m1 = (long long)(m + 1) * ctiles;
+                const int wl = (int)((m1 - 1) / u);   // last work-group touching the query tile
+                worst = std::max(worst, flat_first_ordinal(m, wl + 1, ctiles, u, a.list_tiles));
+            }
+            return worst;
+        };
+        int P = lists_needed(U);
+        while (P > COARSE_MAX_P || (size_t)nq * P * CO_KP > x->partc_cap) {
+            if (U >= ctiles && a.list_tiles >= ctiles) break;
+            if (U < ctiles) U = std::min(ctiles, U + std::max(1, U / 4));
+            else a.list_tiles = std::min(ctiles, a.list_tiles * 2);
+            P = lists_needed(U);
+        }
+        if (P > COARSE_MAX_P || (size_t)nq * P * CO_KP > x->partc_cap)
+            return fail(ICD_ERR_INVALID, "coarse workspace too small for nq=%d (lists per query %d)", nq, P);
+        a.units_per_wg = U; a.P = P;
+        a.part_scores = x->partc_s; a.part_rows = x->partc_r; a.bounds = x->partc_b; a.shared_thr = x->shared_thr;
+        pc = P;
+        x->last_chunks = P;
+        const int nwg = (a.total_units + U - 1) / U;
+        int rc;
+        if (x->dim == 1024) rc = launch_coarse_flat<1024>(x, a, nwg, s);
+        else rc = launch_coarse_flat<768>(x, a, nwg, s);
+        if (rc) return rc;
+    }
+#ifdef ICD_ABLATE
+    else {
+        // A/B variants and timing ablations of coarse_kernel.hpp on the older (query tile, chunk) grid
+        pc = x->chunks_override > 0 ? x->chunks_override : std::max(2, pick_chunks(mtc, ctiles, COARSE_MAX_P, x->num_cu));
+        pc = std::min(pc, std::min(COARSE_MAX_P, ctiles));
+        pc = fit_p(pc, x->partc_cap, CO_KP);
         const int tiles_per = (ctiles + pc - 1) / pc;
         pc = (ctiles + tiles_per - 1) / tiles_per;
         CoarseArgs a{};
@@ -387,32 +449,28 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         a.part_scores = x->partc_s; a.part_rows = x->partc_r;
         x->last_chunks = pc;
         a.dbg = x->dbg;
-        // Product configuration = CO_PRODUCT_VAR (coarse_kernel.hpp). Other VAR values are A/B variants
-        // and timing ablations, built only with -DICD_ABLATE and selected by env ICD_COARSE_VAR.
-        constexpr int PV = CO_PRODUCT_VAR;
+        const int var = atoi(var_env);
         int rc;
-        if (x->dim == 1024) rc = launch_coarse<1024, PV>(x, a, mtc, s);
-        else {
-#ifdef ICD_ABLATE
-            int var = PV;
-            if (const char *e = getenv("ICD_COARSE_VAR")) var = atoi(e);
-            if (false) {}
-            else if (var == 10000) rc = launch_coarse8<768, 0>(x, a, mtc, s);
-            else if (var == 10001) rc = launch_coarse8<768, 1>(x, a, mtc, s);
+        if (false) {}
+        else if (var == 10000) rc = launch_coarse8<768, 0>(x, a, mtc, s);
+        else if (var == 10001) rc = launch_coarse8<768, 1>(x, a, mtc, s);
 #define ICD_VAR_CASE(V) else if (var == V) rc = launch_coarse<768, V>(x, a, mtc, s);
-            ICD_VAR_CASE(0) ICD_VAR_CASE(1) ICD_VAR_CASE(8) ICD_VAR_CASE(129) ICD_VAR_CASE(512) ICD_VAR_CASE(513)
-            ICD_VAR_CASE(520) ICD_VAR_CASE(528) ICD_VAR_CASE(576) ICD_VAR_CASE(584) ICD_VAR_CASE(6144) ICD_VAR_CASE(6208) ICD_VAR_CASE(2048) ICD_VAR_CASE(2112) ICD_VAR_CASE(641) ICD_VAR_CASE(8833) ICD_VAR_CASE(17025) ICD_VAR_CASE(25217)
+        ICD_VAR_CASE(0) ICD_VAR_CASE(1) ICD_VAR_CASE(8) ICD_VAR_CASE(129) ICD_VAR_CASE(512) ICD_VAR_CASE(513)
+        ICD_VAR_CASE(520) ICD_VAR_CASE(528) ICD_VAR_CASE(576) ICD_VAR_CASE(584) ICD_VAR_CASE(6144) ICD_VAR_CASE(2048)
+        ICD_VAR_CASE(641) ICD_VAR_CASE(8833) ICD_VAR_CASE(17025) ICD_VAR_CASE(25217)
 #undef ICD_VAR_CASE
-            else
-#endif
-            rc = launch_coarse<768, PV>(x, a, mtc, s);
-        }
+        else return fail(ICD_ERR_INVALID, "ICD_COARSE_VAR=%d is not built", var);
         if (rc) return rc;
+        // these kernels leave sorted lists: a full list's last entry bounds what it dropped
+        hipLaunchKernelGGL(bounds_from_sorted_lists_kernel, dim3((nq * pc + 255) / 256), dim3(256), 0, s,
+                           x->partc_s, x->partc_r, x->partc_b, nq * pc, CO_KP);
+        HIP_TRY(hipGetLastError());
     }
+#endif
     rec(x, 2, s);
     {
         FinArgs g = f;
-        g.part_scores = x->partc_s; g.part_rows = x->partc_r; g.P = pc; g.KP = CO_KP; g.nq = nq;
+        g.part_scores = x->partc_s; g.part_rows = x->partc_r; g.bounds = x->partc_b; g.P = pc; g.KP = CO_KP; g.nq = nq;
         int rc = launch_finalize<true>(x, g, s);
         if (rc) return rc;
     }
@@ -507,12 +565,14 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     }
     if (x->fast) {
         CR_TRY(wsalloc(&x->q16, (size_t)x->max_nq_pad * dim));
-        x->partc_cap = std::max<size_t>((size_t)x->max_nq_pad * 4 * CO_KP, (size_t)1 << 20);
+        x->partc_cap = std::max<size_t>((size_t)x->max_nq_pad * 6 * CO_KP, (size_t)1 << 20);
         CR_TRY(wsalloc(&x->partc_s, x->partc_cap));
         CR_TRY(wsalloc(&x->partc_r, x->partc_cap));
+        CR_TRY(wsalloc(&x->partc_b, x->partc_cap / CO_KP));
     }
     CR_TRY(wsalloc(&x->qnorm, (size_t)x->max_nq_pad));
     CR_TRY(wsalloc(&x->qbad, (size_t)x->max_nq_pad));
+    CR_TRY(wsalloc(&x->shared_thr, (size_t)x->max_nq_pad));
     CR_TRY(wsalloc(&x->qdev, (size_t)max_nq * dim));
     x->partx_cap = std::max<size_t>((size_t)x->max_nq_pad * 2 * exact_kp_for(max_k), (size_t)1 << 21);
     CR_TRY(wsalloc(&x->partx_s, x->partx_cap));

@@ -288,13 +288,15 @@ struct Sel2Ops {
                 mx = max(mx, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mx, 0x143, 0xc, 0xf, false));   // row_bcast:31
                 uint32_t hi_s = readlane<uint32_t>(mx, 63);
                 uint32_t lo_s = order_f32(__builtin_bit_cast(float, readlane<uint32_t>(__float_as_uint(s.thr), b)));
-                int c = nvalid;
-                while (c != KP && hi_s - lo_s > 1u) {
+                // (a threshold adopted from another list of the query may sit above some of the entries)
+                int c = __popcll(__ballot(okey > lo_s));
+                if (c <= KP) hi_s = lo_s;   // nothing to bisect: keep what is above the threshold
+                while (c > KP && hi_s - lo_s > 1u) {
                     const uint32_t mid = lo_s + ((hi_s - lo_s) >> 1);
                     const int cm = __popcll(__ballot(okey > mid));
                     if (cm >= KP) { lo_s = mid; c = cm; } else hi_s = mid;
                 }
-                if (c == KP) {
+                if (c <= KP) {
                     const bool keep = okey > lo_s;
                     const u64 km = __ballot(keep);
                     const int dest = __popcll(km & ((1ull << lane) - 1ull));
@@ -304,8 +306,8 @@ struct Sel2Ops {
                     }
                     if ((lane & 31) == b) {
                         s.thr = unorder_f32(lo_s);   // every kept entry is above it, every dropped one at or below
-                        s.kept = KP;
-                        s.aw0 = h ? qb + (CAP - 1) * 4 : qb + (uint32_t)KP * 4;
+                        s.kept = c;
+                        s.aw0 = h ? qb + (CAP - 1) * 4 : qb + (uint32_t)c * 4;
                         s.aw = s.aw0;
                     }
                     continue;
@@ -346,7 +348,7 @@ struct Sel2Ops {
             float nthr = 0.f;
             if (mk) nthr = __builtin_bit_cast(float, readlane<uint32_t>(__float_as_uint(v), __ffsll((long long)mk) - 1));
             if ((lane & 31) == b) {
-                if (nvalid >= KP) s.thr = nthr;
+                if (nvalid >= KP) s.thr = fmaxf(s.thr, nthr);   // (never below a threshold adopted from another list)
                 s.kept = min(nvalid, KP);
                 s.aw0 = h ? qb + (CAP - 1) * 4 : qb + (uint32_t)s.kept * 4;
                 s.aw = s.aw0;
@@ -357,6 +359,47 @@ struct Sel2Ops {
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pt1)::"memory");
             prof[1] += pt1 - pt0;
         }
+    }
+    // End of a list: every query keeps at most KP entries, packed at the front of its buffer (unsorted), and
+    // s.kept / s.thr are final. Queries holding more than KP entries go through the compaction above
+    // (bisection, ranking on ties); the others only move the high lane's entries next to the low lane's.
+    __device__ static __forceinline__ void flush(Sel2 &s, int lane, char *smem, uint32_t wave_qbase, uint32_t wave_scratch) {
+        check(s, lane, smem, wave_qbase, wave_scratch, false, KP);
+        const int h = lane >> 5;
+        const int mine = used(s, h);
+        const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)mine, (unsigned)mine, false, false);
+        const int other = (int)(h ? sw[0] : sw[1]);
+        const int hi_cnt = h ? mine : other;
+        uint32_t need = (uint32_t)__ballot(hi_cnt > 0);   // both lanes of a query agree
+        while (need) {
+            const int b = __ffs((int)need) - 1;
+            need &= need - 1;
+            const int nlo = readlane<int>(s.kept, b) + readlane<int>(mine, b);
+            const int nhi = readlane<int>(mine, b + 32);
+            const uint32_t qb = wave_qbase + (uint32_t)b * QBYTES;
+            const bool valid = (lane >= CAP - nhi);          // the low side is already in place
+            float v = 0.f;
+            uint32_t row = 0;
+            if (valid) {
+                v = *reinterpret_cast<const float *>(smem + qb + lane * 4);
+                row = *reinterpret_cast<const uint32_t *>(smem + qb + ROW_OFF + lane * 4);
+            }
+            const int dest = nlo + (lane - (CAP - nhi));
+            if (valid) {
+                *reinterpret_cast<float *>(smem + qb + dest * 4) = v;
+                *reinterpret_cast<uint32_t *>(smem + qb + ROW_OFF + dest * 4) = row;
+            }
+            if ((lane & 31) == b) {
+                s.kept = nlo + nhi;
+                s.aw0 = h ? qb + (CAP - 1) * 4 : qb + (uint32_t)s.kept * 4;
+                s.aw = s.aw0;
+            }
+        }
+        // queries with entries on the low side only: kept = prefix + appended
+        const int mine2 = used(s, h);
+        if (h == 0 && mine2 > 0) { s.kept += mine2; s.aw0 = s.aw; }
+        const auto sw2 = __builtin_amdgcn_permlane32_swap((unsigned)s.kept, (unsigned)s.kept, false, false);
+        if (h == 1) s.kept = (int)sw2[0];   // the high lane mirrors the query-level count
     }
 };
 
