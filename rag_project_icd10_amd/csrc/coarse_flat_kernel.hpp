@@ -27,6 +27,7 @@ struct CoarseFlatArgs {
     int ctiles;              // n_pad / 128
     int total_units;         // query tiles * ctiles
     int units_per_wg;        // U
+    int pos_period;          // ctiles / gcd(U, ctiles): work-groups l and l + pos_period start on the same corpus tile
     int list_tiles;          // a list covers at most this many tiles
     int P;                   // list slots per query (>= the largest number of lists of any query tile)
     float *part_scores;      // [nq][P][KP]
@@ -63,7 +64,24 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
-    const int u_begin = blockIdx.x * a.units_per_wg;
+    // Which range does this work-group take? Work-groups l, l + T, l + 2T, ... (T = pos_period) sweep the same corpus
+    // tiles at the same time (for other query tiles). The dispatcher deals consecutive blockIdx round-robin over the
+    // 8 XCDs, each with its own L2: remap so that an XCD gets a contiguous stretch of the CLASS-MAJOR order
+    // (class 0's members, class 1's, ...) - then the ~G/T work-groups that stream the same tiles share one L2 and
+    // the corpus is fetched from the Infinity Cache once per class instead of once per work-group (measured:
+    // FETCH_SIZE 4.3 GB -> see profiles/). Pure placement: any bijection is correct.
+    int wg;
+    {
+        const int G = (int)gridDim.x, w = (int)blockIdx.x;
+        const int xcd = w & 7, q8 = G >> 3, r8 = G & 7;
+        const int jx = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (w >> 3);   // contiguous per XCD
+        const int T = a.pos_period, qT = T > 0 ? G / T : 0, rT = G - qT * max(T, 1);
+        if (T <= 0) wg = w;            // (A/B: identity)
+        else if (qT == 0) wg = jx;
+        else if (jx < rT * (qT + 1)) wg = jx / (qT + 1) + (jx % (qT + 1)) * T;
+        else { const int jj = jx - rT * (qT + 1); wg = rT + jj / qT + (jj % qT) * T; }
+    }
+    const int u_begin = wg * a.units_per_wg;
     const int u_end = min(a.total_units, u_begin + a.units_per_wg);
     if (u_begin >= u_end) return;
 
@@ -103,7 +121,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
         const int j = (t0 - run0) / a.list_tiles;
         const int t1 = min(run1, run0 + (j + 1) * a.list_tiles);
         const int ntiles = t1 - t0;
-        const int ord = flat_first_ordinal(mtile, (int)blockIdx.x, a.ctiles, a.units_per_wg, a.list_tiles) + j;
+        const int ord = flat_first_ordinal(mtile, wg, a.ctiles, a.units_per_wg, a.list_tiles) + j;
         const int slot0 = mtile * CO_BM;
 
         if (mtile != cur_mtile) {   // query fragments -> registers (B operand: lane holds Q[query c][16 s + 8 h + j])

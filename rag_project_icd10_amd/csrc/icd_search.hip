@@ -426,6 +426,24 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         if (P > COARSE_MAX_P || (size_t)nq * P * CO_KP > x->partc_cap)
             return fail(ICD_ERR_INVALID, "coarse workspace too small for nq=%d (lists per query %d)", nq, P);
         a.units_per_wg = U; a.P = P;
+        {
+            int g = U % ctiles, h2 = ctiles;   // gcd(U mod ctiles, ctiles); gcd(0, c) = c
+            while (g) { const int t = h2 % g; h2 = g; g = t; }
+            a.pos_period = ctiles / h2;
+            // A class of work-groups that stream the same tiles should have about a dozen members per XCD-local
+            // group: many more and they all hit the same L2 channel at the same time (measured slower), so large
+            // classes are split into sub-classes (l mod T s also start on the same tile).
+            const int nwg_ = (a.total_units + U - 1) / U;
+            const int members = nwg_ / std::max(1, a.pos_period);
+            int split = (members + 11) / 12;
+            if (const char *e = getenv("ICD_XCD_MODE")) {   // A/B switch: 0 identity, 1 XCD swizzle only, 2 classes unsplit
+                const int m = atoi(e);
+                if (m == 0) a.pos_period = 0;
+                else if (m == 1) a.pos_period = 1 << 30;
+                else if (m == 2) split = 1;
+            }
+            if (a.pos_period > 0 && a.pos_period < (1 << 20)) a.pos_period *= std::max(1, split);
+        }
         a.part_scores = x->partc_s; a.part_rows = x->partc_r; a.bounds = x->partc_b; a.shared_thr = x->shared_thr;
         pc = P;
         x->last_chunks = P;
