@@ -71,6 +71,25 @@ def cpu_baseline(corpus, levels, queries, k, budget_s=12.0):
                                       f"{corpus.shape[0]}x{corpus.shape[1]} fp32 corpus, numpy/BLAS"}
 
 
+def pmc_traffic(kernel, nq, n):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/rNN_pmc_traffic.json, made by scripts/gpu_pmc2.sh: FETCH_SIZE and WRITE_SIZE collected in their own
+    passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950). PMC counters cannot be read from inside
+    this process; the number is reported only for the workload it was collected on."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files or (nq, n) != (10000, 37000):
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        for name, v in d.items():
+            if name.startswith(kernel):
+                return float(v["traffic_bytes"])
+    except Exception:
+        return None
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,7 +182,9 @@ def main():
             "kernel_ms": {kname: round(v, 5) for kname, v in prof.items() if kname != "count"},
             "roofline": {"bound": "mfma", "kernel": "coarse_flat_kernel" if stats["last_mode"] == MODE_AUTO else "exact_topk_kernel",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None, "flops_per_launch": flops, "launch_ms": dom_ms, "launches_averaged": prof["count"]},
+                         "traffic": pmc_traffic("coarse_flat_kernel" if stats["last_mode"] == MODE_AUTO else "exact_topk_kernel", nq, n),
+                         "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r*_pmc_traffic.json)",
+                         "flops_per_launch": flops, "launch_ms": dom_ms, "launches_averaged": prof["count"]},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(corpus, levels, queries, k)
