@@ -32,7 +32,10 @@ __device__ __forceinline__ void static_for(F &&f) {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-constexpr int CO_KP = 16;
+#ifndef ICD_CO_KP
+#define ICD_CO_KP 16
+#endif
+constexpr int CO_KP = ICD_CO_KP;   // candidates kept per (query, list)
 constexpr int CO_BM = 128;
 constexpr int CO_BN = 128;
 constexpr int CO_BK = 64;

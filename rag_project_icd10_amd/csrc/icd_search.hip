@@ -12,7 +12,9 @@
 #include <string>
 
 #include "../../include/icd_search.h"
-#include "coarse8_kernel.hpp"
+#ifdef ICD_ABLATE
+#include "coarse8_kernel.hpp"   // 8-wave K-split experiment (slower; A/B builds only)
+#endif
 #include "coarse_flat_kernel.hpp"
 #include "coarse_kernel.hpp"
 #include "exact_kernel.hpp"
@@ -157,19 +159,6 @@ int launch_exact(icd_index *x, const ExactArgs &a, int mtiles, hipStream_t s) {
     return ICD_OK;
 }
 
-template <int D, int VAR>
-int launch_coarse(icd_index *x, const CoarseArgs &a, int mtiles, hipStream_t s) {
-    auto kern = coarse_topk_kernel<D, VAR>;
-    static thread_local int configured_dev = -1;
-    if (configured_dev != x->device) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CO_LDS_BYTES));
-        configured_dev = x->device;
-    }
-    hipLaunchKernelGGL(kern, dim3(mtiles * a.P), dim3(256), CO_LDS_BYTES, s, a);
-    HIP_TRY(hipGetLastError());
-    return ICD_OK;
-}
-
 template <int D>
 int launch_coarse_flat(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream_t s) {
     auto kern = coarse_flat_kernel<D>;
@@ -179,6 +168,20 @@ int launch_coarse_flat(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream
         configured_dev = x->device;
     }
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), CO_LDS_BYTES, s, a);
+    HIP_TRY(hipGetLastError());
+    return ICD_OK;
+}
+
+#ifdef ICD_ABLATE
+template <int D, int VAR>
+int launch_coarse(icd_index *x, const CoarseArgs &a, int mtiles, hipStream_t s) {
+    auto kern = coarse_topk_kernel<D, VAR>;
+    static thread_local int configured_dev = -1;
+    if (configured_dev != x->device) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CO_LDS_BYTES));
+        configured_dev = x->device;
+    }
+    hipLaunchKernelGGL(kern, dim3(mtiles * a.P), dim3(256), CO_LDS_BYTES, s, a);
     HIP_TRY(hipGetLastError());
     return ICD_OK;
 }
@@ -195,6 +198,8 @@ int launch_coarse8(icd_index *x, const CoarseArgs &a, int mtiles, hipStream_t s)
     HIP_TRY(hipGetLastError());
     return ICD_OK;
 }
+
+#endif
 
 // streaming exact kernel + list reduction for a sparse query set (device-side gated when nq_ptr is given)
 // streaming exact kernel + list reduction for a sparse query set (device-side gated when nq_ptr is given).

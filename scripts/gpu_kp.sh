@@ -1,0 +1,6 @@
+cd rag_project_icd10_amd/csrc
+O=../../gpurun_out/kp.log
+: > $O
+for rep in 1 2; do timeout 120 ./icd_selftest --oracle ../../oracle/libicd_oracle.so --skip-cases --bench --iters 20 2>&1 | grep -E "mode=auto|parity" >> $O; done
+timeout 300 ./icd_selftest --oracle ../../oracle/libicd_oracle.so --skip-cases --bench --iters 5 --nq 125000 --n 37000 2>&1 | grep -E "mode=auto|parity" >> $O
+cat $O

@@ -189,6 +189,31 @@ def test_full_size_config2_properties(oracle):
     idx.close()
 
 
+def test_config5_shard_size_properties(oracle):
+    """BASELINE configs[4] per-GPU shard: 1 250 000 x 768 rows (3.84 GB fp32 + 1.92 GB fp16 in HBM), a few hundred
+    queries: oracle on a query sample, the rest through properties; ids carry the shard's id_base."""
+    n, nq, k, base = 1_250_000, 300, 10, 3 * 1_250_000
+    rng = np.random.default_rng(1234 + 3)
+    corpus = rng.standard_normal((n, 768), dtype=np.float32)
+    corpus /= np.linalg.norm(corpus, axis=1, keepdims=True)
+    levels = icd_levels(n, 1238)
+    queries = unit_rows(nq, 768, 4321)
+    idx = IcdIndex(corpus, levels, max_nq=nq, max_k=k, id_base=base)
+    s, i = idx.search(queries, k, MODE_AUTO)
+    st = idx.stats()
+    assert st["last_mode"] == MODE_AUTO
+    assert (i >= base).all() and (i < base + n).all() and (np.diff(s, axis=1) <= 0).all()
+    sample = np.arange(0, nq, 25)
+    os_, oi = oracle.flat_ip_topk(corpus, queries[sample], k, id_base=base)
+    assert np.array_equal(i[sample], oi) and _bits(s[sample]) == _bits(os_)
+    s1, i1 = idx.search(queries[:3], k, MODE_AUTO)                              # tiny batch: streaming kernel, same answer
+    assert np.array_equal(i1, i[:3]) and _bits(s1) == _bits(s[:3])
+    adj, raw, ids, lv = idx.search_reweighted(queries[sample], k, MODE_AUTO)
+    want = oracle.reweight(os_, oi, levels, id_base=base)
+    assert np.array_equal(ids, want[2]) and _bits(adj) == _bits(want[0])
+    idx.close()
+
+
 def test_device_tensor_path_and_merge_kernel(oracle):
     import torch
     n, nq, k = 5000, 300, 10
