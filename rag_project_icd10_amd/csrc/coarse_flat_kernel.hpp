@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             }
             // wave-uniform skip first (v_cmp + one scalar branch when no lane passes), the per-lane append behind it
             const bool pass = v > st.thr;
-            if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(pass) != 0ull, 0)) {   // unlikely: laid out of line, the common path falls through
                 asm volatile("" ::: "memory");   // keeps the scalar branch: without it the two conditions merge into a predicate
                 if (pass) {
                     *reinterpret_cast<float *>(smem + st.aw) = v;

@@ -21,6 +21,9 @@ struct FinArgs {
     const int *part_rows;
     const float *bounds;       // fast path: [slot][P] largest score each list may have dropped (-inf: none)
     int P, KP;
+    int P_dense;        // with nq_ptr: lists per slot when more than sparse_max slots are active (0: always P)
+    int sparse_max;
+    int lds_cand;       // candidate slots the launch's LDS was sized for (0: P * KP)
     int nq;             // slots (upper bound if nq_ptr)
     const int *nq_ptr;  // nullable
     const int *qlist;   // nullable: slot -> query index
@@ -134,10 +137,13 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
     if (slot >= nq) return;  // wave-uniform; no work-group barriers below
     const int qidx = a.qlist ? a.qlist[slot] : slot;
 
-    const int ncand = a.P * a.KP;
-    char *wbase = smem + (size_t)wave * fin_wave_lds_bytes(RESCORE, a.dim, ncand);
+    // the fallback's two producers leave different numbers of lists per slot (stream_topk: P, exact_topk: P_dense)
+    const int P = (a.nq_ptr && a.P_dense > 0 && nq > a.sparse_max) ? a.P_dense : a.P;
+    const int ncand = P * a.KP;
+    const int lds_cand = a.lds_cand > 0 ? a.lds_cand : ncand;
+    char *wbase = smem + (size_t)wave * fin_wave_lds_bytes(RESCORE, a.dim, lds_cand);
     u64 *keys = reinterpret_cast<u64 *>(wbase);
-    u64 *sorted = keys + fin_key_slots(ncand);
+    u64 *sorted = keys + fin_key_slots(lds_cand);
     double *adjbuf = reinterpret_cast<double *>(sorted + FIN_MAX_K);
     float *qvec = reinterpret_cast<float *>(adjbuf + FIN_MAX_K);
 
@@ -175,8 +181,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
     if (RESCORE) {
         // every list comes with the threshold it ended on: nothing it dropped scores above that. The lists
         // are ranked by a key with 6 low score bits dropped when scores tie (Sel2), hence the relative slack.
-        if (lane < a.P) {
-            const float bd = a.bounds[(size_t)slot * a.P + lane];
+        if (lane < P) {
+            const float bd = a.bounds[(size_t)slot * P + lane];
             if (bd > -INFINITY) tau = bd + fabsf(bd) * COARSE_KEY_SLACK;
         }
     }

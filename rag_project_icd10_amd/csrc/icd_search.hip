@@ -253,7 +253,7 @@ int launch_stream(icd_index *x, const float *dq, const int *qlist, const int *nq
 template <bool RESCORE>
 int launch_finalize(icd_index *x, const FinArgs &a, hipStream_t s) {
     auto kern = finalize_kernel<RESCORE>;
-    const size_t lds = 4 * fin_wave_lds_bytes(RESCORE, x->dim, a.P * a.KP);
+    const size_t lds = 4 * fin_wave_lds_bytes(RESCORE, x->dim, a.lds_cand > 0 ? a.lds_cand : a.P * a.KP);
     static thread_local int configured_dev = -1;
     if (configured_dev != x->device) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -322,6 +322,10 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         return ICD_ST(128, 4);
 #undef ICD_ST
     };
+    auto fit_p = [&](int p, size_t cap, int kp) {
+        while (p > 1 && (size_t)nq * p * kp > cap) --p;
+        return p;
+    };
     auto run_exact = [&](const int *qlist, const int *nq_ptr, int px, bool mfma, bool stream) -> int {
         if (!nq_ptr) x->last_chunks = px;   // (the fallback keeps the coarse pass's chunk count)
         int rc = ICD_OK;
@@ -332,12 +336,24 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             px = used;
             if (!nq_ptr) x->last_chunks = px;
         }
+        int px_dense = 0;
         if (mfma) {
+            // The MFMA kernel may have to take EVERY query (all of them flagged): its list count is sized against
+            // the workspace like a full exact run; only the streaming kernel (<= ST_MAX_ACTIVE slots) uses px.
+            int pm = px;
+            if (stream) {
+                pm = pick_chunks(mtx, row_tiles, pmax_x, 2 * x->num_cu);
+                pm = fit_p(pm, x->partx_cap, kpx);
+                if ((size_t)nq * pm * kpx > x->partx_cap) return fail(ICD_ERR_INVALID, "workspace too small for nq=%d k=%d", nq, k);
+                const int tiles_per = (row_tiles + pm - 1) / pm;
+                pm = (row_tiles + tiles_per - 1) / tiles_per;
+                px_dense = pm;
+            }
             ExactArgs a{};
             a.corpus = x->corpus; a.queries = dq; a.qlist = qlist; a.nq_ptr = nq_ptr; a.nq = nq;
             a.min_active = stream ? ST_MAX_ACTIVE : 0;
-            a.n = (int)x->n; a.dim = x->dim; a.P = px;
-            a.rows_per_chunk = ((row_tiles + px - 1) / px) * 128;
+            a.n = (int)x->n; a.dim = x->dim; a.P = pm;
+            a.rows_per_chunk = ((row_tiles + pm - 1) / pm) * 128;
             a.part_scores = x->partx_s; a.part_rows = x->partx_r;
             if (kpx == 16) rc = launch_exact<16, 1, 4>(x, a, mtx, s);
             else if (kpx == 64) rc = launch_exact<64, 2, 2>(x, a, mtx, s);
@@ -347,15 +363,12 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         rec(x, 4, s);
         FinArgs g = f;
         g.part_scores = x->partx_s; g.part_rows = x->partx_r; g.P = px; g.KP = kpx;
+        g.P_dense = px_dense; g.sparse_max = ST_MAX_ACTIVE; g.lds_cand = std::max(px, px_dense) * kpx;
         g.nq = nq; g.nq_ptr = nq_ptr; g.qlist = qlist;
         rc = launch_finalize<false>(x, g, s);
         rec(x, 5, s);
         (void)ex;
         return rc;
-    };
-    auto fit_p = [&](int p, size_t cap, int kp) {
-        while (p > 1 && (size_t)nq * p * kp > cap) --p;
-        return p;
     };
 
     const int p_sparse = FIN_MAX_CAND / kpx;   // lists per slot that finalize<false> merges (32 / 8 / 4)

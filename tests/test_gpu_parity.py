@@ -118,6 +118,24 @@ def test_dense_fallback_list_takes_the_mfma_exact_kernel(oracle):
     idx.close()
 
 
+def test_every_query_flagged_in_a_large_batch(oracle):
+    """all 6000 queries fail certification (fp16 image overflows): the dense fallback's partial lists must be sized
+    for the whole batch (its list count is fitted to the workspace, independently of the sparse path's 32 lists)"""
+    corpus, levels = unit_rows(2000, 768, 98), icd_levels(2000, 99)
+    queries = unit_rows(6000, 768, 100)
+    queries[:, 7] = 1e6
+    idx = IcdIndex(corpus, levels, max_nq=6000, max_k=10)
+    s, i = idx.search(queries, 10, MODE_AUTO)
+    st = idx.stats()
+    assert st["last_fallback"] == 6000
+    sample = np.arange(0, 6000, 37)
+    os_, oi = oracle.flat_ip_topk(corpus, queries[sample], 10)
+    assert np.array_equal(i[sample], oi) and _bits(s[sample]) == _bits(os_)
+    se, ie = idx.search(queries, 10, MODE_EXACT)
+    assert np.array_equal(i, ie) and _bits(s) == _bits(se)
+    idx.close()
+
+
 def test_dim_other_than_fast_path(oracle):
     corpus, levels, queries = unit_rows(900, 64, 60), icd_levels(900, 61), unit_rows(11, 64, 62)
     idx = IcdIndex(corpus, levels, max_nq=16, max_k=10)
