@@ -36,7 +36,8 @@ struct CoarseFlatArgs {
     unsigned int *shared_thr; // [nq_pad] order_f32 keys, cleared before the launch: max over a query's lists of their thresholds
 };
 
-constexpr int CO_BOOT_MIN_TILES = 8;   // lists at least this long start from a bootstrapped threshold
+constexpr int CO_BOOT_MIN_TILES = 16;  // lists at least this long bootstrap their threshold ...
+constexpr int CO_BOOT_TILES = 8;       // ... over their first tiles
 
 // number of lists a run of `len` tiles is cut into
 __host__ __device__ inline int flat_lists_of_run(int len, int list_tiles) { return (len + list_tiles - 1) / list_tiles; }
@@ -146,6 +147,8 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
 
         Sel2 st;
         Ops::init(st, wave_qbase + (uint32_t)c * Ops::QBYTES, h, (slot0 + wave * 32 + c) < a.nq);
+        float boot1 = -INFINITY, boot2 = -INFINITY, boot3 = -INFINITY;   // bootstrap: the lane's three best scores so far
+        const int boot_tiles = ntiles >= CO_BOOT_MIN_TILES ? CO_BOOT_TILES : 0;
         unsigned int *my_shared = a.shared_thr + (slot0 + wave * 32 + c);
         const bool publish = (slot0 + wave * 32 + c) < a.nq;   // (padding queries sit at +inf and never publish)
         uint32_t published = 0u;
@@ -238,25 +241,30 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             // fused select of the finished tile (rows >= n exist only in the corpus's last tile)
             const int tile_row0 = (t0 + tile) * CO_BN;
             const uint32_t rowbase = (uint32_t)(tile_row0 + 4 * h);
-            if (tile == 0 && ntiles >= CO_BOOT_MIN_TILES && tile_row0 + CO_BN <= a.n) {
+            if (tile < boot_tiles && tile_row0 + CO_BN <= a.n) {
                 // Threshold bootstrap. A list that starts at -inf appends all 128 rows of its first tile and the
                 // next few hundred, and compacts 5-8 times per query before its threshold means anything (~60 us
-                // per list and wave). Any starting threshold is VALID - the list reports its final threshold as the
-                // bound on what it dropped, and finalize certifies against the bounds - so start from the smaller of
-                // the two lanes' second-best score of this tile (about the 4th best of its 128 rows): in a list of
-                // >= 8 tiles more than KP rows beat it, so the list ends exactly as it would have.
-                float m1 = -INFINITY, m2 = -INFINITY;
+                // per list and wave). Any threshold is VALID - the list reports the threshold it ends on as the
+                // bound on what it dropped, and finalize certifies against the bounds - so over the list's first
+                // CO_BOOT_TILES tiles every lane tracks the three best scores it has seen (5 VALU per score) and the
+                // threshold follows the smaller of the two lanes' third best: about the 6th best of the rows
+                // seen so far. In a list of >= CO_BOOT_MIN_TILES tiles more than KP rows beat the level this
+                // reaches (0.6 % of the rows), so the list still fills and ends on its own KP-th best. Third best,
+                // not second: with the second best a list whose first rows happen to hold four of the query's
+                // global top hits ends on a bound inside the top-k and fails the certificate (measured 4 of 10 000).
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float v = acc[t][r];
-                        const float lo = fminf(m1, v);
-                        m1 = fmaxf(m1, v);
-                        m2 = fmaxf(m2, lo);
+                        const float lo1 = fminf(boot1, v);
+                        boot1 = fmaxf(boot1, v);
+                        const float lo2 = fminf(boot2, lo1);
+                        boot2 = fmaxf(boot2, lo1);
+                        boot3 = fmaxf(boot3, lo2);
                     }
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m2), __float_as_uint(m2), false, false);
-                const float thr0 = fminf(m2, __uint_as_float(h ? sw[0] : sw[1]));
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(boot3), __float_as_uint(boot3), false, false);
+                const float thr0 = fminf(boot3, __uint_as_float(h ? sw[0] : sw[1]));
                 if (thr0 > st.thr) st.thr = thr0;   // (padding queries keep +inf)
             }
             if (tile_row0 + CO_BN > a.n) static_for<0, 64>([&](auto F) { filter_reg(acc, F, rowbase, std::true_type{}); });
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
         asm volatile("" ::"v"(afn[0]), "v"(afn[1]), "v"(afn[2]), "v"(afn[3]));
 
         // ---- end of the list: pack every query's entries to the front (top-KP if it holds more) and emit ----
-        Ops::check(st, lane, smem, wave_qbase, wave_scratch, true);
+        Ops::flush(st, lane, smem, wave_qbase, wave_scratch);
         const bool last_of_mtile = (t1 == a.ctiles);
         for (int b = 0; b < 32; ++b) {
             const int slot = slot0 + wave * 32 + b;
