@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Randomised shape sweep of the HIP search path against the CPU oracle (GPU box only; not part of pytest).
+
+    python scripts/gpu_fuzz.py [--cases 40] [--seed 7]
+
+Every case draws (rows, queries, dim, k, data kind, mode, id_base), searches through the C ABI and compares ids (exact),
+scores (bit-identical) and the reweighted outputs with oracle/ on a query sample. Data kinds: gaussian unit rows,
+clustered rows (near ties: forces the exact fallback), rows with exact duplicates, a batch whose fp16 image overflows.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def rows(rng, n, dim, kind):
+    if kind == "clustered":
+        cent = rng.standard_normal((32, dim)).astype(np.float32)
+        x = cent[rng.integers(0, 32, n)] + 0.05 * rng.standard_normal((n, dim)).astype(np.float32)
+    else:
+        x = rng.standard_normal((n, dim)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    if kind == "dups" and n > 20:
+        src = rng.integers(0, n, n // 10)
+        dst = rng.integers(0, n, n // 10)
+        x[dst] = x[src]
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=7)
+    args = ap.parse_args()
+    import oracle as orc
+    from rag_project_icd10_amd._native import MODE_AUTO, MODE_EXACT, IcdIndex
+    rng = np.random.default_rng(args.seed)
+    bad = 0
+    t0 = time.time()
+    for case in range(args.cases):
+        dim = int(rng.choice([768, 768, 768, 1024, 96, 256]))
+        n = int(rng.choice([1, 7, 127, 128, 129, 1000, 4097, 20000, 37000, 100003]))
+        nq = int(rng.choice([1, 2, 9, 16, 17, 64, 65, 128, 129, 1000, 3000]))
+        k = int(rng.choice([1, 5, 10, 10, 10, 12, 13, 50, 100]))
+        kind = str(rng.choice(["gauss", "gauss", "clustered", "dups", "overflow"]))
+        mode = MODE_AUTO if rng.random() < 0.8 else MODE_EXACT
+        id_base = int(rng.choice([0, 0, 5_000_000_000]))
+        if n * dim > 100003 * 768 or (n >= 100000 and nq > 1000):
+            nq = min(nq, 1000)
+        corpus = rows(rng, n, dim, "gauss" if kind == "overflow" else kind)
+        queries = rows(rng, nq, dim, "gauss" if kind in ("overflow", "dups") else kind)
+        if kind == "overflow":
+            queries[rng.random(nq) < 0.5, rng.integers(0, dim)] = 3e5
+        r = rng.random(n)
+        levels = np.where(r < 0.1243, 1, np.where(r < 0.4234, 2, 3)).astype(np.int32)
+        idx = IcdIndex(corpus, levels, max_nq=nq, max_k=k, id_base=id_base)
+        s, i = idx.search(queries, k, mode)
+        adj, raw, ids, lv = idx.search_reweighted(queries, k, mode)
+        st = idx.stats()
+        idx.close()
+        sample = np.unique(np.concatenate([np.arange(0, nq, max(1, nq // 24)), [nq - 1]]))
+        os_, oi = orc.flat_ip_topk(corpus, queries[sample], k, id_base=id_base)
+        want = orc.reweight(os_, oi, levels, id_base=id_base)
+        ok = (np.array_equal(i[sample], oi) and s[sample].tobytes() == os_.tobytes()
+              and np.array_equal(ids[sample], want[2]) and adj[sample].tobytes() == want[0].tobytes()
+              and np.array_equal(lv[sample], want[3]))
+        bad += 0 if ok else 1
+        print(f"{'ok  ' if ok else 'FAIL'} case {case:3d}: n={n} nq={nq} dim={dim} k={k} kind={kind} mode={'auto' if mode == MODE_AUTO else 'exact'} "
+              f"id_base={id_base} -> last_mode={st['last_mode']} lists={st['last_chunks']} fallback={st['last_fallback']}", flush=True)
+    print(f"gpu_fuzz: {args.cases - bad} ok, {bad} failed in {time.time() - t0:.1f} s")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
