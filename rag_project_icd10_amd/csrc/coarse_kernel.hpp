@@ -513,6 +513,8 @@ struct ConvertArgs {
     unsigned int *rmax_bits; // nullable: atomicMax of norm bits (norm >= 0)
     unsigned int *any_bad;   // nullable: set to 1 if any row is bad
     unsigned int *zero_u32;  // nullable [rows_pad]: cleared (the coarse pass's shared per-query thresholds)
+    long long perm_mul;      // with perm_mod > 0: dst row p holds src row (p * perm_mul) mod perm_mod (an affine permutation)
+    int perm_mod;
 };
 
 __global__ __launch_bounds__(256) void convert_rows_kernel(ConvertArgs a) {
@@ -527,7 +529,8 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(ConvertArgs a) {
         }
         return;
     }
-    const float *s = a.src + (size_t)row * a.dim;
+    const int srow = a.perm_mod > 0 ? (int)(((long long)row * a.perm_mul) % a.perm_mod) : row;
+    const float *s = a.src + (size_t)srow * a.dim;
     float ss = 0.0f;
     bool bad = false;
     for (int i = lane * 4; i < a.dim; i += 256) {

@@ -20,6 +20,8 @@ struct FinArgs {
     const float *part_scores;  // [slot][P][KP]
     const int *part_rows;
     const float *bounds;       // fast path: [slot][P] largest score each list may have dropped (-inf: none)
+    long long perm_mul;        // fast path: list rows are positions of the permuted fp16 corpus; original row =
+    int perm_mod;              //            (position * perm_mul) mod perm_mod (perm_mod = 0: identity)
     int P, KP;
     int P_dense;        // with nq_ptr: lists per slot when more than sparse_max slots are active (0: always P)
     int sparse_max;
@@ -165,6 +167,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
                 crow[e] = a.part_rows[pbase + i];
                 cscore[e] = a.part_scores[pbase + i];
             }
+        }
+        if (RESCORE && a.perm_mod > 0) {
+#pragma unroll
+            for (int e = 0; e < FIN_EF; ++e)
+                if (crow[e] >= 0) crow[e] = (int)(((long long)crow[e] * a.perm_mul) % a.perm_mod);
         }
 #pragma unroll
         for (int e = 0; e < FIN_EF; ++e) {

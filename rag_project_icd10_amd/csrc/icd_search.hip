@@ -78,6 +78,7 @@ struct icd_index {
     float *qnorm = nullptr;
     unsigned char *qbad = nullptr;
     unsigned int *shared_thr = nullptr;   // [max_nq_pad] coarse pass: per-query threshold shared by its lists
+    long long perm_mul = 0; int perm_mod = 0;   // row order of the fp16 corpus: position p holds row (p * perm_mul) mod perm_mod
     float *partc_s = nullptr; int *partc_r = nullptr; float *partc_b = nullptr; size_t partc_cap = 0;   // coarse lists + bounds
     float *partx_s = nullptr; int *partx_r = nullptr; size_t partx_cap = 0;
     float *lists_s = nullptr; int *lists_r = nullptr; size_t lists_cap = 0;   // streaming kernel: [slot][4 nwg][KP]
@@ -507,6 +508,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     {
         FinArgs g = f;
         g.part_scores = x->partc_s; g.part_rows = x->partc_r; g.bounds = x->partc_b; g.P = pc; g.KP = CO_KP; g.nq = nq;
+        g.perm_mul = x->perm_mul; g.perm_mod = x->perm_mod;
         int rc = launch_finalize<true>(x, g, s);
         if (rc) return rc;
     }
@@ -588,9 +590,20 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     };
     if (fast_dim) {
         CR_TRY(dmalloc(&x->c16, (size_t)x->n_pad * dim));
+        // Row order of the fp16 copy: a corpus in code order keeps families of near-identical rows next to each
+        // other, so ONE candidate list would collect a query's whole family, end on a bound inside it and fail the
+        // certificate. An affine permutation with a golden-ratio stride spreads neighbours evenly over the lists;
+        // finalize maps list positions back with the same formula (no table). ICD_NO_PERMUTE=1 keeps the order (A/B).
+        if (n > 2 && !getenv("ICD_NO_PERMUTE")) {
+            long long a_ = (long long)(0.6180339887498949 * (double)n) | 1;
+            auto gcd = [](long long u, long long v) { while (v) { const long long t = u % v; u = v; v = t; } return u; };
+            while (gcd(a_, n) != 1) a_ += 2;
+            x->perm_mul = a_ % n; x->perm_mod = (int)n;
+        }
         ConvertArgs cv{};
         cv.src = x->corpus; cv.dst = x->c16; cv.rows = (int)n; cv.rows_pad = x->n_pad; cv.dim = dim;
         cv.rmax_bits = x->scratch_u32; cv.any_bad = x->scratch_u32 + 1;
+        cv.perm_mul = x->perm_mul; cv.perm_mod = x->perm_mod;
         hipLaunchKernelGGL(convert_rows_kernel, dim3((x->n_pad + 3) / 4), dim3(256), 0, 0, cv);
         CR_TRY(hipGetLastError());
         unsigned hv[2] = {0, 0};

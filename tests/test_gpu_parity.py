@@ -136,6 +136,35 @@ def test_every_query_flagged_in_a_large_batch(oracle):
     idx.close()
 
 
+def _family_corpus(nfam, per, dim, seed):
+    """rows in CODE ORDER: families of `per` near-identical rows sit next to each other, like the ICD corpus whose
+    semantic_text repeats the ancestors' names (tools/build_database.py:156-171)"""
+    rng = np.random.default_rng(seed)
+    cent = rng.standard_normal((nfam, dim)).astype(np.float32)
+    x = np.repeat(cent, per, axis=0) + 0.35 * rng.standard_normal((nfam * per, dim)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    q = cent[rng.integers(0, nfam, 256)] + 0.35 * rng.standard_normal((256, dim)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return np.ascontiguousarray(x, dtype=np.float32), np.ascontiguousarray(q, dtype=np.float32)
+
+
+def test_corpus_in_code_order_stays_on_the_fast_path(oracle, monkeypatch):
+    """A query's whole family is contiguous in the corpus. The fp16 copy is stored in a permuted row order so the family
+    spreads over the candidate lists; without it one list holds the family, ends on a bound inside it and the
+    certificate fails for most queries (results stay exact either way)."""
+    corpus, queries = _family_corpus(300, 120, 768, 77)
+    levels = icd_levels(len(corpus), 78)
+    idx = IcdIndex(corpus, levels, max_nq=256, max_k=10)
+    st = _check(oracle, idx, corpus, levels, queries, 10, MODE_AUTO)
+    idx.close()
+    assert st["last_mode"] == MODE_AUTO and st["last_fallback"] <= 256 // 8
+    monkeypatch.setenv("ICD_NO_PERMUTE", "1")
+    idx = IcdIndex(corpus, levels, max_nq=256, max_k=10)
+    st2 = _check(oracle, idx, corpus, levels, queries, 10, MODE_AUTO)
+    idx.close()
+    assert st2["last_fallback"] >= st["last_fallback"]
+
+
 def test_dim_other_than_fast_path(oracle):
     corpus, levels, queries = unit_rows(900, 64, 60), icd_levels(900, 61), unit_rows(11, 64, 62)
     idx = IcdIndex(corpus, levels, max_nq=16, max_k=10)
