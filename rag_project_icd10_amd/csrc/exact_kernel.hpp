@@ -23,9 +23,23 @@ struct ExactArgs {
     int dim;               // multiple of 32
     int P;                 // corpus chunks
     int rows_per_chunk;    // multiple of 128
+    int adaptive_max_p;    // > 0 (with nq_ptr): choose the chunk count on the device from the actual slot count:
+                           // S = min(adaptive_max_p, gridDim.x / active query tiles), lists laid out [slot][S][KP]
+                           // (finalize.hpp recomputes S the same way). A short flagged list then spreads over many
+                           // more work-groups than the worst-case (every query flagged) chunk count allows.
     float *part_scores;    // [slot][P][KP]
     int *part_rows;        // [slot][P][KP]
 };
+
+// chunk count of the adaptive layout (device: exact_topk_kernel; the same call in finalize.hpp)
+__host__ __device__ inline int exact_adaptive_chunks(int nq_active, int bmq, int grid, int max_p, int n_rows) {
+    const int mtiles = (nq_active + bmq - 1) / bmq;
+    const int row_tiles = (n_rows + 127) / 128;
+    int p = mtiles > 0 ? grid / mtiles : 1;
+    p = p < max_p ? p : max_p;
+    p = p < row_tiles ? p : row_tiles;
+    return p > 1 ? p : 1;
+}
 
 template <int KP, int E, int NW>
 __global__ __launch_bounds__(NW * 64) void exact_topk_kernel(ExactArgs a) {
@@ -40,11 +54,25 @@ __global__ __launch_bounds__(NW * 64) void exact_topk_kernel(ExactArgs a) {
 
     const int nq = a.nq_ptr ? min(*a.nq_ptr, a.nq) : a.nq;
     if (a.nq_ptr && nq <= a.min_active) return;
-    const int mtile = blockIdx.x / a.P, chunk = blockIdx.x % a.P;
+    int P = a.P, rows_per_chunk = a.rows_per_chunk;
+    if (a.nq_ptr && a.adaptive_max_p > 0) {
+        P = exact_adaptive_chunks(nq, BMQ, (int)gridDim.x, a.adaptive_max_p, a.n);
+        rows_per_chunk = (((a.n + BN - 1) / BN + P - 1) / P) * BN;
+    }
+    const int mtile = blockIdx.x / P, chunk = blockIdx.x % P;
     const int slot0 = mtile * BMQ;
     if (slot0 >= nq) return;
-    const int row_begin = chunk * a.rows_per_chunk;
-    const int row_end = min(a.n, row_begin + a.rows_per_chunk);
+    const int row_begin = chunk * rows_per_chunk;
+    const int row_end = min(a.n, row_begin + rows_per_chunk);
+    if (row_begin >= row_end) {   // (more chunks than row tiles: this work-group's lists stay empty)
+        for (int b = 0; b < BMQ; ++b) {
+            const int slot = slot0 + b;
+            if (slot >= nq) break;
+            const size_t o = ((size_t)slot * P + chunk) * KP;
+            for (int j = threadIdx.x; j < KP; j += NT) { a.part_scores[o + j] = -INFINITY; a.part_rows[o + j] = -1; }
+        }
+        return;
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int dim = a.dim, nks = dim / BK;
@@ -173,7 +201,7 @@ __global__ __launch_bounds__(NW * 64) void exact_topk_kernel(ExactArgs a) {
         if (slot >= nq) break;
         const int nb = min(readlane<int>(st.cnt, b), KP);
         const u64 *qb = wbuf + (size_t)b * CAP;
-        const size_t o = ((size_t)slot * a.P + chunk) * KP;
+        const size_t o = ((size_t)slot * P + chunk) * KP;
         for (int j = lane; j < KP; j += 64) {
             float s = -INFINITY;
             int row = -1;

@@ -8,6 +8,7 @@
 //   services/milvus_service.py:550-558  level weights {1:1.2, 2:1.0, 3:0.8}, default 1.0
 //   services/milvus_service.py:314      stable sort by adjusted score, descending
 #pragma once
+#include "exact_kernel.hpp"
 #include "topk_select.hpp"
 
 namespace icd {
@@ -25,6 +26,7 @@ struct FinArgs {
     int P, KP;
     int P_dense;        // with nq_ptr: lists per slot when more than sparse_max slots are active (0: always P)
     int sparse_max;
+    int dense_grid, dense_bmq, dense_max_p, n_rows;   // dense_max_p > 0: exact_topk chose its chunk count on the device
     int lds_cand;       // candidate slots the launch's LDS was sized for (0: P * KP)
     int nq;             // slots (upper bound if nq_ptr)
     const int *nq_ptr;  // nullable
@@ -140,7 +142,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
     const int qidx = a.qlist ? a.qlist[slot] : slot;
 
     // the fallback's two producers leave different numbers of lists per slot (stream_topk: P, exact_topk: P_dense)
-    const int P = (a.nq_ptr && a.P_dense > 0 && nq > a.sparse_max) ? a.P_dense : a.P;
+    int P = a.P;
+    if (a.nq_ptr && a.P_dense > 0 && nq > a.sparse_max)
+        P = a.dense_max_p > 0 ? exact_adaptive_chunks(nq, a.dense_bmq, a.dense_grid, a.dense_max_p, a.n_rows) : a.P_dense;
     const int ncand = P * a.KP;
     const int lds_cand = a.lds_cand > 0 ? a.lds_cand : ncand;
     char *wbase = smem + (size_t)wave * fin_wave_lds_bytes(RESCORE, a.dim, lds_cand);

@@ -310,14 +310,19 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     const int pmax_x = std::min(16, FIN_MAX_CAND / kpx);
     // sparse: streaming kernel (+ list reduction) instead of / next to the MFMA exact kernel
     // queries per pass: host-known for direct calls (1, 2, 4 or 8), 8 for the device-gated fallback
+    const int p_sparse = FIN_MAX_CAND / kpx;   // lists per slot that finalize<false> merges (32 / 8 / 4)
+    // How many flagged queries still go to the streaming kernel: it re-reads the corpus once per 8 queries (~35 us at
+    // 37k rows), the fp32-MFMA kernel needs ~1.4 ms for ANY count up to a few thousand (one 128-query tile per
+    // work-group, 16 chunks at most: few CUs busy), so the crossover is near 300; the list workspace caps it by k.
+    const int sparse_max = (int)std::min<size_t>(ST_FALLBACK_MAX_ACTIVE, x->lists_cap / ((size_t)1024 * kpx));
     auto run_stream = [&](const int *qlist, const int *nq_ptr, int nqs, int p_out, int *p_used) -> int {
         int qb = nq_ptr ? 8 : (nqs <= 1 ? 1 : (nqs <= 2 ? 2 : (nqs <= 4 ? 4 : 8)));
         while (qb > 1 && !stream_fits(kpx, qb, x->dim)) qb >>= 1;
 #define ICD_ST(KPV, EV) \
-        (qb == 1 ? launch_stream<KPV, EV, 1>(x, dq, qlist, nq_ptr, nqs, ST_MAX_ACTIVE, p_out, p_used, s) : \
-         qb == 2 ? launch_stream<KPV, EV, 2>(x, dq, qlist, nq_ptr, nqs, ST_MAX_ACTIVE, p_out, p_used, s) : \
-         qb == 4 ? launch_stream<KPV, EV, 4>(x, dq, qlist, nq_ptr, nqs, ST_MAX_ACTIVE, p_out, p_used, s) : \
-                   launch_stream<KPV, EV, 8>(x, dq, qlist, nq_ptr, nqs, ST_MAX_ACTIVE, p_out, p_used, s))
+        (qb == 1 ? launch_stream<KPV, EV, 1>(x, dq, qlist, nq_ptr, nqs, sparse_max, p_out, p_used, s) : \
+         qb == 2 ? launch_stream<KPV, EV, 2>(x, dq, qlist, nq_ptr, nqs, sparse_max, p_out, p_used, s) : \
+         qb == 4 ? launch_stream<KPV, EV, 4>(x, dq, qlist, nq_ptr, nqs, sparse_max, p_out, p_used, s) : \
+                   launch_stream<KPV, EV, 8>(x, dq, qlist, nq_ptr, nqs, sparse_max, p_out, p_used, s))
         if (kpx == 16) return ICD_ST(16, 2);
         if (kpx == 64) return ICD_ST(64, 3);
         return ICD_ST(128, 4);
@@ -352,7 +357,8 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             }
             ExactArgs a{};
             a.corpus = x->corpus; a.queries = dq; a.qlist = qlist; a.nq_ptr = nq_ptr; a.nq = nq;
-            a.min_active = stream ? ST_MAX_ACTIVE : 0;
+            a.min_active = stream ? sparse_max : 0;
+            a.adaptive_max_p = stream ? p_sparse : 0;   // fallback: the chunk count follows the actual flagged count
             a.n = (int)x->n; a.dim = x->dim; a.P = pm;
             a.rows_per_chunk = ((row_tiles + pm - 1) / pm) * 128;
             a.part_scores = x->partx_s; a.part_rows = x->partx_r;
@@ -364,7 +370,8 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         rec(x, 4, s);
         FinArgs g = f;
         g.part_scores = x->partx_s; g.part_rows = x->partx_r; g.P = px; g.KP = kpx;
-        g.P_dense = px_dense; g.sparse_max = ST_MAX_ACTIVE; g.lds_cand = std::max(px, px_dense) * kpx;
+        g.P_dense = px_dense; g.sparse_max = sparse_max; g.lds_cand = std::max(px, stream ? p_sparse : px_dense) * kpx;
+        g.dense_grid = mtx * std::max(1, px_dense); g.dense_bmq = bmq; g.dense_max_p = (stream && mfma) ? p_sparse : 0; g.n_rows = (int)x->n;
         g.nq = nq; g.nq_ptr = nq_ptr; g.qlist = qlist;
         rc = launch_finalize<false>(x, g, s);
         rec(x, 5, s);
@@ -372,7 +379,6 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         return rc;
     };
 
-    const int p_sparse = FIN_MAX_CAND / kpx;   // lists per slot that finalize<false> merges (32 / 8 / 4)
     // small batches (the reference's one-query-per-call shape): stream the corpus once, exact, no coarse pass
     const bool stream_ok = x->dim % (32 * ST_PF) == 0 && stream_fits(kpx, 1, x->dim);
     const bool tiny = stream_ok && nq <= (use_fast ? 16 : ST_MAX_ACTIVE);
@@ -624,9 +630,10 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     CR_TRY(wsalloc(&x->shared_thr, (size_t)x->max_nq_pad));
     CR_TRY(wsalloc(&x->qdev, (size_t)max_nq * dim));
     x->partx_cap = std::max<size_t>((size_t)x->max_nq_pad * 2 * exact_kp_for(max_k), (size_t)1 << 21);
-    CR_TRY(wsalloc(&x->partx_s, x->partx_cap));
-    CR_TRY(wsalloc(&x->partx_r, x->partx_cap));
-    x->lists_cap = (size_t)ST_MAX_ACTIVE * 1024 * exact_kp_for(max_k);
+    // (+ one query tile of the widest layout: the device-chosen chunk count of the fallback rounds the slot count up)
+    CR_TRY(wsalloc(&x->partx_s, x->partx_cap + (size_t)128 * FIN_MAX_CAND));
+    CR_TRY(wsalloc(&x->partx_r, x->partx_cap + (size_t)128 * FIN_MAX_CAND));
+    x->lists_cap = std::max((size_t)ST_MAX_ACTIVE * 1024 * exact_kp_for(max_k), (size_t)ST_FALLBACK_MAX_ACTIVE * 1024 * 16);
     CR_TRY(wsalloc(&x->lists_s, x->lists_cap));
     CR_TRY(wsalloc(&x->lists_r, x->lists_cap));
     CR_TRY(wsalloc(&x->nflag, 4));

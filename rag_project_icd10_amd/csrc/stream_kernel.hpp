@@ -24,7 +24,8 @@ namespace icd {
 
 constexpr int ST_QB = 8;          // queries per pass (template QB <= ST_QB: fewer for tiny batches)
 constexpr int ST_PF = 1;          // dim must be a multiple of 32 * ST_PF
-constexpr int ST_MAX_ACTIVE = 64; // the sparse path is taken for at most this many queries
+constexpr int ST_MAX_ACTIVE = 64; // direct calls: batches up to this size take the streaming kernel (EXACT mode)
+constexpr int ST_FALLBACK_MAX_ACTIVE = 192;   // AUTO fallback: flagged lists up to this long (less for large k: workspace)
 constexpr int ST_STAGE_BYTES = 8192;   // one wave stage: 64 rows x 32 floats
 constexpr int ST_PAD_ROWS = 512;       // zero rows the index keeps behind the corpus (stages may run past n)
 

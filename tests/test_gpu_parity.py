@@ -108,12 +108,15 @@ def test_streaming_kernel_variants(oracle, n, nq, dim, k, mode):
 
 
 def test_dense_fallback_list_takes_the_mfma_exact_kernel(oracle):
-    """more than 64 uncertified queries: the device-side gate routes the fallback to exact_topk, not stream_topk"""
+    """more than 256 uncertified queries: the device-side gate routes the fallback to exact_topk, not stream_topk;
+    100 of them: stream_topk in 13 passes of 8"""
     corpus, levels = unit_rows(3000, 768, 95), icd_levels(3000, 96)
-    queries = unit_rows(300, 768, 97)
-    queries[::3, 11] = 1e6        # 100 queries whose fp16 image overflows
-    idx = IcdIndex(corpus, levels, max_nq=300, max_k=10)
+    queries = unit_rows(900, 768, 97)
+    queries[::3, 11] = 1e6        # 300 queries whose fp16 image overflows
+    idx = IcdIndex(corpus, levels, max_nq=900, max_k=10)
     st = _check(oracle, idx, corpus, levels, queries, 10, MODE_AUTO)
+    assert st["last_fallback"] == 300
+    st = _check(oracle, idx, corpus, levels, queries[:300], 10, MODE_AUTO)
     assert st["last_fallback"] == 100
     idx.close()
 
