@@ -179,6 +179,31 @@ __global__ __launch_bounds__(NW * 64) void exact_topk_kernel(ExactArgs a) {
 
         // fused select
         const bool partial = tile_row0 + BN > row_end;
+        if (KP == 16 && tile_row0 == row_begin && !partial) {
+            // Threshold bootstrap of a chunk's first tile. Starting at -inf every row of the first tiles is appended and
+            // each 16-register group ends in a compaction of all 32 queries (~1 ms per chunk: more than a 9-tile
+            // chunk's MFMAs). Exact lists need a threshold that at least KP rows reach: every lane keeps the 8 best
+            // of its 64 scores (branch-free insertion, 16 VALU per score, once per chunk) and the smaller of the two
+            // lanes' 8th best is reached by 16 distinct rows of this tile. Ties with it pass (thr_row = max).
+            float m[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[t][r];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float lo = fminf(m[j], v);
+                        m[j] = fmaxf(m[j], v);
+                        v = lo;
+                    }
+                }
+            const float other = __shfl_xor(m[7], 32);
+            const float t0 = fminf(m[7], other);
+            if (my_valid && t0 > st.thr) { st.thr = t0; st.thr_row = 0xFFFFFFFFu; }
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const uint32_t row0 = (uint32_t)(tile_row0 + t * 32);

@@ -20,3 +20,9 @@ for nbad in (0, 8, 100, 200, 1000, 3000):
     print("flagged %4d: %.3f ms per step (fallback %d) | coarse %.3f finalize %.3f exact %.3f exact_fin %.3f" % (nbad, dt * 1e3, idx.stats()["last_fallback"], pr["ms_coarse"], pr["ms_finalize"], pr["ms_exact"], pr["ms_exact_finalize"]))
 idx.close()
 PY
+cd rag_project_icd10_amd/csrc
+timeout 300 ./icd_selftest --oracle ../../oracle/libicd_oracle.so --skip-cases --bench --iters 10 --nq 1000 --n 40474 2>&1 | grep -E "mode=exact|parity"
+timeout 300 ./icd_selftest --oracle ../../oracle/libicd_oracle.so --skip-cases --bench --iters 3 --nq 10000 --n 37000 2>&1 | grep -E "mode=exact|parity"
+timeout 600 ./icd_selftest --oracle ../../oracle/libicd_oracle.so 2>&1 | grep -E "FAIL|passed"
+cd ../..
+bash scripts/gpu_check.sh
