@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     for (int i = 0; i < 4; ++i) {
         const int row_local = (wave * 4 + i) * 8 + (lane >> 3);
         const int piece = (lane & 7) ^ ((row_local >> 1) & 7);
-        src_off[i] = (uint32_t)row_local * (uint32_t)(D * 2) + (uint32_t)piece * 16u;
+        src_off[i] = (uint32_t)row_local * (uint32_t)(D * 2) + (uint32_t)piece * 16u - (uint32_t)(i * 1024);   // (piece i is issued with instruction offset 1024 i, see issue_stage)
     }
     uint32_t rd_off[4];
     {
@@ -139,10 +139,13 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             const int trow = min(g_tile, last_tile - t0);   // stages past the sweep re-read valid memory, never consumed
             char *dst = smem + ring_slot * CO_STAGE_BYTES + wave * 4096;
             const uint32_t soff = (uint32_t)trow * (uint32_t)(CO_BN * D * 2) + (uint32_t)g_ks * (CO_BK * 2);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, (__attribute__((address_space(3))) void *)(dst + i * 1024),
-                                                         16, src_off[i], soff, 0, 0);
+            // The instruction offset is added to the LDS address AND the buffer address: piece i lands at dst + 1024 i
+            // with ONE M0 for the four pieces; src_off[i] was reduced by 1024 i to compensate on the buffer side.
+            __attribute__((address_space(3))) void *ldst = (__attribute__((address_space(3))) void *)dst;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, ldst, 16, src_off[0], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, ldst, 16, src_off[1], soff, 1024, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, ldst, 16, src_off[2], soff, 2048, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, ldst, 16, src_off[3], soff, 3072, 0);
         };
 
         Sel2 st;
