@@ -168,6 +168,27 @@ def test_corpus_in_code_order_stays_on_the_fast_path(oracle, monkeypatch):
     assert st2["last_fallback"] >= st["last_fallback"]
 
 
+def test_one_index_many_call_shapes(oracle):
+    """the same handle serves batches of very different sizes, k and modes back to back (workspaces, shared thresholds
+    and device-side counters carry nothing over from call to call)"""
+    corpus, levels = unit_rows(20000, 768, 110), icd_levels(20000, 111)
+    queries = unit_rows(2500, 768, 112)
+    bad = queries.copy()
+    bad[::7, 5] = 2e5
+    idx = IcdIndex(corpus, levels, max_nq=2500, max_k=64)
+    plan = [(2500, 10, MODE_AUTO, queries), (1, 10, MODE_AUTO, queries), (300, 5, MODE_AUTO, bad), (2500, 10, MODE_AUTO, bad),
+            (17, 12, MODE_AUTO, queries), (700, 10, MODE_EXACT, queries), (129, 64, MODE_AUTO, queries), (2500, 10, MODE_AUTO, queries),
+            (64, 1, MODE_EXACT, bad), (1000, 10, MODE_AUTO, queries)]
+    for nq, k, mode, src in plan:
+        q = src[:nq]
+        s, i = idx.search(q, k, mode)
+        sample = np.unique(np.concatenate([np.arange(0, nq, max(1, nq // 40)), [nq - 1]]))
+        os_, oi = oracle.flat_ip_topk(corpus, q[sample], k)
+        assert np.array_equal(i[sample], oi), (nq, k, mode)
+        assert _bits(s[sample]) == _bits(os_), (nq, k, mode)
+    idx.close()
+
+
 def test_dim_other_than_fast_path(oracle):
     corpus, levels, queries = unit_rows(900, 64, 60), icd_levels(900, 61), unit_rows(11, 64, 62)
     idx = IcdIndex(corpus, levels, max_nq=16, max_k=10)
