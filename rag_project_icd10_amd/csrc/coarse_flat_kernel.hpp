@@ -54,6 +54,109 @@ __host__ __device__ inline int flat_first_ordinal(int m, int w, int ctiles, int 
     return ord;
 }
 
+// End of a list, all 32 queries of the wave at once (lane = half a query; the one-query-at-a-time compaction of
+// Sel2Ops costs ~1 400 cycles per query: 45 000 per list and wave, 7 % of a 90-tile sweep). Every lane loads the 32
+// scores and rows of its half of the query's buffer (slots rotated by the query index: conflict-free), the two lanes
+// of a query bisect the KP-th best score together (counts exchanged with v_permlane32_swap), and the survivors go
+// straight to the list in global memory - the LDS buffer is not rewritten, the list ends here.
+//   slots [0, nlo) and [64 - nhi, 64) of the buffer are valid; thr = the query's threshold (entries at or below an
+//   adopted threshold may still be present: they are candidates like any other).
+// Returns the list's bound (upper bound on everything dropped). Ties at the KP-th score: the tied entries that fit
+// are kept, the bound is the tied score.
+template <int KP>
+__device__ __forceinline__ float flush_emit_parallel(const char *smem, uint32_t qb, int h, int rot, int nlo, int nhi, float thr,
+                                                      bool store, float *out_scores, int *out_rows) {
+    constexpr int CAP = 64, HALF = 32;
+    float v[HALF];
+    uint32_t rw[HALF];
+    const int lo_end = nlo, hi_begin = CAP - nhi;
+#pragma unroll
+    for (int j = 0; j < HALF; ++j) {
+        const int slot = HALF * h + ((j + rot) & (HALF - 1));
+        const bool valid = slot < lo_end || slot >= hi_begin;
+        const float sv = *reinterpret_cast<const float *>(smem + qb + slot * 4);
+        rw[j] = *reinterpret_cast<const uint32_t *>(smem + qb + CAP * 4 + slot * 4);
+        v[j] = valid ? sv : -INFINITY;
+    }
+    auto pair_sum = [&](int x) {
+        const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+        return x + (int)(h ? sw[0] : sw[1]);
+    };
+    const int total = nlo + nhi;
+    // bisection on the order-preserving key; invariant count(v > lo) >= KP > count(v > hi)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < HALF; ++j) mx = fmaxf(mx, v[j]);
+    {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(mx, __uint_as_float(h ? sw[0] : sw[1]));
+    }
+    uint32_t lo = order_f32(thr), hi = order_f32(mx);
+    int cnt_lo = 0;
+#pragma unroll
+    for (int j = 0; j < HALF; ++j) cnt_lo += (v[j] > thr) ? 1 : 0;
+    cnt_lo = pair_sum(cnt_lo);
+    bool active = total > KP && cnt_lo > KP && hi > lo + 1u;
+    while (__builtin_amdgcn_ballot_w64(active) != 0ull) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        const float midf = unorder_f32(mid);
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < HALF; ++j) c += (v[j] > midf) ? 1 : 0;
+        c = pair_sum(c);
+        if (active) {
+            if (c >= KP) { lo = mid; cnt_lo = c; } else hi = mid;
+            active = cnt_lo > KP && hi > lo + 1u;
+        }
+    }
+    // survivors: above lo when that leaves at most KP, else (ties at key hi = lo + 1) above hi plus as many tied as fit
+    // (a buffer of more than KP entries keeps those above lo >= thr - at most KP of them unless scores tie; what it
+    //  drops is at or below lo. A buffer of at most KP entries keeps everything and has dropped nothing new.)
+    float cut = total > KP ? unorder_f32(lo) : -INFINITY;   // keep v > cut
+    float bound = total > KP ? cut : thr;
+    int quota_ties = 0;
+    float tie = 0.0f;
+    if (cnt_lo > KP) {   // (possible only after the loop ended on hi == lo + 1)
+        tie = unorder_f32(hi);
+        int above = 0, tied = 0;
+#pragma unroll
+        for (int j = 0; j < HALF; ++j) { above += (v[j] > tie) ? 1 : 0; tied += (v[j] == tie) ? 1 : 0; }
+        const int above_all = pair_sum(above);
+        const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)tied, (unsigned)tied, false, false);
+        const int tied_low_lane = h ? (int)sw[0] : tied;           // the low lane's ties are served first
+        const int room = KP - above_all;
+        quota_ties = h ? max(0, min(tied, room - min(tied_low_lane, room))) : min(tied, room);
+        cut = tie;
+        bound = tie;
+    }
+    // destination slots: the low lane's survivors first
+    int mine_n = 0;
+#pragma unroll
+    for (int j = 0; j < HALF; ++j) mine_n += (v[j] > cut) ? 1 : 0;
+    mine_n += quota_ties;
+    const auto swn = __builtin_amdgcn_permlane32_swap((unsigned)mine_n, (unsigned)mine_n, false, false);
+    const int other_n = (int)(h ? swn[0] : swn[1]);
+    int dest = h ? other_n : 0;
+    const int kept = mine_n + other_n;   // <= KP
+    if (store) {
+        int ties_left = quota_ties;
+#pragma unroll
+        for (int j = 0; j < HALF; ++j) {
+            bool take = v[j] > cut;
+            if (!take && ties_left > 0 && v[j] == tie && cnt_lo > KP) { take = true; --ties_left; }
+            if (take) {
+                out_scores[dest] = v[j];
+                out_rows[dest] = (int)rw[j];
+                ++dest;
+            }
+        }
+        if (h == 0) {
+            for (int d = kept; d < KP; ++d) { out_scores[d] = -INFINITY; out_rows[d] = -1; }
+        }
+    }
+    return bound;
+}
+
 template <int D>
 __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     constexpr int KS = D / CO_BK;      // stages per tile
@@ -276,32 +379,25 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead stages
         asm volatile("" ::"v"(afn[0]), "v"(afn[1]), "v"(afn[2]), "v"(afn[3]));
 
-        // ---- end of the list: pack every query's entries to the front (top-KP if it holds more) and emit ----
-        Ops::flush(st, lane, smem, wave_qbase, wave_scratch);
-        const bool last_of_mtile = (t1 == a.ctiles);
-        for (int b = 0; b < 32; ++b) {
-            const int slot = slot0 + wave * 32 + b;
-            if (slot >= a.nq) break;
-            const int nb = readlane<int>(st.kept, b);
-            const float thr_b = __builtin_bit_cast(float, readlane<uint32_t>(__float_as_uint(st.thr), b));
-            const uint32_t qb = wave_qbase + (uint32_t)b * Ops::QBYTES;
-            const size_t o = ((size_t)slot * a.P + ord) * CO_KP;
-            if (lane < CO_KP) {
-                float s = -INFINITY;
-                int row = -1;
-                if (lane < nb) {
-                    s = *reinterpret_cast<const float *>(smem + qb + lane * 4);
-                    row = (int)*reinterpret_cast<const uint32_t *>(smem + qb + Ops::ROW_OFF + lane * 4);
-                }
-                a.part_scores[o + lane] = s;
-                a.part_rows[o + lane] = row;
-            }
-            if (lane == 0) a.bounds[(size_t)slot * a.P + ord] = thr_b;
-            if (last_of_mtile) {
-                for (int e = ord + 1; e < a.P; ++e) {
-                    const size_t oe = ((size_t)slot * a.P + e) * CO_KP;
-                    if (lane < CO_KP) { a.part_scores[oe + lane] = -INFINITY; a.part_rows[oe + lane] = -1; }
-                    if (lane == 0) a.bounds[(size_t)slot * a.P + e] = -INFINITY;
+        // ---- end of the list: every query's top-KP entries (unsorted) and its bound go to global memory ----------
+        {
+            const int mine = Ops::used(st, h);
+            const auto swm = __builtin_amdgcn_permlane32_swap((unsigned)mine, (unsigned)mine, false, false);
+            const int other = (int)(h ? swm[0] : swm[1]);
+            const int nlo = st.kept + (h ? other : mine), nhi = h ? mine : other;
+            const int slot = slot0 + wave * 32 + c;
+            const bool store = slot < a.nq;
+            const size_t o = ((size_t)min(slot, a.nq - 1) * a.P + ord) * CO_KP;
+            const float bound = flush_emit_parallel<CO_KP>(smem, wave_qbase + (uint32_t)c * Ops::QBYTES, h, c, nlo, nhi, st.thr,
+                                                           store, a.part_scores + o, a.part_rows + o);
+            if (store && h == 0) {
+                a.bounds[(size_t)slot * a.P + ord] = bound;
+                if (t1 == a.ctiles) {   // last list of the query tile: the unused ordinals are empty
+                    for (int e = ord + 1; e < a.P; ++e) {
+                        const size_t oe = ((size_t)slot * a.P + e) * CO_KP;
+                        for (int d = 0; d < CO_KP; ++d) { a.part_scores[oe + d] = -INFINITY; a.part_rows[oe + d] = -1; }
+                        a.bounds[(size_t)slot * a.P + e] = -INFINITY;
+                    }
                 }
             }
         }
