@@ -152,6 +152,17 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
     u64 *sorted = keys + fin_key_slots(lds_cand);
     double *adjbuf = reinterpret_cast<double *>(sorted + FIN_MAX_K);
     float *qvec = reinterpret_cast<float *>(adjbuf + FIN_MAX_K);
+    // issued first, consumed last: the query (rescoring operand) and its norm / usability flag travel while the
+    // candidates are merged (a wave's life is a chain of dependent round trips; these need not be part of it)
+    float qn_early = 0.0f;
+    unsigned char qbad_early = 0;
+    if (RESCORE) {
+        qn_early = a.qnorm[qidx];
+        qbad_early = a.qbad[qidx];
+        const float *qsrc0 = a.queries + (size_t)qidx * a.dim;
+        for (int d = lane * 4; d < a.dim; d += 256)
+            *reinterpret_cast<float4 *>(qvec + d) = *reinterpret_cast<const float4 *>(qsrc0 + d);
+    }
 
     const int k = a.k;
     const size_t pbase = (size_t)slot * ncand;
@@ -212,7 +223,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
         // 3. certification window
         const u64 mine = (lane < nres) ? sorted[lane] : 0ull;  // lane == coarse rank
         const float coarse = (lane < nres) ? key_score(mine) : -INFINITY;
-        const float eps = a.eps_rel * a.qnorm[qidx] * a.rmax;
+        const float eps = a.eps_rel * qn_early * a.rmax;
         bool certified;
         float L;
         if (nres >= k) {
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
             L = -INFINITY;
             certified = (tau == -INFINITY);
         }
-        if (a.qbad[qidx]) certified = false;
+        if (qbad_early) certified = false;
         if (!certified) {
             if (lane == 0) {
                 const int i = atomicAdd(a.nflag, 1);
@@ -234,9 +245,6 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
         }
         const bool inwin = (lane < nres) && (coarse >= L);
         // 4. canonical rescoring of the window (scalar fmaf chain, d ascending)
-        const float *qsrc = a.queries + (size_t)qidx * a.dim;
-        for (int d = lane * 4; d < a.dim; d += 256)
-            *reinterpret_cast<float4 *>(qvec + d) = *reinterpret_cast<const float4 *>(qsrc + d);
         u64 xkey = 0ull;
         if (inwin) {
             const uint32_t row = key_row(mine);
