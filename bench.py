@@ -109,11 +109,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # test hook (single-GPU boxes): ICD_BENCH_BACKEND=gloo ICD_BENCH_ONE_DEVICE=1 runs the N-rank control flow with
+    # every rank on cuda:0 and the reductions on the CPU; the driver's runs use nccl (= RCCL), one GPU per rank
+    backend = os.environ.get("ICD_BENCH_BACKEND", "nccl")
+    if os.environ.get("ICD_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
     dim, nq, n, k = 768, args.nq, args.n, args.k
     mode = MODE_AUTO if args.mode == "auto" else MODE_EXACT
 
@@ -144,7 +153,7 @@ def main():
     prof = index.profile_summary()
     index.set_profiling(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stats = index.stats()
