@@ -360,47 +360,6 @@ struct Sel2Ops {
             prof[1] += pt1 - pt0;
         }
     }
-    // End of a list: every query keeps at most KP entries, packed at the front of its buffer (unsorted), and
-    // s.kept / s.thr are final. Queries holding more than KP entries go through the compaction above
-    // (bisection, ranking on ties); the others only move the high lane's entries next to the low lane's.
-    __device__ static __forceinline__ void flush(Sel2 &s, int lane, char *smem, uint32_t wave_qbase, uint32_t wave_scratch) {
-        check(s, lane, smem, wave_qbase, wave_scratch, false, KP);
-        const int h = lane >> 5;
-        const int mine = used(s, h);
-        const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)mine, (unsigned)mine, false, false);
-        const int other = (int)(h ? sw[0] : sw[1]);
-        const int hi_cnt = h ? mine : other;
-        uint32_t need = (uint32_t)__ballot(hi_cnt > 0);   // both lanes of a query agree
-        while (need) {
-            const int b = __ffs((int)need) - 1;
-            need &= need - 1;
-            const int nlo = readlane<int>(s.kept, b) + readlane<int>(mine, b);
-            const int nhi = readlane<int>(mine, b + 32);
-            const uint32_t qb = wave_qbase + (uint32_t)b * QBYTES;
-            const bool valid = (lane >= CAP - nhi);          // the low side is already in place
-            float v = 0.f;
-            uint32_t row = 0;
-            if (valid) {
-                v = *reinterpret_cast<const float *>(smem + qb + lane * 4);
-                row = *reinterpret_cast<const uint32_t *>(smem + qb + ROW_OFF + lane * 4);
-            }
-            const int dest = nlo + (lane - (CAP - nhi));
-            if (valid) {
-                *reinterpret_cast<float *>(smem + qb + dest * 4) = v;
-                *reinterpret_cast<uint32_t *>(smem + qb + ROW_OFF + dest * 4) = row;
-            }
-            if ((lane & 31) == b) {
-                s.kept = nlo + nhi;
-                s.aw0 = h ? qb + (CAP - 1) * 4 : qb + (uint32_t)s.kept * 4;
-                s.aw = s.aw0;
-            }
-        }
-        // queries with entries on the low side only: kept = prefix + appended
-        const int mine2 = used(s, h);
-        if (h == 0 && mine2 > 0) { s.kept += mine2; s.aw0 = s.aw; }
-        const auto sw2 = __builtin_amdgcn_permlane32_swap((unsigned)s.kept, (unsigned)s.kept, false, false);
-        if (h == 1) s.kept = (int)sw2[0];   // the high lane mirrors the query-level count
-    }
 };
 
 }  // namespace icd
