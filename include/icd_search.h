@@ -80,7 +80,7 @@ typedef struct icd_stats {
     /* counters of the most recent search (valid after the stream is synchronised) */
     int64_t last_nq;
     int64_t last_fallback;      /* queries that took the exact fallback in AUTO mode */
-    int32_t last_chunks;        /* corpus chunks (P) used by the coarse kernel */
+    int32_t last_chunks;        /* candidate lists per query (P) of the last call's scoring pass */
     int32_t last_mode;
 } icd_stats;
 
@@ -149,7 +149,8 @@ int icd_index_lookup_levels(icd_index *idx, const int64_t *ids, int64_t count, i
 
 int icd_index_stats(icd_index *idx, icd_stats *out);
 
-/* Tuning knobs (0 = automatic): number of corpus chunks P per query tile for the coarse kernel. */
+/* Tuning knob / test hook (0 = automatic): aim for about `chunks` candidate lists per query in the coarse pass
+ * (the automatic choice gives every CU the same number of 128 x 128 tiles). */
 int icd_index_set_chunks(icd_index *idx, int32_t chunks);
 
 /* Diagnostic builds only (env ICD_COARSE_VAR=8): per-wave cycle sums of the coarse kernel,
