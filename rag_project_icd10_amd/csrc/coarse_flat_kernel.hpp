@@ -36,7 +36,7 @@ struct CoarseFlatArgs {
     unsigned int *shared_thr; // [nq_pad] order_f32 keys, cleared before the launch: max over a query's lists of their thresholds
 };
 
-constexpr int CO_BOOT_MIN_TILES = 16;  // lists at least this long bootstrap their threshold ...
+constexpr int CO_BOOT_MIN_TILES = 6;   // lists at least this long bootstrap their threshold ...
 constexpr int CO_BOOT_TILES = 8;       // ... over their first tiles
 
 // number of lists a run of `len` tiles is cut into
@@ -254,7 +254,8 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
         Sel2 st;
         Ops::init(st, wave_qbase + (uint32_t)c * Ops::QBYTES, h, (slot0 + wave * 32 + c) < a.nq);
         float boot1 = -INFINITY, boot2 = -INFINITY, boot3 = -INFINITY;   // bootstrap: the lane's three best scores so far
-        const int boot_tiles = ntiles >= CO_BOOT_MIN_TILES ? CO_BOOT_TILES : 0;
+        // (a third of the list at most: 6 rows above the level per boot_tiles tiles -> >= 18 in the whole list)
+        const int boot_tiles = ntiles >= CO_BOOT_MIN_TILES ? min(CO_BOOT_TILES, ntiles / 3) : 0;
         unsigned int *my_shared = a.shared_thr + (slot0 + wave * 32 + c);
         const bool publish = (slot0 + wave * 32 + c) < a.nq;   // (padding queries sit at +inf and never publish)
         uint32_t published = 0u;

@@ -132,7 +132,10 @@ __host__ __device__ inline size_t fin_wave_lds_bytes(bool rescore, int dim, int 
     return (size_t)fin_key_slots(ncand) * 8 + FIN_MAX_K * 8 + FIN_MAX_K * 8 + (rescore ? (size_t)dim * 4 : 0);
 }
 
-template <bool RESCORE>
+// DEEP: the rescoring keeps 2 x 12 row pieces in flight per lane instead of 8 - fewer dependent round trips for a
+// launch whose waves all fit on the chip at once (latency matters), more registers / fewer resident waves for a
+// large one (throughput matters: measured slower at 10 000 queries). The host picks by the query count.
+template <bool RESCORE, bool DEEP = false>
 __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -197,7 +200,10 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
         }
     }
     // 2. rank all candidates; keep the best T sorted
-    const int T = RESCORE ? 64 : k;
+    // RESCORE keeps the best T coarse candidates as the rescoring window; everything past T counts as dropped (it raises
+    // tau below). 32 is plenty (the window holds ~12 rows) and, with many lists, lets rank_top's prefilter cut the
+    // ranking loop from ~300 survivors to ~50.
+    const int T = RESCORE ? (ncand > 128 ? 32 : 64) : k;
     int rank[FIN_EF];
     float tau = -INFINITY;  // largest coarse score that may have been dropped anywhere
     if (RESCORE) {
@@ -251,16 +257,51 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
             const float4 *c4 = reinterpret_cast<const float4 *>(a.corpus + (size_t)row * a.dim);
             const float4 *q4 = reinterpret_cast<const float4 *>(qvec);
             float acc = 0.0f;
-            const int n4 = a.dim >> 2;
-            // (deeper software prefetch of the row costs registers and with them resident waves: measured slower)
+            const int n4 = a.dim >> 2;   // multiple of 8 (dim % 32 == 0)
+            if constexpr (DEEP) {
+                constexpr int RB = 12;
+                float4 cur[RB], nxt[RB];
+                const int nb = n4 / RB * RB;   // (dims that are not a multiple of 48 floats finish in the plain loop)
+#pragma unroll
+                for (int j = 0; j < RB; ++j) cur[j] = c4[j < n4 ? j : 0];
+                for (int i0 = 0; i0 < nb; i0 += RB) {
+                    const bool more = i0 + 2 * RB <= nb;
+                    if (more) {
+#pragma unroll
+                        for (int j = 0; j < RB; ++j) nxt[j] = c4[i0 + RB + j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < RB; ++j) {
+                        const float4 qv = q4[i0 + j];
+                        acc = __builtin_fmaf(qv.x, cur[j].x, acc);
+                        acc = __builtin_fmaf(qv.y, cur[j].y, acc);
+                        acc = __builtin_fmaf(qv.z, cur[j].z, acc);
+                        acc = __builtin_fmaf(qv.w, cur[j].w, acc);
+                    }
+                    if (more) {
+#pragma unroll
+                        for (int j = 0; j < RB; ++j) cur[j] = nxt[j];
+                    }
+                }
+                for (int i = nb; i < n4; ++i) {
+                    const float4 cv = c4[i];
+                    const float4 qv = q4[i];
+                    acc = __builtin_fmaf(qv.x, cv.x, acc);
+                    acc = __builtin_fmaf(qv.y, cv.y, acc);
+                    acc = __builtin_fmaf(qv.z, cv.z, acc);
+                    acc = __builtin_fmaf(qv.w, cv.w, acc);
+                }
+            } else {
+                // (deeper software prefetch of the row costs registers and with them resident waves: slower for big launches)
 #pragma unroll 8
-            for (int i = 0; i < n4; ++i) {
-                const float4 cv = c4[i];
-                const float4 qv = q4[i];
-                acc = __builtin_fmaf(qv.x, cv.x, acc);
-                acc = __builtin_fmaf(qv.y, cv.y, acc);
-                acc = __builtin_fmaf(qv.z, cv.z, acc);
-                acc = __builtin_fmaf(qv.w, cv.w, acc);
+                for (int i = 0; i < n4; ++i) {
+                    const float4 cv = c4[i];
+                    const float4 qv = q4[i];
+                    acc = __builtin_fmaf(qv.x, cv.x, acc);
+                    acc = __builtin_fmaf(qv.y, cv.y, acc);
+                    acc = __builtin_fmaf(qv.z, cv.z, acc);
+                    acc = __builtin_fmaf(qv.w, cv.w, acc);
+                }
             }
             if (acc == acc && acc != -INFINITY) xkey = make_key(acc, row);
         }
