@@ -469,12 +469,14 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             const int nwg_ = (a.total_units + U - 1) / U;
             const int members = nwg_ / std::max(1, a.pos_period);
             int split = (members + 11) / 12;
+#ifdef ICD_ABLATE
             if (const char *e = getenv("ICD_XCD_MODE")) {   // A/B switch: 0 identity, 1 XCD swizzle only, 2 classes unsplit
                 const int m = atoi(e);
                 if (m == 0) a.pos_period = 0;
                 else if (m == 1) a.pos_period = 1 << 30;
                 else if (m == 2) split = 1;
             }
+#endif
             if (a.pos_period > 0 && a.pos_period < (1 << 20)) a.pos_period *= std::max(1, split);
         }
         a.part_scores = x->partc_s; a.part_rows = x->partc_r; a.bounds = x->partc_b; a.shared_thr = x->shared_thr;
