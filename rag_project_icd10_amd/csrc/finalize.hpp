@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
     // RESCORE keeps the best T coarse candidates as the rescoring window; everything past T counts as dropped (it raises
     // tau below). 32 is plenty (the window holds ~12 rows) and, with many lists, lets rank_top's prefilter cut the
     // ranking loop from ~300 survivors to ~50.
-    const int T = RESCORE ? (ncand > 128 ? 32 : 64) : k;
+    const int T = RESCORE ? ((ncand > 128 && k <= 12) ? 32 : 64) : k;
     int rank[FIN_EF];
     float tau = -INFINITY;  // largest coarse score that may have been dropped anywhere
     if (RESCORE) {

@@ -46,7 +46,7 @@ int fail(int code, const char *fmt, ...) {
     } while (0)
 
 constexpr float EPS_REL = 1.2e-3f;
-constexpr int FAST_MAX_K = 12;       // coarse lists hold KP = 16 candidates per chunk
+constexpr int FAST_MAX_K = 32;       // the rescoring window is one candidate per lane (64): k + the rows inside 2 eps of the k-th
 constexpr int COARSE_MAX_P = 32;     // P * KP <= FIN_MAX_CAND
 constexpr int NUM_EV = 6;
 constexpr int EV_RING = 128;         // profiled searches kept for icd_index_profile_summary
@@ -435,6 +435,9 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         // largest score any list may have dropped, and with one list that is the query's own 16th best (8 % of
         // Gaussian queries then fail, profiles/r01_sizes_before_pmin2.log); with two or more it is about rank 32.
         a.list_tiles = std::max(1, (ctiles + 1) / 2);
+        // Larger k: every list keeps KP = 16 candidates and ends on its own 16th best, so the bound the certificate
+        // compares the k-th best against sits near rank 16 P / 2 of the whole corpus: ask for about k / 4 lists.
+        if (k > 8) a.list_tiles = std::max(1, std::min(a.list_tiles, ctiles / ((k + 3) / 4)));
         int U = std::max(1, (a.total_units + x->num_cu - 1) / x->num_cu);
         if (x->chunks_override > 0) {   // test hook: about `chunks` lists per query
             U = std::max(1, (ctiles + x->chunks_override - 1) / x->chunks_override);
@@ -630,7 +633,8 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     }
     if (x->fast) {
         CR_TRY(wsalloc(&x->q16, (size_t)x->max_nq_pad * dim));
-        x->partc_cap = std::max<size_t>((size_t)x->max_nq_pad * 6 * CO_KP, (size_t)1 << 20);
+        const int lists_for_max_k = std::min(COARSE_MAX_P, std::max(6, (std::min(max_k, FAST_MAX_K) + 3) / 4 + 4));
+        x->partc_cap = std::max<size_t>((size_t)x->max_nq_pad * lists_for_max_k * CO_KP, (size_t)1 << 20);
         CR_TRY(wsalloc(&x->partc_s, x->partc_cap));
         CR_TRY(wsalloc(&x->partc_r, x->partc_cap));
         CR_TRY(wsalloc(&x->partc_b, x->partc_cap / CO_KP));

@@ -189,6 +189,19 @@ def test_one_index_many_call_shapes(oracle):
     idx.close()
 
 
+@pytest.mark.parametrize("k", [13, 20, 32])
+def test_larger_k_on_the_fast_path(oracle, k):
+    """/query searches top_k * 2 (F7): k up to 32 stays on the certified fp16 path (more lists per query, one rescoring
+    candidate per lane); larger k takes the exact kernel"""
+    corpus, levels, queries = unit_rows(20000, 768, 120), icd_levels(20000, 121), unit_rows(700, 768, 122)
+    idx = IcdIndex(corpus, levels, max_nq=700, max_k=64)
+    st = _check(oracle, idx, corpus, levels, queries, k, MODE_AUTO)
+    assert st["last_mode"] == MODE_AUTO and st["last_fallback"] <= 70
+    st = _check(oracle, idx, corpus, levels, queries, 33, MODE_AUTO)
+    assert st["last_mode"] == MODE_EXACT
+    idx.close()
+
+
 def test_dim_other_than_fast_path(oracle):
     corpus, levels, queries = unit_rows(900, 64, 60), icd_levels(900, 61), unit_rows(11, 64, 62)
     idx = IcdIndex(corpus, levels, max_nq=16, max_k=10)
