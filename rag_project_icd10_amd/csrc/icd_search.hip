@@ -389,7 +389,8 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
 
     // small batches (the reference's one-query-per-call shape): stream the corpus once, exact, no coarse pass
     const bool stream_ok = x->dim % (32 * ST_PF) == 0 && stream_fits(kpx, 1, x->dim);
-    const bool tiny = stream_ok && nq <= (use_fast ? 16 : ST_MAX_ACTIVE);
+    // (k > 16 needs the 64-entry lists of the streaming kernel, ~0.9 ms per 16 queries: the coarse pass is faster there)
+    const bool tiny = stream_ok && nq <= (use_fast ? (k <= 16 ? 16 : 0) : ST_MAX_ACTIVE);
     if (tiny) {
         x->last_mode = ICD_MODE_EXACT;
         x->last_chunks = p_sparse;

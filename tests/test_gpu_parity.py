@@ -57,11 +57,11 @@ def test_parity_small(oracle, n, nq, dim, k, kind, mode):
 
 
 @pytest.mark.parametrize("k", [17, 64, 100])
-def test_large_k_uses_exact_kernel(oracle, k):
+def test_large_k(oracle, k):
     corpus, levels, queries = unit_rows(5000, 768, 40), icd_levels(5000, 41), unit_rows(9, 768, 42)
     idx = IcdIndex(corpus, levels, max_nq=16, max_k=100)
     st = _check(oracle, idx, corpus, levels, queries, k, MODE_AUTO)
-    assert st["last_mode"] == MODE_EXACT      # AUTO routes k > 12 to the fp32 kernel
+    assert st["last_mode"] == (MODE_AUTO if k <= 32 else MODE_EXACT)      # AUTO routes k > 32 to the exact kernels
     idx.close()
 
 
