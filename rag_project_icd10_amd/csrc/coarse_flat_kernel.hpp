@@ -29,6 +29,7 @@ struct CoarseFlatArgs {
     int units_per_wg;        // U
     int pos_period;          // ctiles / gcd(U, ctiles): work-groups l and l + pos_period start on the same corpus tile
     int list_tiles;          // a list covers at most this many tiles
+    int boot_tiles;          // threshold bootstrap over at most this many first tiles of a list (less for larger k)
     int P;                   // list slots per query (>= the largest number of lists of any query tile)
     float *part_scores;      // [nq][P][KP]
     int *part_rows;
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
         Ops::init(st, wave_qbase + (uint32_t)c * Ops::QBYTES, h, (slot0 + wave * 32 + c) < a.nq);
         float boot1 = -INFINITY, boot2 = -INFINITY, boot3 = -INFINITY;   // bootstrap: the lane's three best scores so far
         // (a third of the list at most: 6 rows above the level per boot_tiles tiles -> >= 18 in the whole list)
-        const int boot_tiles = ntiles >= CO_BOOT_MIN_TILES ? min(CO_BOOT_TILES, ntiles / 3) : 0;
+        const int boot_tiles = ntiles >= CO_BOOT_MIN_TILES ? min(a.boot_tiles, ntiles / 3) : 0;
         unsigned int *my_shared = a.shared_thr + (slot0 + wave * 32 + c);
         const bool publish = (slot0 + wave * 32 + c) < a.nq;   // (padding queries sit at +inf and never publish)
         uint32_t published = 0u;

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
     // RESCORE keeps the best T coarse candidates as the rescoring window; everything past T counts as dropped (it raises
     // tau below). 32 is plenty (the window holds ~12 rows) and, with many lists, lets rank_top's prefilter cut the
     // ranking loop from ~300 survivors to ~50.
-    const int T = RESCORE ? ((ncand > 128 && k <= 12) ? 32 : 64) : k;
+    const int T = RESCORE ? ((k > 32 && ncand >= 128) ? 128 : ((ncand > 128 && k <= 12) ? 32 : 64)) : k;
     int rank[FIN_EF];
     float tau = -INFINITY;  // largest coarse score that may have been dropped anywhere
     if (RESCORE) {
@@ -226,9 +226,16 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
 
     if (RESCORE) {
         tau = wave_max_f32(tau);
-        // 3. certification window
-        const u64 mine = (lane < nres) ? sorted[lane] : 0ull;  // lane == coarse rank
-        const float coarse = (lane < nres) ? key_score(mine) : -INFINITY;
+        // 3. certification window: candidate of coarse rank lane + 64 e (one per lane for k <= 32, two for larger k)
+        const int EW = T > 64 ? 2 : 1;
+        u64 mine[2];
+        float coarse[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int idx = lane + 64 * e;
+            mine[e] = (e < EW && idx < nres) ? sorted[idx] : 0ull;
+            coarse[e] = mine[e] != 0ull ? key_score(mine[e]) : -INFINITY;
+        }
         const float eps = a.eps_rel * qn_early * a.rmax;
         bool certified;
         float L;
@@ -249,15 +256,12 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
             }
             return;
         }
-        const bool inwin = (lane < nres) && (coarse >= L);
         // 4. canonical rescoring of the window (scalar fmaf chain, d ascending)
-        u64 xkey = 0ull;
-        if (inwin) {
-            const uint32_t row = key_row(mine);
+        const float4 *q4 = reinterpret_cast<const float4 *>(qvec);
+        const int n4 = a.dim >> 2;   // multiple of 8 (dim % 32 == 0)
+        auto chain = [&](uint32_t row) -> float {
             const float4 *c4 = reinterpret_cast<const float4 *>(a.corpus + (size_t)row * a.dim);
-            const float4 *q4 = reinterpret_cast<const float4 *>(qvec);
             float acc = 0.0f;
-            const int n4 = a.dim >> 2;   // multiple of 8 (dim % 32 == 0)
             if constexpr (DEEP) {
                 constexpr int RB = 12;
                 float4 cur[RB], nxt[RB];
@@ -303,14 +307,30 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
                     acc = __builtin_fmaf(qv.w, cv.w, acc);
                 }
             }
-            if (acc == acc && acc != -INFINITY) xkey = make_key(acc, row);
+            return acc;
+        };
+        u64 xkey[2] = {0ull, 0ull};
+        for (int e = 0; e < EW; ++e) {
+            if (mine[e] != 0ull && coarse[e] >= L) {
+                const uint32_t row = key_row(mine[e]);
+                const float acc = chain(row);
+                if (acc == acc && acc != -INFINITY) xkey[e] = make_key(acc, row);
+            }
         }
-        // 5. rank the rescored candidates (one per lane) and keep the best k
-        keys[lane] = xkey;
-        int xr = 0;
-        for (int j = 0; j < 64; ++j) xr += (keys[j] > xkey) ? 1 : 0;
-        const int nx = __popcll(__ballot(xkey != 0ull));
-        if (xkey != 0ull && xr < k) sorted[xr] = xkey;
+        // 5. rank the rescored candidates and keep the best k
+        for (int e = 0; e < EW; ++e) keys[lane + 64 * e] = xkey[e];
+        int xr[2] = {0, 0};
+        for (int j = 0; j < 64 * EW; ++j) {
+            const u64 kj = keys[j];
+            xr[0] += (kj > xkey[0]) ? 1 : 0;
+            xr[1] += (kj > xkey[1]) ? 1 : 0;
+        }
+        int nx = 0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            nx += __popcll(__ballot(xkey[e] != 0ull));
+            if (xkey[e] != 0ull && xr[e] < k) sorted[xr[e]] = xkey[e];
+        }
         nres = min(nx, k);
     }
     // 6-7. outputs (raw order + level reweight / stable re-sort)

@@ -46,7 +46,7 @@ int fail(int code, const char *fmt, ...) {
     } while (0)
 
 constexpr float EPS_REL = 1.2e-3f;
-constexpr int FAST_MAX_K = 32;       // the rescoring window is one candidate per lane (64): k + the rows inside 2 eps of the k-th
+constexpr int FAST_MAX_K = 64;       // the rescoring window is one (k <= 32) or two candidates per lane: k + the rows inside 2 eps of the k-th
 constexpr int COARSE_MAX_P = 32;     // P * KP <= FIN_MAX_CAND
 constexpr int NUM_EV = 6;
 constexpr int EV_RING = 128;         // profiled searches kept for icd_index_profile_summary
@@ -439,6 +439,10 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         // Larger k: every list keeps KP = 16 candidates and ends on its own 16th best, so the bound the certificate
         // compares the k-th best against sits near rank 16 P / 2 of the whole corpus: ask for about k / 4 lists.
         if (k > 8) a.list_tiles = std::max(1, std::min(a.list_tiles, ctiles / ((k + 3) / 4)));
+        // The bootstrap level (6th best of the first boot_tiles * 128 rows of a list) must stay far below the k-th best
+        // of the whole corpus or the list's bound lands inside the window: fewer tiles for larger k (measured at
+        // k = 48 with 8 tiles: 1.6 % of the queries uncertified).
+        a.boot_tiles = std::max(1, std::min(CO_BOOT_TILES, 96 / std::max(1, k)));
         int U = std::max(1, (a.total_units + x->num_cu - 1) / x->num_cu);
         if (x->chunks_override > 0) {   // test hook: about `chunks` lists per query
             U = std::max(1, (ctiles + x->chunks_override - 1) / x->chunks_override);

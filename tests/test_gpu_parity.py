@@ -61,7 +61,7 @@ def test_large_k(oracle, k):
     corpus, levels, queries = unit_rows(5000, 768, 40), icd_levels(5000, 41), unit_rows(9, 768, 42)
     idx = IcdIndex(corpus, levels, max_nq=16, max_k=100)
     st = _check(oracle, idx, corpus, levels, queries, k, MODE_AUTO)
-    assert st["last_mode"] == (MODE_AUTO if k <= 32 else MODE_EXACT)      # AUTO routes k > 32 to the exact kernels
+    assert st["last_mode"] == (MODE_AUTO if k <= 64 else MODE_EXACT)      # AUTO routes k > 64 to the exact kernels
     idx.close()
 
 
@@ -93,7 +93,7 @@ def test_heavy_duplicates_through_the_coarse_path(oracle):
 
 
 @pytest.mark.parametrize("n,nq,dim,k,mode", [
-    (3000, 1, 1024, 10, MODE_AUTO), (3000, 3, 1024, 64, MODE_AUTO), (2500, 2, 96, 7, MODE_AUTO),
+    (3000, 1, 1024, 10, MODE_AUTO), (3000, 3, 1024, 64, MODE_EXACT), (2500, 2, 96, 7, MODE_AUTO),
     (9000, 40, 768, 10, MODE_EXACT), (9000, 64, 768, 100, MODE_EXACT), (700, 16, 768, 128, MODE_AUTO),
     (257, 7, 2048, 10, MODE_EXACT),
 ])
@@ -189,15 +189,15 @@ def test_one_index_many_call_shapes(oracle):
     idx.close()
 
 
-@pytest.mark.parametrize("k", [13, 20, 32])
+@pytest.mark.parametrize("k", [13, 20, 32, 48, 64])
 def test_larger_k_on_the_fast_path(oracle, k):
-    """/query searches top_k * 2 (F7): k up to 32 stays on the certified fp16 path (more lists per query, one rescoring
-    candidate per lane); larger k takes the exact kernel"""
+    """/query searches top_k * 2 (F7): k up to 64 stays on the certified fp16 path (about k / 4 lists per query, one or
+    two rescoring candidates per lane); larger k takes the exact kernel"""
     corpus, levels, queries = unit_rows(20000, 768, 120), icd_levels(20000, 121), unit_rows(700, 768, 122)
-    idx = IcdIndex(corpus, levels, max_nq=700, max_k=64)
+    idx = IcdIndex(corpus, levels, max_nq=700, max_k=100)
     st = _check(oracle, idx, corpus, levels, queries, k, MODE_AUTO)
     assert st["last_mode"] == MODE_AUTO and st["last_fallback"] <= 70
-    st = _check(oracle, idx, corpus, levels, queries, 33, MODE_AUTO)
+    st = _check(oracle, idx, corpus, levels, queries, 65, MODE_AUTO)
     assert st["last_mode"] == MODE_EXACT
     idx.close()
 
