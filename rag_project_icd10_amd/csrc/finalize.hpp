@@ -14,7 +14,8 @@
 namespace icd {
 
 constexpr int FIN_MAX_CAND = 512;  // P * KP
-constexpr int FIN_MAX_K = 128;
+constexpr int FIN_MAX_K = 128;     // largest k of a search
+constexpr int FIN_MAX_T = 256;     // largest rescoring window (RESCORE): the best T coarse candidates, T/64 per lane
 constexpr int FIN_EF = FIN_MAX_CAND / 64;
 
 struct FinArgs {
@@ -126,10 +127,10 @@ __device__ __forceinline__ void emit_outputs(const FinArgs &a, int qidx, const u
     }
 }
 
-// LDS per wave: keys[max(ncand, 64) rounded to 64] u64 | sorted[128] u64 | adjbuf[128] double | qvec[dim] float (RESCORE)
+// LDS per wave: keys[max(ncand, 64) rounded to 64] u64 | sorted[256] u64 | adjbuf[128] double | qvec[dim] float (RESCORE)
 __host__ __device__ inline int fin_key_slots(int ncand) { return ncand <= 64 ? 64 : ((ncand + 63) & ~63); }
 __host__ __device__ inline size_t fin_wave_lds_bytes(bool rescore, int dim, int ncand) {
-    return (size_t)fin_key_slots(ncand) * 8 + FIN_MAX_K * 8 + FIN_MAX_K * 8 + (rescore ? (size_t)dim * 4 : 0);
+    return (size_t)fin_key_slots(ncand) * 8 + FIN_MAX_T * 8 + FIN_MAX_K * 8 + (rescore ? (size_t)dim * 4 : 0);
 }
 
 // DEEP: the rescoring keeps 2 x 12 row pieces in flight per lane instead of 8 - fewer dependent round trips for a
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
     char *wbase = smem + (size_t)wave * fin_wave_lds_bytes(RESCORE, a.dim, lds_cand);
     u64 *keys = reinterpret_cast<u64 *>(wbase);
     u64 *sorted = keys + fin_key_slots(lds_cand);
-    double *adjbuf = reinterpret_cast<double *>(sorted + FIN_MAX_K);
+    double *adjbuf = reinterpret_cast<double *>(sorted + FIN_MAX_T);
     float *qvec = reinterpret_cast<float *>(adjbuf + FIN_MAX_K);
     // issued first, consumed last: the query (rescoring operand) and its norm / usability flag travel while the
     // candidates are merged (a wave's life is a chain of dependent round trips; these need not be part of it)
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
     // RESCORE keeps the best T coarse candidates as the rescoring window; everything past T counts as dropped (it raises
     // tau below). 32 is plenty (the window holds ~12 rows) and, with many lists, lets rank_top's prefilter cut the
     // ranking loop from ~300 survivors to ~50.
-    const int T = RESCORE ? ((k > 32 && ncand >= 128) ? 128 : ((ncand > 128 && k <= 12) ? 32 : 64)) : k;
+    const int T = RESCORE ? ((k > 64 && ncand >= 256) ? 256 : (k > 32 && ncand >= 128) ? 128 : ((ncand > 128 && k <= 12) ? 32 : 64)) : k;
     int rank[FIN_EF];
     float tau = -INFINITY;  // largest coarse score that may have been dropped anywhere
     if (RESCORE) {
@@ -226,12 +227,13 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
 
     if (RESCORE) {
         tau = wave_max_f32(tau);
-        // 3. certification window: candidate of coarse rank lane + 64 e (one per lane for k <= 32, two for larger k)
-        const int EW = T > 64 ? 2 : 1;
-        u64 mine[2];
-        float coarse[2];
+        // 3. certification window: candidate of coarse rank lane + 64 e (one per lane for k <= 32, up to four for larger k)
+        constexpr int EWM = FIN_MAX_T / 64;
+        const int EW = T / 64 > 1 ? T / 64 : 1;
+        u64 mine[EWM];
+        float coarse[EWM];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < EWM; ++e) {
             const int idx = lane + 64 * e;
             mine[e] = (e < EW && idx < nres) ? sorted[idx] : 0ull;
             coarse[e] = mine[e] != 0ull ? key_score(mine[e]) : -INFINITY;
@@ -309,8 +311,12 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
             }
             return acc;
         };
-        u64 xkey[2] = {0ull, 0ull};
-        for (int e = 0; e < EW; ++e) {
+        u64 xkey[EWM];
+#pragma unroll
+        for (int e = 0; e < EWM; ++e) xkey[e] = 0ull;
+#pragma unroll
+        for (int e = 0; e < EWM; ++e) {
+            if (e >= EW) break;
             if (mine[e] != 0ull && coarse[e] >= L) {
                 const uint32_t row = key_row(mine[e]);
                 const float acc = chain(row);
@@ -318,16 +324,20 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
             }
         }
         // 5. rank the rescored candidates and keep the best k
-        for (int e = 0; e < EW; ++e) keys[lane + 64 * e] = xkey[e];
-        int xr[2] = {0, 0};
+#pragma unroll
+        for (int e = 0; e < EWM; ++e)
+            if (e < EW) keys[lane + 64 * e] = xkey[e];
+        int xr[EWM];
+#pragma unroll
+        for (int e = 0; e < EWM; ++e) xr[e] = 0;
         for (int j = 0; j < 64 * EW; ++j) {
             const u64 kj = keys[j];
-            xr[0] += (kj > xkey[0]) ? 1 : 0;
-            xr[1] += (kj > xkey[1]) ? 1 : 0;
+#pragma unroll
+            for (int e = 0; e < EWM; ++e) xr[e] += (kj > xkey[e]) ? 1 : 0;
         }
         int nx = 0;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < EWM; ++e) {
             nx += __popcll(__ballot(xkey[e] != 0ull));
             if (xkey[e] != 0ull && xr[e] < k) sorted[xr[e]] = xkey[e];
         }

@@ -46,7 +46,7 @@ int fail(int code, const char *fmt, ...) {
     } while (0)
 
 constexpr float EPS_REL = 1.2e-3f;
-constexpr int FAST_MAX_K = 64;       // the rescoring window is one (k <= 32) or two candidates per lane: k + the rows inside 2 eps of the k-th
+constexpr int FAST_MAX_K = 100;      // the rescoring window holds up to 256 candidates (four per lane): k + the rows inside 2 eps of the k-th
 constexpr int COARSE_MAX_P = 32;     // P * KP <= FIN_MAX_CAND
 constexpr int NUM_EV = 6;
 constexpr int EV_RING = 128;         // profiled searches kept for icd_index_profile_summary

@@ -61,7 +61,7 @@ def test_large_k(oracle, k):
     corpus, levels, queries = unit_rows(5000, 768, 40), icd_levels(5000, 41), unit_rows(9, 768, 42)
     idx = IcdIndex(corpus, levels, max_nq=16, max_k=100)
     st = _check(oracle, idx, corpus, levels, queries, k, MODE_AUTO)
-    assert st["last_mode"] == (MODE_AUTO if k <= 64 else MODE_EXACT)      # AUTO routes k > 64 to the exact kernels
+    assert st["last_mode"] == MODE_AUTO      # k <= 100 stays on the certified fp16 path
     idx.close()
 
 
@@ -189,15 +189,15 @@ def test_one_index_many_call_shapes(oracle):
     idx.close()
 
 
-@pytest.mark.parametrize("k", [13, 20, 32, 48, 64])
+@pytest.mark.parametrize("k", [13, 20, 32, 48, 64, 100])
 def test_larger_k_on_the_fast_path(oracle, k):
-    """/query searches top_k * 2 (F7): k up to 64 stays on the certified fp16 path (about k / 4 lists per query, one or
-    two rescoring candidates per lane); larger k takes the exact kernel"""
+    """/query searches top_k * 2 (F7): k up to 100 stays on the certified fp16 path (about k / 4 lists per query, one to
+    four rescoring candidates per lane); larger k takes the exact kernel"""
     corpus, levels, queries = unit_rows(20000, 768, 120), icd_levels(20000, 121), unit_rows(700, 768, 122)
-    idx = IcdIndex(corpus, levels, max_nq=700, max_k=100)
+    idx = IcdIndex(corpus, levels, max_nq=700, max_k=128)
     st = _check(oracle, idx, corpus, levels, queries, k, MODE_AUTO)
     assert st["last_mode"] == MODE_AUTO and st["last_fallback"] <= 70
-    st = _check(oracle, idx, corpus, levels, queries, 65, MODE_AUTO)
+    st = _check(oracle, idx, corpus, levels, queries, 101, MODE_AUTO)
     assert st["last_mode"] == MODE_EXACT
     idx.close()
 
