@@ -48,13 +48,20 @@ def main():
         n = int(rng.choice([1, 7, 127, 128, 129, 1000, 4097, 20000, 37000, 100003]))
         nq = int(rng.choice([1, 2, 9, 16, 17, 64, 65, 128, 129, 1000, 3000]))
         k = int(rng.choice([1, 5, 10, 10, 10, 12, 13, 50, 100]))
-        kind = str(rng.choice(["gauss", "gauss", "clustered", "dups", "overflow"]))
+        kind = str(rng.choice(["gauss", "gauss", "clustered", "dups", "overflow", "zeros", "scaled"]))
         mode = MODE_AUTO if rng.random() < 0.8 else MODE_EXACT
         id_base = int(rng.choice([0, 0, 5_000_000_000]))
         if n * dim > 100003 * 768 or (n >= 100000 and nq > 1000):
             nq = min(nq, 1000)
-        corpus = rows(rng, n, dim, "gauss" if kind == "overflow" else kind)
-        queries = rows(rng, nq, dim, "gauss" if kind in ("overflow", "dups") else kind)
+        corpus = rows(rng, n, dim, "gauss" if kind in ("overflow", "zeros", "scaled") else kind)
+        queries = rows(rng, nq, dim, "gauss" if kind in ("overflow", "dups", "zeros", "scaled") else kind)
+        if kind == "zeros":       # all-zero queries and rows: every score ties at 0, ids must come out row-ascending
+            queries[rng.random(nq) < 0.3] = 0.0
+            corpus[rng.random(n) < 0.2] = 0.0
+        if kind == "scaled":      # wildly different norms, negative correlations, subnormal-sized components
+            corpus *= rng.choice([1e-3, 1.0, 40.0], (n, 1)).astype(np.float32)
+            queries *= rng.choice([-7.0, 1e-2, 1.0], (nq, 1)).astype(np.float32)
+            corpus[:, : dim // 8] *= 1e-6
         if kind == "overflow":
             queries[rng.random(nq) < 0.5, rng.integers(0, dim)] = 3e5
         r = rng.random(n)
