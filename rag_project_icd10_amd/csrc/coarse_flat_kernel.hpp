@@ -38,6 +38,7 @@ struct CoarseFlatArgs {
 };
 
 constexpr int CO_BOOT_MIN_TILES = 6;   // lists at least this long bootstrap their threshold ...
+constexpr int CO_QUOTA = (CO_CAP - CO_KP) / 2 - CO_CHECK_EVERY;   // 16: appends per lane between compactions
 constexpr int CO_BOOT_TILES = 8;       // ... over their first tiles
 
 // number of lists a run of `len` tiles is cut into
@@ -278,7 +279,13 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                     st.aw += st.inc;
                 }
             }
-            if constexpr (r % CO_CHECK_EVERY == CO_CHECK_EVERY - 1) Ops::check(st, lane, smem, wave_qbase, wave_scratch, false, CO_LIMIT);
+            if constexpr (r % CO_CHECK_EVERY == CO_CHECK_EVERY - 1) {
+                // overflow guard, cheap form: each lane of a query may append CO_QUOTA entries on its side of the buffer
+                // between compactions (kept 16 + 2 x (16 + the 8 of one check interval) = 64 slots); only when some lane
+                // is past its quota does the wave run the full check (partner counts, compaction)
+                if (__builtin_amdgcn_ballot_w64(Ops::used(st, h) > CO_QUOTA) != 0ull)
+                    Ops::check(st, lane, smem, wave_qbase, wave_scratch, false, CO_LIMIT, nullptr, CO_QUOTA);
+            }
         };
 
         // prologue: stages 0..S-2 in flight, stage 0 published, its first fragments read

@@ -136,8 +136,10 @@ __host__ __device__ inline size_t fin_wave_lds_bytes(bool rescore, int dim, int 
 // DEEP: the rescoring keeps 2 x 12 row pieces in flight per lane instead of 8 - fewer dependent round trips for a
 // launch whose waves all fit on the chip at once (latency matters), more registers / fewer resident waves for a
 // large one (throughput matters: measured slower at 10 000 queries). The host picks by the query count.
-template <bool RESCORE, bool DEEP = false>
-__global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
+// EWM: rescoring candidates per lane the instantiation can hold (1 for k <= 32: the common case keeps its registers and
+// resident waves; 4 for k up to 100).
+template <bool RESCORE, bool DEEP = false, int EWM = 4>
+__global__ __launch_bounds__(256, (EWM == 1 && !DEEP) ? 7 : 1) void finalize_kernel(FinArgs a) {   // (7 waves per SIMD: <= 72 VGPRs)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nq = a.nq_ptr ? min(*a.nq_ptr, a.nq) : a.nq;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
     // RESCORE keeps the best T coarse candidates as the rescoring window; everything past T counts as dropped (it raises
     // tau below). 32 is plenty (the window holds ~12 rows) and, with many lists, lets rank_top's prefilter cut the
     // ranking loop from ~300 survivors to ~50.
-    const int T = RESCORE ? ((k > 64 && ncand >= 256) ? 256 : (k > 32 && ncand >= 128) ? 128 : ((ncand > 128 && k <= 12) ? 32 : 64)) : k;
+    const int T = RESCORE ? ((EWM >= 4 && k > 64 && ncand >= 256) ? 256 : (EWM >= 2 && k > 32 && ncand >= 128) ? 128 : ((ncand > 128 && k <= 12) ? 32 : 64)) : k;
     int rank[FIN_EF];
     float tau = -INFINITY;  // largest coarse score that may have been dropped anywhere
     if (RESCORE) {
@@ -228,8 +230,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
     if (RESCORE) {
         tau = wave_max_f32(tau);
         // 3. certification window: candidate of coarse rank lane + 64 e (one per lane for k <= 32, up to four for larger k)
-        constexpr int EWM = FIN_MAX_T / 64;
-        const int EW = T / 64 > 1 ? T / 64 : 1;
+        const int EW = T / 64 > 1 ? (T / 64 < EWM ? T / 64 : EWM) : 1;
         u64 mine[EWM];
         float coarse[EWM];
 #pragma unroll

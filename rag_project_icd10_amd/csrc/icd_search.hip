@@ -251,9 +251,9 @@ int launch_stream(icd_index *x, const float *dq, const int *qlist, const int *nq
     return ICD_OK;
 }
 
-template <bool RESCORE, bool DEEP>
+template <bool RESCORE, bool DEEP, int EWM>
 int launch_finalize_t(icd_index *x, const FinArgs &a, hipStream_t s) {
-    auto kern = finalize_kernel<RESCORE, DEEP>;
+    auto kern = finalize_kernel<RESCORE, DEEP, EWM>;
     const size_t lds = 4 * fin_wave_lds_bytes(RESCORE, x->dim, a.lds_cand > 0 ? a.lds_cand : a.P * a.KP);
     static thread_local int configured_dev = -1;
     if (configured_dev != x->device) {
@@ -270,8 +270,9 @@ template <bool RESCORE>
 int launch_finalize(icd_index *x, const FinArgs &a, hipStream_t s) {
     // one wave per query: up to ~28 waves per CU are resident, so a launch of a few thousand queries is a single
     // round of waves and its duration is one wave's latency: prefetch the rescoring rows deeper there
-    if (RESCORE && a.nq <= 8 * x->num_cu) return launch_finalize_t<RESCORE, true>(x, a, s);
-    return launch_finalize_t<RESCORE, false>(x, a, s);
+    const bool deep = RESCORE && a.nq <= 8 * x->num_cu;
+    if (!RESCORE || a.k <= 32) return deep ? launch_finalize_t<RESCORE, true, 1>(x, a, s) : launch_finalize_t<RESCORE, false, 1>(x, a, s);
+    return deep ? launch_finalize_t<RESCORE, true, 4>(x, a, s) : launch_finalize_t<RESCORE, false, 4>(x, a, s);
 }
 
 void rec(icd_index *x, int i, hipStream_t s) {

@@ -243,14 +243,16 @@ struct Sel2Ops {
     // 16-register group; a lower value at tile ends compacts early, while all waves are in step)
     __device__ static __forceinline__ void check(Sel2 &s, int lane, char *smem, uint32_t wave_qbase,
                                                  uint32_t wave_scratch, bool force, int limit = CAP - 32,
-                                                 unsigned long long *prof = nullptr) {
+                                                 unsigned long long *prof = nullptr, int quota = CAP) {
         const int h = lane >> 5;
         const int mine = used(s, h);
         // partner lane's count without touching LDS: v_permlane32_swap exchanges the two wave halves
         const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)mine, (unsigned)mine, false, false);
         const int other = (int)(h ? sw[0] : sw[1]);
         const int total = s.kept + mine + other;
-        uint32_t need = (uint32_t)__ballot(force ? (total > 0) : (total > limit));
+        // (quota: a lane that has appended more than this since the last compaction asks for one - the caller's cheap
+        //  per-lane pre-check uses the same rule, so the query that triggered the call is always compacted)
+        uint32_t need = (uint32_t)__ballot(force ? (total > 0) : (total > limit || mine > quota || other > quota));
         unsigned long long pt0 = 0;
         if (prof && need) {
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pt0)::"memory");
