@@ -15,6 +15,7 @@
 // of a query tile also writes the unused ordinals as empty.
 #pragma once
 #include "coarse_kernel.hpp"
+#include "flat_partition.hpp"
 
 namespace icd {
 
@@ -40,21 +41,6 @@ struct CoarseFlatArgs {
 constexpr int CO_BOOT_MIN_TILES = 6;   // lists at least this long bootstrap their threshold ...
 constexpr int CO_QUOTA = (CO_CAP - CO_KP) / 2 - CO_CHECK_EVERY;   // 16: appends per lane between compactions
 constexpr int CO_BOOT_TILES = 8;       // ... over their first tiles
-
-// number of lists a run of `len` tiles is cut into
-__host__ __device__ inline int flat_lists_of_run(int len, int list_tiles) { return (len + list_tiles - 1) / list_tiles; }
-
-// ordinal (within query tile m) of the first list of work-group w's run: the lists of the earlier work-groups
-__host__ __device__ inline int flat_first_ordinal(int m, int w, int ctiles, int U, int list_tiles) {
-    const long long m0 = (long long)m * ctiles, m1 = m0 + ctiles;
-    int ord = 0;
-    for (long long wp = m0 / U; wp < w; ++wp) {
-        const long long r0 = wp * U > m0 ? wp * U : m0;
-        const long long r1 = (wp + 1) * U < m1 ? (wp + 1) * U : m1;
-        if (r1 > r0) ord += flat_lists_of_run((int)(r1 - r0), list_tiles);
-    }
-    return ord;
-}
 
 // End of a list, all 32 queries of the wave at once (lane = half a query; the one-query-at-a-time compaction of
 // Sel2Ops costs ~1 400 cycles per query: 45 000 per list and wave, 7 % of a 90-tile sweep). Every lane loads the 32
@@ -176,17 +162,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     // (class 0's members, class 1's, ...) - then the ~G/T work-groups that stream the same tiles share one L2 and
     // the corpus is fetched from the Infinity Cache once per class instead of once per work-group (measured:
     // FETCH_SIZE 4.3 GB -> see profiles/). Pure placement: any bijection is correct.
-    int wg;
-    {
-        const int G = (int)gridDim.x, w = (int)blockIdx.x;
-        const int xcd = w & 7, q8 = G >> 3, r8 = G & 7;
-        const int jx = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (w >> 3);   // contiguous per XCD
-        const int T = a.pos_period, qT = T > 0 ? G / T : 0, rT = G - qT * max(T, 1);
-        if (T <= 0) wg = w;            // (A/B: identity)
-        else if (qT == 0) wg = jx;
-        else if (jx < rT * (qT + 1)) wg = jx / (qT + 1) + (jx % (qT + 1)) * T;
-        else { const int jj = jx - rT * (qT + 1); wg = rT + jj / qT + (jj % qT) * T; }
-    }
+    const int wg = flat_workgroup_of_block((int)blockIdx.x, (int)gridDim.x, a.pos_period);
     const int u_begin = wg * a.units_per_wg;
     const int u_end = min(a.total_units, u_begin + a.units_per_wg);
     if (u_begin >= u_end) return;
