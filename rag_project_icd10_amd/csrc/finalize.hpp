@@ -127,10 +127,13 @@ __device__ __forceinline__ void emit_outputs(const FinArgs &a, int qidx, const u
     }
 }
 
-// LDS per wave: keys[max(ncand, 64) rounded to 64] u64 | sorted[256] u64 | adjbuf[128] double | qvec[dim] float (RESCORE)
+// LDS per wave: keys[max(ncand, 64) rounded to 64] u64 | sorted[64 ewm] u64 | adjbuf[64 or 128] double | qvec[dim] float (RESCORE)
 __host__ __device__ inline int fin_key_slots(int ncand) { return ncand <= 64 ? 64 : ((ncand + 63) & ~63); }
-__host__ __device__ inline size_t fin_wave_lds_bytes(bool rescore, int dim, int ncand) {
-    return (size_t)fin_key_slots(ncand) * 8 + FIN_MAX_T * 8 + FIN_MAX_K * 8 + (rescore ? (size_t)dim * 4 : 0);
+// ewm = rescoring candidates per lane of the instantiation (1: k <= 32; 4: larger k and the exact path)
+__host__ __device__ inline int fin_sorted_slots(int ewm) { return 64 * ewm; }
+__host__ __device__ inline int fin_adj_slots(int ewm) { return ewm == 1 ? 64 : FIN_MAX_K; }
+__host__ __device__ inline size_t fin_wave_lds_bytes(bool rescore, int dim, int ncand, int ewm) {
+    return (size_t)fin_key_slots(ncand) * 8 + (size_t)fin_sorted_slots(ewm) * 8 + (size_t)fin_adj_slots(ewm) * 8 + (rescore ? (size_t)dim * 4 : 0);
 }
 
 // DEEP: the rescoring keeps 2 x 12 row pieces in flight per lane instead of 8 - fewer dependent round trips for a
@@ -153,11 +156,11 @@ __global__ __launch_bounds__(256, (EWM == 1 && !DEEP) ? 7 : 1) void finalize_ker
         P = a.dense_max_p > 0 ? exact_adaptive_chunks(nq, a.dense_bmq, a.dense_grid, a.dense_max_p, a.n_rows) : a.P_dense;
     const int ncand = P * a.KP;
     const int lds_cand = a.lds_cand > 0 ? a.lds_cand : ncand;
-    char *wbase = smem + (size_t)wave * fin_wave_lds_bytes(RESCORE, a.dim, lds_cand);
+    char *wbase = smem + (size_t)wave * fin_wave_lds_bytes(RESCORE, a.dim, lds_cand, EWM);
     u64 *keys = reinterpret_cast<u64 *>(wbase);
     u64 *sorted = keys + fin_key_slots(lds_cand);
-    double *adjbuf = reinterpret_cast<double *>(sorted + FIN_MAX_T);
-    float *qvec = reinterpret_cast<float *>(adjbuf + FIN_MAX_K);
+    double *adjbuf = reinterpret_cast<double *>(sorted + fin_sorted_slots(EWM));
+    float *qvec = reinterpret_cast<float *>(adjbuf + fin_adj_slots(EWM));
     // issued first, consumed last: the query (rescoring operand) and its norm / usability flag travel while the
     // candidates are merged (a wave's life is a chain of dependent round trips; these need not be part of it)
     float qn_early = 0.0f;

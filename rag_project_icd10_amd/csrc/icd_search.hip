@@ -254,11 +254,11 @@ int launch_stream(icd_index *x, const float *dq, const int *qlist, const int *nq
 template <bool RESCORE, bool DEEP, int EWM>
 int launch_finalize_t(icd_index *x, const FinArgs &a, hipStream_t s) {
     auto kern = finalize_kernel<RESCORE, DEEP, EWM>;
-    const size_t lds = 4 * fin_wave_lds_bytes(RESCORE, x->dim, a.lds_cand > 0 ? a.lds_cand : a.P * a.KP);
+    const size_t lds = 4 * fin_wave_lds_bytes(RESCORE, x->dim, a.lds_cand > 0 ? a.lds_cand : a.P * a.KP, EWM);
     static thread_local int configured_dev = -1;
     if (configured_dev != x->device) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(4 * fin_wave_lds_bytes(RESCORE, x->dim, FIN_MAX_CAND))));
+                                    (int)(4 * fin_wave_lds_bytes(RESCORE, x->dim, FIN_MAX_CAND, EWM))));
         configured_dev = x->device;
     }
     hipLaunchKernelGGL(kern, dim3((a.nq + 3) / 4), dim3(256), lds, s, a);
@@ -271,7 +271,7 @@ int launch_finalize(icd_index *x, const FinArgs &a, hipStream_t s) {
     // one wave per query: up to ~28 waves per CU are resident, so a launch of a few thousand queries is a single
     // round of waves and its duration is one wave's latency: prefetch the rescoring rows deeper there
     const bool deep = RESCORE && a.nq <= 8 * x->num_cu;
-    if (!RESCORE || a.k <= 32) return deep ? launch_finalize_t<RESCORE, true, 1>(x, a, s) : launch_finalize_t<RESCORE, false, 1>(x, a, s);
+    if (a.k <= 32) return deep ? launch_finalize_t<RESCORE, true, 1>(x, a, s) : launch_finalize_t<RESCORE, false, 1>(x, a, s);
     return deep ? launch_finalize_t<RESCORE, true, 4>(x, a, s) : launch_finalize_t<RESCORE, false, 4>(x, a, s);
 }
 
