@@ -136,6 +136,50 @@ __host__ __device__ inline size_t fin_wave_lds_bytes(bool rescore, int dim, int 
     return (size_t)fin_key_slots(ncand) * 8 + (size_t)fin_sorted_slots(ewm) * 8 + (size_t)fin_adj_slots(ewm) * 8 + (rescore ? (size_t)dim * 4 : 0);
 }
 
+// Load one query's candidates (NE per lane), rank them (rank_top) and scatter the best T, sorted, into sorted[].
+// Returns the number of valid candidates; tau picks up the score of the candidate of rank T (the best one left out).
+template <bool RESCORE, int NE>
+__device__ __forceinline__ int fin_merge(const FinArgs &a, size_t pbase, int ncand, int T, u64 *keys, u64 *sorted, int lane, float &tau) {
+    u64 key[NE];
+    int nvalid = 0;
+    {
+        int crow[NE];
+        float cscore[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {   // rows and scores as independent loads: one round trip, not two per element
+            const int i = lane + 64 * e;
+            crow[e] = -1;
+            cscore[e] = 0.0f;
+            if (i < ncand) {
+                crow[e] = a.part_rows[pbase + i];
+                cscore[e] = a.part_scores[pbase + i];
+            }
+        }
+        if (RESCORE && a.perm_mod > 0) {   // list positions of the permuted fp16 corpus -> original rows
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+                if (crow[e] >= 0) crow[e] = (int)(((long long)crow[e] * a.perm_mul) % a.perm_mod);
+        }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int i = lane + 64 * e;
+            key[e] = crow[e] >= 0 ? make_key(cscore[e], (uint32_t)crow[e]) : 0ull;
+            if (i < ncand) keys[i] = key[e];
+            nvalid += __popcll(__ballot(key[e] != 0ull));
+        }
+    }
+    int rank[NE];
+    rank_top<NE>(key, rank, ncand, T, keys, lane);   // (may replace keys[] by the survivor list)
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        if (key[e] != 0ull) {
+            if (rank[e] < T) sorted[rank[e]] = key[e];
+            else if (RESCORE && rank[e] == T) tau = fmaxf(tau, key_score(key[e]));
+        }
+    }
+    return nvalid;
+}
+
 // DEEP: the rescoring keeps 2 x 12 row pieces in flight per lane instead of 8 - fewer dependent round trips for a
 // launch whose waves all fit on the chip at once (latency matters), more registers / fewer resident waves for a
 // large one (throughput matters: measured slower at 10 000 queries). The host picks by the query count.
@@ -176,41 +220,13 @@ __global__ __launch_bounds__(256, (EWM == 1 && !DEEP) ? 7 : 1) void finalize_ker
     const int k = a.k;
     const size_t pbase = (size_t)slot * ncand;
 
-    // 1. load candidates (rows and scores as independent loads: one round trip, not two per element), stage keys
-    u64 key[FIN_EF];
-    int nvalid = 0;
-    {
-        int crow[FIN_EF];
-        float cscore[FIN_EF];
-#pragma unroll
-        for (int e = 0; e < FIN_EF; ++e) {
-            const int i = lane + 64 * e;
-            crow[e] = -1;
-            cscore[e] = 0.0f;
-            if (i < ncand) {
-                crow[e] = a.part_rows[pbase + i];
-                cscore[e] = a.part_scores[pbase + i];
-            }
-        }
-        if (RESCORE && a.perm_mod > 0) {
-#pragma unroll
-            for (int e = 0; e < FIN_EF; ++e)
-                if (crow[e] >= 0) crow[e] = (int)(((long long)crow[e] * a.perm_mul) % a.perm_mod);
-        }
-#pragma unroll
-        for (int e = 0; e < FIN_EF; ++e) {
-            const int i = lane + 64 * e;
-            key[e] = crow[e] >= 0 ? make_key(cscore[e], (uint32_t)crow[e]) : 0ull;
-            if (i < ncand) keys[i] = key[e];
-            nvalid += __popcll(__ballot(key[e] != 0ull));
-        }
-    }
-    // 2. rank all candidates; keep the best T sorted
+    // 1-2. load the candidates, rank them, keep the best T sorted. Instantiated per candidates-per-lane (2 covers the
+    // common P * KP <= 128; the loops of an 8-per-lane instance would run six dead elements through ~12 VALU per
+    // candidate: the kernel is VALU-issue bound, 4 000 VALU per wave)
     // RESCORE keeps the best T coarse candidates as the rescoring window; everything past T counts as dropped (it raises
-    // tau below). 32 is plenty (the window holds ~12 rows) and, with many lists, lets rank_top's prefilter cut the
+    // tau). 32 is plenty at k <= 12 (the window holds ~12 rows) and, with many lists, lets rank_top's prefilter cut the
     // ranking loop from ~300 survivors to ~50.
     const int T = RESCORE ? ((EWM >= 4 && k > 64 && ncand >= 256) ? 256 : (EWM >= 2 && k > 32 && ncand >= 128) ? 128 : ((ncand > 128 && k <= 12) ? 32 : 64)) : k;
-    int rank[FIN_EF];
     float tau = -INFINITY;  // largest coarse score that may have been dropped anywhere
     if (RESCORE) {
         // every list comes with the threshold it ended on: nothing it dropped scores above that. The lists
@@ -220,14 +236,9 @@ __global__ __launch_bounds__(256, (EWM == 1 && !DEEP) ? 7 : 1) void finalize_ker
             if (bd > -INFINITY) tau = bd + fabsf(bd) * COARSE_KEY_SLACK;
         }
     }
-    rank_top<FIN_EF>(key, rank, ncand, T, keys, lane);   // (may replace keys[] by the survivor list)
-#pragma unroll
-    for (int e = 0; e < FIN_EF; ++e) {
-        if (key[e] != 0ull) {
-            if (rank[e] < T) sorted[rank[e]] = key[e];
-            else if (RESCORE && rank[e] == T) tau = fmaxf(tau, key_score(key[e]));
-        }
-    }
+    int nvalid;
+    if (ncand <= 128) nvalid = fin_merge<RESCORE, 2>(a, pbase, ncand, T, keys, sorted, lane, tau);
+    else nvalid = fin_merge<RESCORE, FIN_EF>(a, pbase, ncand, T, keys, sorted, lane, tau);
     int nres = min(nvalid, T);
 
     if (RESCORE) {
