@@ -24,6 +24,7 @@ struct FinArgs {
     const float *bounds;       // fast path: [slot][P] largest score each list may have dropped (-inf: none)
     long long perm_mul;        // fast path: list rows are positions of the permuted fp16 corpus; original row =
     int perm_mod;              //            (position * perm_mul) mod perm_mod (perm_mod = 0: identity)
+    double perm_inv;           //            1 / perm_mod when perm_mod^2 < 2^53 (the modulo then runs in f64), else 0
     int P, KP;
     int P_dense;        // with nq_ptr: lists per slot when more than sparse_max slots are active (0: always P)
     int sparse_max;
@@ -136,6 +137,20 @@ __host__ __device__ inline size_t fin_wave_lds_bytes(bool rescore, int dim, int 
     return (size_t)fin_key_slots(ncand) * 8 + (size_t)fin_sorted_slots(ewm) * 8 + (size_t)fin_adj_slots(ewm) * 8 + (rescore ? (size_t)dim * 4 : 0);
 }
 
+// (p * mul) mod n. A 64-bit integer modulo is ~150 VALU instructions on this machine and the kernel is VALU-issue
+// bound; with n^2 < 2^53 the product, the quotient estimate and the remainder are exact in f64 (6 instructions).
+__device__ __forceinline__ int perm_row(int p, long long mul, int n, double inv) {
+    if (inv > 0.0) {
+        const double x = (double)p * (double)mul;          // < n^2 < 2^53: exact
+        double q = floor(x * inv);                         // within 1 of the true quotient
+        double r = __builtin_fma(-q, (double)n, x);        // exact
+        if (r < 0.0) r += (double)n;
+        if (r >= (double)n) r -= (double)n;
+        return (int)r;
+    }
+    return (int)(((long long)p * mul) % n);
+}
+
 // Load one query's candidates (NE per lane), rank them (rank_top) and scatter the best T, sorted, into sorted[].
 // Returns the number of valid candidates; tau picks up the score of the candidate of rank T (the best one left out).
 template <bool RESCORE, int NE>
@@ -158,7 +173,7 @@ __device__ __forceinline__ int fin_merge(const FinArgs &a, size_t pbase, int nca
         if (RESCORE && a.perm_mod > 0) {   // list positions of the permuted fp16 corpus -> original rows
 #pragma unroll
             for (int e = 0; e < NE; ++e)
-                if (crow[e] >= 0) crow[e] = (int)(((long long)crow[e] * a.perm_mul) % a.perm_mod);
+                if (crow[e] >= 0) crow[e] = perm_row(crow[e], a.perm_mul, a.perm_mod, a.perm_inv);
         }
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
@@ -345,10 +360,20 @@ __global__ __launch_bounds__(256, (EWM == 1 && !DEEP) ? 7 : 1) void finalize_ker
         int xr[EWM];
 #pragma unroll
         for (int e = 0; e < EWM; ++e) xr[e] = 0;
-        for (int j = 0; j < 64 * EW; ++j) {
-            const u64 kj = keys[j];
+        if constexpr (EWM == 1) {
+            // only the window lanes hold a rescored key: visit those (about a dozen), not all 64 slots
+            u64 live = __ballot(xkey[0] != 0ull);
+            while (live) {
+                const int j = __ffsll((long long)live) - 1;
+                live &= live - 1;
+                xr[0] += (readlane_u64(xkey[0], j) > xkey[0]) ? 1 : 0;
+            }
+        } else {
+            for (int j = 0; j < 64 * EW; ++j) {
+                const u64 kj = keys[j];
 #pragma unroll
-            for (int e = 0; e < EWM; ++e) xr[e] += (kj > xkey[e]) ? 1 : 0;
+                for (int e = 0; e < EWM; ++e) xr[e] += (kj > xkey[e]) ? 1 : 0;
+            }
         }
         int nx = 0;
 #pragma unroll

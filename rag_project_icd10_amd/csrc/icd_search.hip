@@ -534,6 +534,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         FinArgs g = f;
         g.part_scores = x->partc_s; g.part_rows = x->partc_r; g.bounds = x->partc_b; g.P = pc; g.KP = CO_KP; g.nq = nq;
         g.perm_mul = x->perm_mul; g.perm_mod = x->perm_mod;
+        g.perm_inv = (x->perm_mod > 0 && (double)x->perm_mod * (double)x->perm_mod < 9007199254740992.0) ? 1.0 / (double)x->perm_mod : 0.0;
         int rc = launch_finalize<true>(x, g, s);
         if (rc) return rc;
     }
