@@ -5,8 +5,8 @@ from conftest import icd_levels, unit_rows
 from rag_project_icd10_amd._native import IcdIndex, MODE_AUTO
 corpus, levels = unit_rows(40474, 768, 1234), icd_levels(40474, 1235)
 q = unit_rows(10000, 768, 4321)
-idx = IcdIndex(corpus, levels, max_nq=10000, max_k=100)
-for nq, k in ((1000, 100), (10000, 100), (10000, 80), (10000, 64), (10000, 10), (1, 100), (100, 100)):
+idx = IcdIndex(corpus, levels, max_nq=10000, max_k=128)
+for nq, k in ((10000, 10), (10000, 20), (10000, 32), (10000, 48), (10000, 64), (10000, 100), (1000, 20), (1000, 100), (16, 20), (1, 100), (1000, 128)):
     dq = torch.from_numpy(q[:nq]).cuda()
     for _ in range(3): idx.search_reweighted(dq, k, MODE_AUTO)
     torch.cuda.synchronize(); t0 = time.perf_counter()

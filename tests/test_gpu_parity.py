@@ -94,7 +94,7 @@ def test_heavy_duplicates_through_the_coarse_path(oracle):
 
 @pytest.mark.parametrize("n,nq,dim,k,mode", [
     (3000, 1, 1024, 10, MODE_AUTO), (3000, 3, 1024, 64, MODE_EXACT), (2500, 2, 96, 7, MODE_AUTO),
-    (9000, 40, 768, 10, MODE_EXACT), (9000, 64, 768, 100, MODE_EXACT), (700, 16, 768, 128, MODE_AUTO),
+    (9000, 40, 768, 10, MODE_EXACT), (9000, 64, 768, 100, MODE_EXACT), (700, 16, 768, 128, MODE_EXACT),
     (257, 7, 2048, 10, MODE_EXACT),
 ])
 def test_streaming_kernel_variants(oracle, n, nq, dim, k, mode):
@@ -191,13 +191,13 @@ def test_one_index_many_call_shapes(oracle):
 
 @pytest.mark.parametrize("k", [13, 20, 32, 48, 64, 100])
 def test_larger_k_on_the_fast_path(oracle, k):
-    """/query searches top_k * 2 (F7): k up to 100 stays on the certified fp16 path (about k / 4 lists per query, one to
+    """/query searches top_k * 2 (F7): k up to 100 (everything /query can ask for) stays on the certified fp16 path (about k / 4 lists per query, one to
     four rescoring candidates per lane); larger k takes the exact kernel"""
     corpus, levels, queries = unit_rows(20000, 768, 120), icd_levels(20000, 121), unit_rows(700, 768, 122)
     idx = IcdIndex(corpus, levels, max_nq=700, max_k=128)
     st = _check(oracle, idx, corpus, levels, queries, k, MODE_AUTO)
     assert st["last_mode"] == MODE_AUTO and st["last_fallback"] <= 70
-    st = _check(oracle, idx, corpus, levels, queries, 101, MODE_AUTO)
+    st = _check(oracle, idx, corpus, levels, queries, 101, MODE_AUTO)   # beyond: 32 lists of 16 cannot certify, exact kernels
     assert st["last_mode"] == MODE_EXACT
     idx.close()
 
