@@ -1,0 +1,106 @@
+// coarse_common.hpp — geometry, helpers and the fp32 -> fp16 conversion kernel of the fp16 MFMA coarse pass
+// (v_mfma_f32_32x32x16_f16 with a fused per-query top-KP; the kernel itself is coarse_flat_kernel.hpp).
+//
+// The dominant kernel of the hot path: replaces the FLAT/IP scan behind MilvusClient.search
+// (services/milvus_service.py:280-285) for query batches. Its output is a candidate list per
+// (query, corpus chunk); finalize.hpp certifies and rescoring restores exact fp32 results.
+//
+// Geometry
+//   work-group  = 4 waves, one per SIMD, 128 queries (32 per wave, one query column per lane pair)
+//   queries     = B operand, held in registers for the whole sweep (D/16 fragments of 8 halves)
+//   corpus rows = A operand, 128-row tiles streamed through an LDS ring by LDS-DMA:
+//                 stage = 128 rows x 64 halves (16 KiB), 4 ring slots, 16 one-KiB pieces per stage
+//                 (4 per wave), each piece = 8 rows x one full 128-B line
+//   swizzle     = LDS slot (row, p) holds 16-B piece p ^ ((row>>1)&7) of the row's 128-B segment:
+//                 applied on the DMA SOURCE address and on the ds_read_b128 address (the LDS
+//                 destination of an LDS-DMA is lane-linear); A-fragment reads are conflict-free.
+#pragma once
+#include <type_traits>
+
+#include "topk_select.hpp"
+
+namespace icd {
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E) — keeps every accumulator
+// index a constant so the arrays stay in registers
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+#ifndef ICD_CO_KP
+#define ICD_CO_KP 16
+#endif
+constexpr int CO_KP = ICD_CO_KP;   // candidates kept per (query, list)
+constexpr int CO_BM = 128;
+constexpr int CO_BN = 128;
+constexpr int CO_BK = 64;
+constexpr int CO_S = 4;
+constexpr int CO_STAGE_BYTES = CO_BN * CO_BK * 2;  // 16384
+constexpr int CO_RING_BYTES = CO_S * CO_STAGE_BYTES;
+constexpr int CO_CAP = 64;
+constexpr int CO_CHECK_EVERY = 8;                       // registers between overflow checks (2 lanes append per register)
+constexpr int CO_LIMIT = CO_CAP - 2 * CO_CHECK_EVERY;    // compact a query once it holds more entries than this
+constexpr int CO_LDS_BYTES = CO_RING_BYTES + CO_BM * CO_CAP * 8 + 4 * 256;
+
+// ---- fp32 -> fp16 images ---------------------------------------------------------------------------
+// One wave per row: converts with round-to-nearest-even, accumulates the row's squared norm in fp32,
+// flags rows whose fp16 image is unusable (non-finite input or |x| > 65504).
+struct ConvertArgs {
+    const float *src;        // [rows][dim]
+    _Float16 *dst;           // [rows_pad][dim]
+    int rows, rows_pad, dim;
+    float *norm;             // nullable [rows]: L2 norm rounded up
+    unsigned char *bad;      // nullable [rows]
+    unsigned int *rmax_bits; // nullable: atomicMax of norm bits (norm >= 0)
+    unsigned int *any_bad;   // nullable: set to 1 if any row is bad
+    unsigned int *zero_u32;  // nullable [rows_pad]: cleared (the coarse pass's shared per-query thresholds)
+    long long perm_mul;      // with perm_mod > 0: dst row p holds src row (p * perm_mul) mod perm_mod (an affine permutation)
+    int perm_mod;
+};
+
+__global__ __launch_bounds__(256) void convert_rows_kernel(ConvertArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= a.rows_pad) return;
+    if (a.zero_u32 && lane == 0) a.zero_u32[row] = 0u;
+    _Float16 *d = a.dst + (size_t)row * a.dim;
+    if (row >= a.rows) {
+        for (int i = lane * 4; i < a.dim; i += 256) {
+            d[i] = (_Float16)0.0f; d[i + 1] = (_Float16)0.0f; d[i + 2] = (_Float16)0.0f; d[i + 3] = (_Float16)0.0f;
+        }
+        return;
+    }
+    const int srow = a.perm_mod > 0 ? (int)(((long long)row * a.perm_mul) % a.perm_mod) : row;
+    const float *s = a.src + (size_t)srow * a.dim;
+    float ss = 0.0f;
+    bool bad = false;
+    for (int i = lane * 4; i < a.dim; i += 256) {
+        const float4 v = *reinterpret_cast<const float4 *>(s + i);
+        const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bad |= !(fabsf(f[j]) <= 65504.0f);
+            ss = __builtin_fmaf(f[j], f[j], ss);
+            d[i + j] = (_Float16)f[j];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+    const bool anybad = __any(bad);
+    if (lane == 0) {
+        float nrm = sqrtf(ss) * 1.000001f;  // round up: it multiplies an error bound
+        if (!(nrm == nrm)) nrm = INFINITY;
+        if (a.norm) a.norm[row] = nrm;
+        if (a.bad) a.bad[row] = anybad ? 1 : 0;
+        if (a.rmax_bits) atomicMax(a.rmax_bits, __float_as_uint(nrm));
+        if (a.any_bad && anybad) atomicOr(a.any_bad, 1u);
+    }
+}
+
+}  // namespace icd

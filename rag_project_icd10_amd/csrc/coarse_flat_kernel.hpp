@@ -1,5 +1,5 @@
-// coarse_flat_kernel.hpp — the product form of the fp16-MFMA coarse pass: coarse_kernel.hpp's
-// software-pipelined stage (VAR 512) over a FLAT partition of the (query tile x corpus tile) grid.
+// coarse_flat_kernel.hpp — the product form of the fp16-MFMA coarse pass: a software-pipelined
+// stage over a FLAT partition of the (query tile x corpus tile) grid.
 //
 // Replaces the scoring + k-selection inside MilvusClient.search on the FLAT/IP index
 // (services/milvus_service.py:280-285) for batches; exactness is restored by finalize.hpp.
@@ -14,7 +14,7 @@
 // dropped nothing). Ordinals count the lists of a query tile in row order; the work-group that reaches the end
 // of a query tile also writes the unused ordinals as empty.
 #pragma once
-#include "coarse_kernel.hpp"
+#include "coarse_common.hpp"
 #include "flat_partition.hpp"
 
 namespace icd {
@@ -36,6 +36,7 @@ struct CoarseFlatArgs {
     int *part_rows;
     float *bounds;           // [nq][P]
     unsigned int *shared_thr; // [nq_pad] order_f32 keys, cleared before the launch: max over a query's lists of their thresholds
+    unsigned long long *dbg;  // diagnostic builds only (VAR & 1024): [block][wave][8] cycle sums
 };
 
 constexpr int CO_BOOT_MIN_TILES = 6;   // lists at least this long bootstrap their threshold ...
@@ -145,11 +146,35 @@ __device__ __forceinline__ float flush_emit_parallel(const char *smem, uint32_t 
     return bound;
 }
 
-template <int D>
+// VAR: bit flags of the stage variants (A/B builds instantiate several, `make ABLATE=1`; the product one is CF_PRODUCT_VAR)
+//   1    shared-threshold load issued two stages before the tile end (asm, counted wait) instead of a drained load after it
+//   2    LDS-DMA pieces one behind each of the four MFMAs that follow the barrier instead of a burst in front of them
+//   8    query fragments pinned to accumulator registers
+//   32   ring of 3 stages, 64 ring of 6 stages (TIMING ONLY: the compaction scratch aliases the ring)
+//   128  A fragments read two k-steps ahead of their MFMAs instead of one
+//   256  TIMING ONLY: no s_barrier        512  TIMING ONLY: no wait for the LDS-DMA pieces
+//   1024 diagnostic: s_memtime stamps around the mid-stage wait, the barrier and the select (CoarseFlatArgs::dbg)
+constexpr int CF_PRODUCT_VAR = 0;
+__host__ __device__ constexpr int cf_ring_stages(int var) { return (var & 32) ? 3 : ((var & 64) ? 6 : CO_S); }
+__host__ __device__ constexpr int cf_lds_bytes(int var) {
+    return cf_ring_stages(var) * CO_STAGE_BYTES + CO_BM * CO_CAP * 8 + ((var & 64) ? 0 : 4 * 256);
+}
+#define ICD_CF_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); \
+    __builtin_amdgcn_sched_barrier(0); } while (0)
+
+template <int D, int VAR = CF_PRODUCT_VAR>
 __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
+    constexpr bool EARLY_THR = (VAR & 1) != 0;
+    constexpr bool DMA_SPREAD = (VAR & 2) != 0;
+    constexpr bool Q_AGPR = (VAR & 8) != 0;
+    constexpr bool PF2 = (VAR & 128) != 0;
+    constexpr bool NOBAR = (VAR & 256) != 0, NOVM = (VAR & 512) != 0, STAMPS = (VAR & 1024) != 0;
+    constexpr int S = cf_ring_stages(VAR);            // ring slots
+    constexpr int VM_MID = NOVM ? 63 : 4 * (S - 3);   // LDS-DMA pieces that may stay in flight at the mid-stage wait
     constexpr int KS = D / CO_BK;      // stages per tile
     constexpr int NF = D / 16;         // query fragments per lane
-    static_assert(KS % CO_S == 0, "ring slot must be a compile-time function of the stage");
+    static_assert(KS % S == 0, "ring slot must be a compile-time function of the stage");
     using Ops = Sel2Ops<CO_KP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -187,8 +212,10 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) f[t] = *reinterpret_cast<const half8 *>(sb + t * 4096);
     };
-    const uint32_t wave_qbase = (uint32_t)CO_RING_BYTES + (uint32_t)(wave * 32) * Ops::QBYTES;
-    const uint32_t wave_scratch = (uint32_t)CO_RING_BYTES + (uint32_t)CO_BM * Ops::QBYTES + (uint32_t)wave * 256u;
+    constexpr uint32_t RING_BYTES = (uint32_t)S * CO_STAGE_BYTES;
+    const uint32_t wave_qbase = RING_BYTES + (uint32_t)(wave * 32) * Ops::QBYTES;
+    const uint32_t wave_scratch = ((VAR & 64) ? 0u : RING_BYTES + (uint32_t)CO_BM * Ops::QBYTES) + (uint32_t)wave * 256u;
+    unsigned long long st_vm = 0, st_bar = 0, st_body = 0, st_sel = 0, st_tiles = 0, st_prev = 0;   // (STAMPS)
     const int last_tile = a.ctiles - 1;
 
     half8 qf[NF];
@@ -210,6 +237,10 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             const _Float16 *qrow = a.q16 + (size_t)(slot0 + wave * 32 + c) * D + 8 * h;
 #pragma unroll
             for (int s = 0; s < NF; ++s) qf[s] = *reinterpret_cast<const half8 *>(qrow + 16 * s);
+            if constexpr (Q_AGPR) {
+#pragma unroll
+                for (int s = 0; s < NF; ++s) asm volatile("" : "+a"(qf[s]));
+            }
             cur_mtile = mtile;
         }
         // buffer_load ... lds: per-lane part in voffset, tile/stage part in a scalar soffset, base = the list's first row
@@ -267,12 +298,15 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
         // prologue: stages 0..S-2 in flight, stage 0 published, its first fragments read
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (query fragment loads: the vmcnt accounting starts from zero)
 #pragma unroll
-        for (int p = 0; p < CO_S - 1; ++p) issue_stage(p / KS, p % KS, p % CO_S);
-        half8 afn[4];
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int p = 0; p < S - 1; ++p) issue_stage(p / KS, p % KS, p % S);
+        half8 afn[4], bfn[4];
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(4 * (S - 2)) : "memory");
         read_frags(afn, 0, 0);
+        if constexpr (PF2) read_frags(bfn, 0, 1);
+        if constexpr (STAMPS) ICD_CF_STAMP(st_prev);
 
         for (int tile = 0; tile < ntiles; ++tile) {
+            uint32_t seen_early = 0u;
             f32x16 acc[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -280,48 +314,99 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
             static_for<0, KS>([&](auto KSI) {
                 constexpr int ks = decltype(KSI)::value;
-                constexpr int slot = ks % CO_S;
+                constexpr int slot = ks % S, nslot = (ks + 1) % S;
                 auto mfma4 = [&](const half8 (&f)[4], int qi) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[t], qf[qi], acc[t], 0, 0, 0);
                 };
-                // stage g = (tile, ks) was published by the previous mid-stage barrier; afn holds its k-step 0
+                // stage g = (tile, ks) was published by the previous mid-stage barrier; afn holds its k-step 0 (PF2: bfn its k-step 1)
                 half8 f1[4], f2[4], f3[4];
-                read_frags(f1, slot, 1);
-                mfma4(afn, ks * 4 + 0);
-                read_frags(f2, slot, 2);
-                mfma4(f1, ks * 4 + 1);
-                // pin: reads of k-step s+1 go out before the MFMAs of k-step s
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                // publish stage g+1: this wave's pieces of g+1 have landed when only g+2 is outstanding
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                {   // every wave is past stage g-1: its slot takes stage g+3
-                    constexpr int nks = ks + CO_S - 1;
-                    issue_stage(tile + (nks >= KS ? 1 : 0), nks % KS, nks % CO_S);
+                if constexpr (PF2) {
+                    read_frags(f2, slot, 2);
+                    mfma4(afn, ks * 4 + 0);
+                    read_frags(f3, slot, 3);
+                    mfma4(bfn, ks * 4 + 1);
+                } else {
+                    read_frags(f1, slot, 1);
+                    mfma4(afn, ks * 4 + 0);
+                    read_frags(f2, slot, 2);
+                    mfma4(f1, ks * 4 + 1);
                 }
-                read_frags(f3, slot, 3);
-                mfma4(f2, ks * 4 + 2);
-                read_frags(afn, (ks + 1) % CO_S, 0);
-                mfma4(f3, ks * 4 + 3);
-                __builtin_amdgcn_sched_group_barrier(0x020, 4, 1);
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+                // pin: the reads go out before the MFMAs of the k-step in front of them
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                // publish stage g+1: this wave's pieces of g+1 have landed when only the stages behind it are outstanding
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (STAMPS) {
+                    unsigned long long ta, tb, tc;
+                    ICD_CF_STAMP(ta);
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(VM_MID) : "memory");
+                    ICD_CF_STAMP(tb);
+                    if constexpr (!NOBAR) asm volatile("s_barrier" ::: "memory");
+                    ICD_CF_STAMP(tc);
+                    st_body += ta - st_prev; st_vm += tb - ta; st_bar += tc - tb; st_prev = tc;
+                } else if constexpr (NOBAR) {
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(VM_MID) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(VM_MID) : "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (EARLY_THR && ks == KS - 2) {
+                    // the query's shared threshold for the end of this tile: issued here, older than this stage's and the
+                    // next stage's LDS-DMA pieces, so a counted wait at the tile end covers it without draining them
+                    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(seen_early) : "v"(my_shared) : "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                {   // every wave is past stage g-1: its slot takes stage g+S-1
+                    constexpr int nks = ks + S - 1;
+                    issue_stage(tile + nks / KS, nks % KS, nks % S);
+                }
+                if constexpr (PF2) {
+                    read_frags(afn, nslot, 0);
+                    mfma4(f2, ks * 4 + 2);
+                    read_frags(bfn, nslot, 1);
+                    mfma4(f3, ks * 4 + 3);
+                } else {
+                    read_frags(f3, slot, 3);
+                    mfma4(f2, ks * 4 + 2);
+                    read_frags(afn, nslot, 0);
+                    mfma4(f3, ks * 4 + 3);
+                }
+                if constexpr (!DMA_SPREAD) {          // the four pieces in a burst behind the barrier
+                    __builtin_amdgcn_sched_group_barrier(0x020, 4, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+                } else {                               // one piece behind each of the next four MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             });
+            unsigned long long ts0 = 0;
+            if constexpr (STAMPS) ICD_CF_STAMP(ts0);
             // Threshold sharing between the lists of a query (they are swept by different work-groups at the same
             // time): adopt the largest threshold any of them has published, publish this list's when it is larger.
             // A list still reports the threshold it ends on as its bound, and the largest bound over the lists - what
             // finalize certifies against - is the largest of the lists' OWN k'-th best scores with or without sharing;
             // the weaker lists just stop collecting rows that could never matter. Stale reads are harmless.
             {
-                const uint32_t seen = __hip_atomic_load(my_shared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t seen;
+                if constexpr (EARLY_THR) {
+                    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(seen_early) : "i"(NOVM ? 0 : 4 * (S - 2)) : "memory");
+                    seen = seen_early;
+                } else {
+                    seen = __hip_atomic_load(my_shared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 const uint32_t mine_key = order_f32(st.thr);
                 if (seen > mine_key) st.thr = unorder_f32(seen);
                 else if (h == 0 && publish && mine_key > seen && mine_key > published) {
@@ -360,9 +445,15 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             }
             if (tile_row0 + CO_BN > a.n) static_for<0, 64>([&](auto F) { filter_reg(acc, F, rowbase, std::true_type{}); });
             else static_for<0, 64>([&](auto F) { filter_reg(acc, F, rowbase, std::false_type{}); });
+            if constexpr (STAMPS) {
+                unsigned long long ts1;
+                ICD_CF_STAMP(ts1);
+                st_sel += ts1 - ts0; st_prev += ts1 - ts0; st_tiles += 1;
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead stages
         asm volatile("" ::"v"(afn[0]), "v"(afn[1]), "v"(afn[2]), "v"(afn[3]));
+        if constexpr (PF2) asm volatile("" ::"v"(bfn[0]), "v"(bfn[1]), "v"(bfn[2]), "v"(bfn[3]));
 
         // ---- end of the list: every query's top-KP entries (unsorted) and its bound go to global memory ----------
         {
@@ -388,6 +479,12 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
         }
         __syncthreads();   // every wave is done with the ring and its buffers before the next list's prologue
         u += ntiles;
+    }
+    if constexpr (STAMPS) {
+        if (lane == 0 && a.dbg) {
+            unsigned long long *d = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
+            d[0] = st_vm; d[1] = st_bar; d[2] = st_body; d[3] = st_sel; d[4] = st_tiles;
+        }
     }
 }
 

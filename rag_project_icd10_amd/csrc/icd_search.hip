@@ -12,11 +12,7 @@
 #include <string>
 
 #include "../../include/icd_search.h"
-#ifdef ICD_ABLATE
-#include "coarse8_kernel.hpp"   // 8-wave K-split experiment (slower; A/B builds only)
-#endif
 #include "coarse_flat_kernel.hpp"
-#include "coarse_kernel.hpp"
 #include "exact_kernel.hpp"
 #include "finalize.hpp"
 #include "stream_kernel.hpp"
@@ -160,47 +156,19 @@ int launch_exact(icd_index *x, const ExactArgs &a, int mtiles, hipStream_t s) {
     return ICD_OK;
 }
 
-template <int D>
+template <int D, int VAR = CF_PRODUCT_VAR>
 int launch_coarse_flat(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream_t s) {
-    auto kern = coarse_flat_kernel<D>;
+    auto kern = coarse_flat_kernel<D, VAR>;
+    constexpr int lds = cf_lds_bytes(VAR);
     static thread_local int configured_dev = -1;
     if (configured_dev != x->device) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CO_LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         configured_dev = x->device;
     }
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), CO_LDS_BYTES, s, a);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, s, a);
     HIP_TRY(hipGetLastError());
     return ICD_OK;
 }
-
-#ifdef ICD_ABLATE
-template <int D, int VAR>
-int launch_coarse(icd_index *x, const CoarseArgs &a, int mtiles, hipStream_t s) {
-    auto kern = coarse_topk_kernel<D, VAR>;
-    static thread_local int configured_dev = -1;
-    if (configured_dev != x->device) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CO_LDS_BYTES));
-        configured_dev = x->device;
-    }
-    hipLaunchKernelGGL(kern, dim3(mtiles * a.P), dim3(256), CO_LDS_BYTES, s, a);
-    HIP_TRY(hipGetLastError());
-    return ICD_OK;
-}
-
-template <int D, int VAR>
-int launch_coarse8(icd_index *x, const CoarseArgs &a, int mtiles, hipStream_t s) {
-    auto kern = coarse8_topk_kernel<D, VAR>;
-    static thread_local int configured_dev = -1;
-    if (configured_dev != x->device) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C8_LDS_BYTES));
-        configured_dev = x->device;
-    }
-    hipLaunchKernelGGL(kern, dim3(mtiles * a.P), dim3(512), C8_LDS_BYTES, s, a);
-    HIP_TRY(hipGetLastError());
-    return ICD_OK;
-}
-
-#endif
 
 // streaming exact kernel + list reduction for a sparse query set (device-side gated when nq_ptr is given)
 // streaming exact kernel + list reduction for a sparse query set (device-side gated when nq_ptr is given).
@@ -423,12 +391,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     const int mtc = nq_pad / 128;
     const int ctiles = x->n_pad / 128;
     int pc = 0;
-#ifdef ICD_ABLATE
-    const char *var_env = getenv("ICD_COARSE_VAR");
-#else
-    const char *var_env = nullptr;
-#endif
-    if (!var_env) {
+    {
         // ---- product: flat partition of the (query tile x corpus tile) grid over the CUs (coarse_flat_kernel.hpp) ----
         CoarseFlatArgs a{};
         a.q16 = x->q16; a.c16 = x->c16; a.nq = nq; a.n = (int)x->n; a.n_pad = x->n_pad; a.ctiles = ctiles;
@@ -489,46 +452,26 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             if (a.pos_period > 0 && a.pos_period < (1 << 20)) a.pos_period *= std::max(1, split);
         }
         a.part_scores = x->partc_s; a.part_rows = x->partc_r; a.bounds = x->partc_b; a.shared_thr = x->shared_thr;
+        a.dbg = x->dbg;
         pc = P;
         x->last_chunks = P;
         const int nwg = (a.total_units + U - 1) / U;
         int rc;
         if (x->dim == 1024) rc = launch_coarse_flat<1024>(x, a, nwg, s);
+#ifdef ICD_ABLATE
+        else if (const char *fv = getenv("ICD_FLAT_VAR")) {   // A/B builds: stage / select variants of the flat kernel
+            const int v = atoi(fv);
+            if (false) {}
+#define ICD_FV_CASE(V) else if (v == V) rc = launch_coarse_flat<768, V>(x, a, nwg, s);
+            ICD_FV_CASE(0) ICD_FV_CASE(11) ICD_FV_CASE(11 + 32) ICD_FV_CASE(11 + 64) ICD_FV_CASE(11 + 128) ICD_FV_CASE(11 + 64 + 128)
+            ICD_FV_CASE(11 + 256) ICD_FV_CASE(11 + 512) ICD_FV_CASE(11 + 256 + 512) ICD_FV_CASE(11 + 1024) ICD_FV_CASE(11 + 64 + 1024)
+#undef ICD_FV_CASE
+            else return fail(ICD_ERR_INVALID, "ICD_FLAT_VAR=%d is not built", v);
+        }
+#endif
         else rc = launch_coarse_flat<768>(x, a, nwg, s);
         if (rc) return rc;
     }
-#ifdef ICD_ABLATE
-    else {
-        // A/B variants and timing ablations of coarse_kernel.hpp on the older (query tile, chunk) grid
-        pc = x->chunks_override > 0 ? x->chunks_override : std::max(2, pick_chunks(mtc, ctiles, COARSE_MAX_P, x->num_cu));
-        pc = std::min(pc, std::min(COARSE_MAX_P, ctiles));
-        pc = fit_p(pc, x->partc_cap, CO_KP);
-        const int tiles_per = (ctiles + pc - 1) / pc;
-        pc = (ctiles + tiles_per - 1) / tiles_per;
-        CoarseArgs a{};
-        a.q16 = x->q16; a.c16 = x->c16; a.nq = nq; a.n = (int)x->n; a.n_pad = x->n_pad; a.P = pc;
-        a.rows_per_chunk = tiles_per * 128;
-        a.part_scores = x->partc_s; a.part_rows = x->partc_r;
-        x->last_chunks = pc;
-        a.dbg = x->dbg;
-        const int var = atoi(var_env);
-        int rc;
-        if (false) {}
-        else if (var == 10000) rc = launch_coarse8<768, 0>(x, a, mtc, s);
-        else if (var == 10001) rc = launch_coarse8<768, 1>(x, a, mtc, s);
-#define ICD_VAR_CASE(V) else if (var == V) rc = launch_coarse<768, V>(x, a, mtc, s);
-        ICD_VAR_CASE(0) ICD_VAR_CASE(1) ICD_VAR_CASE(8) ICD_VAR_CASE(129) ICD_VAR_CASE(512) ICD_VAR_CASE(513)
-        ICD_VAR_CASE(520) ICD_VAR_CASE(528) ICD_VAR_CASE(576) ICD_VAR_CASE(584) ICD_VAR_CASE(6144) ICD_VAR_CASE(2048)
-        ICD_VAR_CASE(641) ICD_VAR_CASE(8833) ICD_VAR_CASE(17025) ICD_VAR_CASE(25217)
-#undef ICD_VAR_CASE
-        else return fail(ICD_ERR_INVALID, "ICD_COARSE_VAR=%d is not built", var);
-        if (rc) return rc;
-        // these kernels leave sorted lists: a full list's last entry bounds what it dropped
-        hipLaunchKernelGGL(bounds_from_sorted_lists_kernel, dim3((nq * pc + 255) / 256), dim3(256), 0, s,
-                           x->partc_s, x->partc_r, x->partc_b, nq * pc, CO_KP);
-        HIP_TRY(hipGetLastError());
-    }
-#endif
     rec(x, 2, s);
     {
         FinArgs g = f;
