@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Headline benchmark: batch exact top-k search over the ICD corpus on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload replicated|rowshard]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]), per GPU:
+Workload `replicated` (default; BASELINE.json configs[1] at N = 1, configs[3] at N > 1), per GPU:
     corpus  37 000 x 768 fp32, iid N(0,1) rows L2-normalised, default_rng(1234); levels default_rng(1235)
             from the real CSV histogram;
     queries 10 000 x 768, default_rng(4321 + rank), resident in HBM before the timed region;
@@ -15,14 +15,23 @@ Workload (BASELINE.json configs[1]), per GPU:
 With N > 1 every rank holds a corpus replica and its own query batch (data-parallel, no collective on
 the data path: weak scaling); `value` is the whole-job rate = N * nq * K / max-over-ranks time.
 
+Workload `rowshard` (BASELINE.json configs[4]; SURVEY.md 8d "Config 5"): every rank generates a shard of
+1 250 000 x 768 rows ON THE DEVICE (seed 1234 + rank; N = 8 -> the 10 M-row corpus), the query batch (100 000 x 768,
+seed 4321, replicated) is searched in slices: local top-k of the shard -> ONE RCCL all_gather of (score f32, id i64,
+level i32) per hit -> merge kernel + level reweight on every rank (rag_project_icd10_amd.sharded.ShardedSearch, ROW).
+One STEP = one pass of the whole query batch; per-GPU work is fixed as N grows (weak scaling: the corpus grows).
+With N > 1 the default run also measures this workload and reports it under "rowshard" in the same JSON line, so the
+driver's scaling run (bench.py --gpus 1/2/4/8) yields both curves.
+
 The JSON line also carries
     roofline      dominant kernel (coarse_flat_kernel): algorithmic FLOPs 2*nq*n*dim per launch / its mean
                   duration over the timed steps (hipEvents recorded by the library on the search
-                  stream), against the dense fp16/bf16 MFMA peak (2.5 PFLOP/s);
+                  stream), against the dense fp16/bf16 MFMA peak (2.5 PFLOP/s) and against the bare MFMA stream
+                  of the same loop measured on this chip (clock under load);
     cpu_baseline  the reference's call shape on the host CPU (one query per call: fp32 scan + top-k +
                   level weight + stable sort, oracle/oracle.py reference_shaped_search), rank 0, N = 1
-                  only, on a bounded query sample;
-    recall_at_10 / ids_exact against the CPU oracle on a query sample.
+                  only, on a bounded query sample; plus the batched-torch line and the CPU encoder lines of BASELINE.md 3;
+    recall_at_10 / ids_exact against the CPU oracle on EVERY query of the batch.
 """
 import argparse
 import json
@@ -36,6 +45,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS_F16 = 2500.0  # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+# the kernel's own MFMA stream with nothing else in the loop, 10 000 x 37 000 x 768 (profiles/r01_ablate8_bare_loop_breakdown.log:
+# 0.357 ms): what the instruction stream can reach at the clock the chip holds under this load
+BARE_STREAM_TFLOPS = 1594.0
 
 
 def unit_rows(n, dim, seed):
@@ -49,8 +61,9 @@ def icd_levels(n, seed):
     return np.where(r < 0.1243, 1, np.where(r < 0.4234, 2, 3)).astype(np.int32)
 
 
-def cpu_baseline(corpus, levels, queries, k, budget_s=12.0):
-    """reference-shaped CPU search, one query per call, on a bounded sample of the same workload"""
+def cpu_baseline(corpus, levels, queries, k, budget_s=12.0, with_encoder=True):
+    """reference-shaped CPU search, one query per call, on a bounded sample of the same workload; the "best CPU"
+    batched line and the CPU encoder lines of BASELINE.md section 3 ride along under `extra`"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
     import torch
@@ -66,142 +79,343 @@ def cpu_baseline(corpus, levels, queries, k, budget_s=12.0):
     for q in queries[:m]:
         orc.reference_shaped_search(corpus, levels, q, k)
     dt = time.perf_counter() - t0
-    return {"value": m / dt, "unit": "queries/s", "cores": int(os.cpu_count() or threads), "blas_threads": int(threads),
-            "kind": "port", "sample": f"{m} of the {len(queries)} queries, one query per call (reference call shape), "
-                                      f"{corpus.shape[0]}x{corpus.shape[1]} fp32 corpus, numpy/BLAS"}
+    out = {"value": m / dt, "unit": "queries/s", "cores": int(os.cpu_count() or threads), "blas_threads": int(threads),
+           "kind": "port", "sample": f"{m} of the {len(queries)} queries, one query per call (reference call shape), "
+                                     f"{corpus.shape[0]}x{corpus.shape[1]} fp32 corpus, numpy/BLAS"}
+    extra = {}
+    try:   # "CPU-best": batched Q @ C^T + topk in torch fp32
+        mb = min(len(queries), 1000)
+        tc, tq = torch.from_numpy(corpus), torch.from_numpy(queries[:mb])
+        torch.topk(tq[:64] @ tc.T, k, dim=1)
+        t0 = time.perf_counter()
+        torch.topk(tq @ tc.T, k, dim=1)
+        extra["batched_torch_topk"] = {"value": mb / (time.perf_counter() - t0), "unit": "queries/s",
+                                       "sample": f"{mb} queries in one torch.topk(Q @ C^T) call, fp32"}
+    except Exception as exc:   # a baseline, never fatal
+        extra["batched_torch_topk"] = {"error": str(exc)}
+    if with_encoder:
+        try:   # CPU encoder: the reference's batch-1 encode_query per string, and /embed's batch-32 encode_batch
+            os.environ.setdefault("EMBEDDING_MODEL_NAME", "shibing624/text2vec-base-chinese")
+            from rag_project_icd10_amd.services.embedding_service import EmbeddingService
+            emb = EmbeddingService(allow_synthetic=True, device="cpu")
+            texts = [l.strip() for l in open(os.path.join(ROOT, "tests", "golden", "diagnosis_strings.txt"), encoding="utf-8")][:160]
+            emb.encode_query(texts[0])
+            t0 = time.perf_counter()
+            for t in texts[:32]:
+                emb.encode_query(t)
+            d1 = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            emb.encode_batch(texts[32:160], show_progress=False)
+            d2 = time.perf_counter() - t0
+            extra["encoder_reference_shaped"] = {"value": 32 / d1, "unit": "strings/s", "sample": "32 strings, encode_query one per call (batch 1)",
+                                                 "synthetic_weights": bool(emb.get_model_info().get("synthetic"))}
+            extra["encoder_embed_shaped"] = {"value": 128 / d2, "unit": "strings/s", "sample": "128 strings, encode_batch (batch 32)"}
+        except Exception as exc:
+            extra["encoder"] = {"error": str(exc)}
+    out["extra"] = extra
+    return out
 
 
 def pmc_traffic(kernel, nq, n):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/rNN_pmc_traffic.json, made by scripts/gpu_pmc2.sh: FETCH_SIZE and WRITE_SIZE collected in their own
+    (profiles/rNN_pmc_traffic.json, made by scripts/gpu_pmc.sh: FETCH_SIZE and WRITE_SIZE collected in their own
     passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950). PMC counters cannot be read from inside
-    this process; the number is reported only for the workload it was collected on."""
+    this process; the number is reported only for the workload it was collected on, with the file it came from."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files or (nq, n) != (10000, 37000):
-        return None
+        return None, None
     try:
         d = json.load(open(files[-1]))
         for name, v in d.items():
             if name.startswith(kernel):
-                return float(v["traffic_bytes"])
+                return float(v["traffic_bytes"]), os.path.relpath(files[-1], ROOT)
     except Exception:
-        return None
-    return None
+        return None, None
+    return None, None
 
 
-def main():
+class Ctx:
+    """process-group context of one rank"""
+
+    def __init__(self, backend_env="ICD_BENCH_BACKEND"):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        # test hook (single-GPU boxes / CPU tests): ICD_BENCH_BACKEND=gloo ICD_BENCH_ONE_DEVICE=1 runs the N-rank control
+        # flow with every rank on one device and the reductions on the CPU; the driver's runs use nccl (= RCCL)
+        self.backend = os.environ.get(backend_env, "nccl")
+        if os.environ.get("ICD_BENCH_ONE_DEVICE") == "1":
+            self.local_rank = 0
+        self.cpu_only = os.environ.get("ICD_BENCH_DEVICE") == "cpu"   # tests inject a CPU search (no HIP index)
+        if self.world > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                        device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+        if self.cpu_only:
+            self.dev = torch.device("cpu")
+        else:
+            torch.cuda.set_device(self.local_rank)
+            self.dev = torch.device("cuda", self.local_rank)
+        self.red_dev = self.dev if self.backend == "nccl" else torch.device("cpu")
+
+    def sync(self):
+        if not self.cpu_only:
+            self.torch.cuda.synchronize(self.dev)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.red_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(self, fn, steps, warmup, before_timing=None):
+        """W untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; max over ranks"""
+        out = None
+        for _ in range(warmup):
+            out = fn()
+        self.sync()
+        if before_timing:
+            before_timing()
+        self.barrier()
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        self.sync()
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0), out
+
+
+def hip_index_factory(corpus, levels, device, max_nq, max_k, id_base=0):
+    from rag_project_icd10_amd._native import IcdIndex
+    return IcdIndex(corpus, levels, device=device, max_nq=max_nq, max_k=max_k, id_base=id_base)
+
+
+def run_replicated(ctx, args, index_factory=hip_index_factory):
+    """BASELINE configs[1] (N = 1) / configs[3] (N > 1): corpus replicated, every rank its own query batch"""
+    from rag_project_icd10_amd._native import MODE_AUTO, MODE_EXACT
+    torch = ctx.torch
+    dim, nq, n, k = 768, args.nq, args.n, args.k
+    mode = MODE_AUTO if args.mode == "auto" else MODE_EXACT
+    corpus, levels = unit_rows(n, dim, 1234), icd_levels(n, 1235)
+    queries = unit_rows(nq, dim, 4321 + ctx.rank)
+    index = index_factory(corpus, levels, ctx.local_rank, nq, max(k, 10))
+    dq = torch.from_numpy(queries).to(ctx.dev)
+    ctx.sync()
+
+    def before():
+        index.set_profiling(True)
+        index.profile_summary()  # reset the event window
+
+    elapsed, out = ctx.timed(lambda: index.search_reweighted(dq, k, mode), args.steps, args.warmup, before)
+    prof = index.profile_summary()
+    index.set_profiling(False)
+    stats = index.stats()
+    line = None
+    if ctx.rank == 0:
+        adj, raw, ids, lv = (x.cpu().numpy() for x in out)
+        # parity / recall of EVERY query of rank 0's batch against the CPU oracle (outside the timed region)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as orc
+        t0 = time.perf_counter()
+        os_, oi = orc.flat_ip_topk(corpus, queries, k)
+        want = orc.reweight(os_, oi, levels)
+        check_s = time.perf_counter() - t0
+        recall = float(np.mean([len(set(a) & set(b)) / k for a, b in zip(ids, oi)]))
+        ids_exact = bool(np.array_equal(ids, want[2]))
+        adj_exact = bool(adj.tobytes() == want[0].tobytes())
+        max_dscore = float(np.max(np.abs(raw.astype(np.float64) - want[1].astype(np.float64))))
+
+        fast = mode == MODE_AUTO and stats["last_mode"] == MODE_AUTO
+        dom_ms = prof["ms_coarse"] if fast else prof["ms_exact"]
+        flops = 2.0 * nq * n * dim
+        achieved = flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        peak = PEAK_TFLOPS_F16 if fast else 157.3
+        kern = "coarse_flat_kernel" if fast else "exact_topk_kernel"
+        traffic, traffic_src = pmc_traffic(kern, nq, n)
+        line = {
+            "metric": "queries_per_sec", "value": ctx.world * nq * args.steps / elapsed, "unit": "queries/s",
+            "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16" if fast else "f32",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{1 if ctx.world == 1 else 3}]: {nq} random fp32 768-d queries per GPU x {n}x768 corpus, "
+                                   f"top_k={k}, search only (pre-embedded, HBM-resident inputs), level reweight fused",
+                       "nq_per_gpu": nq, "corpus_rows": n, "dim": dim, "top_k": k, "mode": args.mode,
+                       "parallelism": f"query-sharded x{ctx.world}, corpus replicated" if ctx.world > 1 else "single GPU",
+                       "collective_ranks": ctx.dist.get_world_size() if ctx.world > 1 else 1,
+                       "result_arithmetic": "fp32 canonical chain (bit-identical to the CPU oracle)"},
+            "recall_at_10": recall, "ids_exact": ids_exact, "adjusted_scores_exact": adj_exact, "max_abs_dscore": max_dscore,
+            "parity_checked_queries": int(nq), "parity_check_s": round(check_s, 2),
+            "fallback_queries": int(stats["last_fallback"]), "coarse_chunks": int(stats["last_chunks"]),
+            "kernel_ms": {kname: round(v, 5) for kname, v in prof.items() if kname != "count"},
+            "roofline": {"bound": "mfma", "kernel": kern,
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_unit": "bytes per launch (rocprofv3 PMC passes of this kernel, 2 x FETCH_SIZE + WRITE_SIZE)",
+                         "flops_per_launch": flops, "launch_ms": dom_ms, "launches_averaged": prof["count"],
+                         "bare_mfma_stream_tflops": BARE_STREAM_TFLOPS if fast else None,
+                         "frac_of_bare_mfma_stream": achieved / BARE_STREAM_TFLOPS if fast else None},
+        }
+        if ctx.world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(corpus, levels, queries, k)
+    index.close()
+    return line
+
+
+def device_shard(torch, dev, n, dim, seed):
+    """one shard generated on the device, rows L2-normalised, levels from the real CSV histogram"""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    corpus = torch.empty((n, dim), dtype=torch.float32, device=dev)
+    for s in range(0, n, 250_000):   # generated in slabs: no 2x transient
+        e = min(n, s + 250_000)
+        x = torch.randn((e - s, dim), generator=g, device=dev, dtype=torch.float32)
+        corpus[s:e] = x / x.norm(dim=1, keepdim=True)
+    r = torch.rand(n, generator=g, device=dev)
+    levels = torch.where(r < 0.1243, 1, torch.where(r < 0.4234, 2, 3)).to(torch.int32)
+    return corpus, levels
+
+
+def exact_merge_torch(torch, scores, ids, k):
+    """[G, m, k] best-first lists -> global top-k by (score desc, id asc); plain torch, the checker of the sample"""
+    G, m, _ = scores.shape
+    s = scores.permute(1, 0, 2).reshape(m, G * k).to(torch.float64)
+    i = ids.permute(1, 0, 2).reshape(m, G * k)
+    o1 = torch.argsort(i, dim=1, stable=True)
+    s, i = torch.gather(s, 1, o1), torch.gather(i, 1, o1)
+    o2 = torch.argsort(-s, dim=1, stable=True)
+    return torch.gather(s, 1, o2)[:, :k].to(torch.float32), torch.gather(i, 1, o2)[:, :k]
+
+
+def run_rowshard(ctx, args, index_factory=hip_index_factory, sharded_factory=None):
+    """BASELINE configs[4]: the corpus row-sharded over the ranks (1.25 M rows per GPU), the query batch replicated"""
+    from rag_project_icd10_amd.sharded import ROW_SHARD, ShardedSearch
+    torch, dist = ctx.torch, ctx.dist
+    n, dim, k = args.rows_per_gpu, 768, args.k
+    nq, sl = args.rowshard_queries, args.rowshard_slice
+    corpus, levels = device_shard(torch, ctx.dev, n, dim, 1234 + ctx.rank)
+    t0 = time.perf_counter()
+    index = index_factory(corpus, levels, ctx.local_rank, sl, max(k, 10), ctx.rank * n)
+    ctx.sync()
+    t_build = time.perf_counter() - t0
+    del corpus
+    gq = torch.Generator(device=ctx.dev)
+    gq.manual_seed(4321)
+    queries = torch.randn((nq, dim), generator=gq, device=ctx.dev, dtype=torch.float32)
+    queries /= queries.norm(dim=1, keepdim=True)
+    sharded = sharded_factory(index) if sharded_factory else ShardedSearch.from_index(index, ROW_SHARD)
+
+    def one_pass():
+        return [sharded.search_reweighted(queries[s:s + sl], k) for s in range(0, nq, sl)]
+
+    steps, warmup = max(1, min(args.steps, args.rowshard_steps)), 1
+
+    def before():
+        if hasattr(index, "set_profiling"):
+            index.set_profiling(True)
+            index.profile_summary()
+
+    elapsed, outs = ctx.timed(one_pass, steps, warmup, before)
+    prof = index.profile_summary() if hasattr(index, "profile_summary") else {"ms_coarse": 0.0, "count": 0}
+    if hasattr(index, "set_profiling"):
+        index.set_profiling(False)
+    # correctness on a query sample: every rank's EXACT-kernel hits of its shard, gathered, merged by plain torch
+    # (score desc, id asc) must equal the ids / raw scores the row-sharded path returned
+    from rag_project_icd10_amd._native import MODE_EXACT
+    m = min(64, sl, nq)
+    sample = queries[:m].contiguous()
+    es, ei = index.search(sample, k, MODE_EXACT)
+    if ctx.world > 1:
+        gs = [torch.empty_like(es) for _ in range(ctx.world)]
+        gi = [torch.empty_like(ei) for _ in range(ctx.world)]
+        dist.all_gather(gs, es.contiguous())
+        dist.all_gather(gi, ei.contiguous())
+        es, ei = torch.stack(gs), torch.stack(gi)
+    else:
+        es, ei = es.unsqueeze(0), ei.unsqueeze(0)
+    ws, wi = exact_merge_torch(torch, es, ei, k)
+    adj0, raw0, ids0, lv0 = outs[0]
+    # the path's output is in reweighted order: compare as sets of (id, raw score) per query, and its adjusted order
+    got = torch.argsort(ids0[:m], dim=1)
+    want = torch.argsort(wi, dim=1)
+    ids_ok = bool(torch.equal(torch.gather(ids0[:m], 1, got), torch.gather(wi, 1, want)))
+    raw_ok = bool(torch.equal(torch.gather(raw0[:m], 1, got).view(torch.int32), torch.gather(ws, 1, want).view(torch.int32)))
+    sorted_ok = bool((adj0[:, 1:] <= adj0[:, :-1]).all())
+    stats = index.stats() if hasattr(index, "stats") else {}
+    line = None
+    if ctx.rank == 0:
+        flops_gpu = 2.0 * nq * n * dim
+        launches = -(-nq // sl)
+        dom_ms = float(prof.get("ms_coarse", 0.0))
+        # (slices differ in size only in the last one: price the mean launch against the mean slice)
+        achieved = (flops_gpu / launches) / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        line = {
+            "metric": "queries_per_sec", "value": nq * steps / elapsed, "unit": "queries/s",
+            "n_gpus": ctx.world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[4]: {ctx.world} x {n} rows x {dim} corpus row-sharded (generated on device), "
+                                   f"{nq} queries replicated, top_k={k}, slices of {sl}: local top-k -> all_gather -> merge + reweight",
+                       "rows_per_gpu": n, "corpus_rows_total": ctx.world * n, "queries": nq, "slice": sl, "dim": dim, "top_k": k,
+                       "parallelism": f"row-sharded x{ctx.world}", "collective": "all_gather_into_tensor (RCCL)" if ctx.world > 1 else "none (one shard)",
+                       "collective_ranks": dist.get_world_size() if ctx.world > 1 else 1},
+            "whole_job_tflops": ctx.world * flops_gpu * steps / elapsed / 1e12,
+            "ids_exact_on_sample": ids_ok, "raw_scores_exact_on_sample": raw_ok, "adjusted_sorted": sorted_ok, "sample_queries": int(m),
+            "fallback_queries_last_slice": int(stats.get("last_fallback", 0)),
+            "index_build_s": round(t_build, 3),
+            "roofline": {"bound": "mfma", "kernel": "coarse_flat_kernel", "achieved": achieved, "peak": PEAK_TFLOPS_F16,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS_F16, "traffic": None,
+                         "flops_per_launch": flops_gpu / launches, "launch_ms": dom_ms, "launches_averaged": int(prof.get("count", 0))},
+        }
+    index.close()
+    return line
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=["replicated", "rowshard"], default="replicated")
     ap.add_argument("--nq", type=int, default=10000)
     ap.add_argument("--n", type=int, default=37000)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--mode", choices=["auto", "exact"], default="auto")
+    ap.add_argument("--rows-per-gpu", type=int, default=1_250_000)
+    ap.add_argument("--rowshard-queries", type=int, default=100_000)
+    ap.add_argument("--rowshard-slice", type=int, default=16384)
+    ap.add_argument("--rowshard-steps", type=int, default=3, help="passes of the row-sharded workload (each ~0.2 s per GPU)")
+    ap.add_argument("--no-rowshard", action="store_true", help="N > 1: skip the row-sharded leg of the default run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
-    import torch
-    import torch.distributed as dist
-    from rag_project_icd10_amd._native import MODE_AUTO, MODE_EXACT, IcdIndex
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    # test hook (single-GPU boxes): ICD_BENCH_BACKEND=gloo ICD_BENCH_ONE_DEVICE=1 runs the N-rank control flow with
-    # every rank on cuda:0 and the reductions on the CPU; the driver's runs use nccl (= RCCL), one GPU per rank
-    backend = os.environ.get("ICD_BENCH_BACKEND", "nccl")
-    if os.environ.get("ICD_BENCH_ONE_DEVICE") == "1":
-        local_rank = 0
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    red_dev = dev if backend == "nccl" else torch.device("cpu")
-    dim, nq, n, k = 768, args.nq, args.n, args.k
-    mode = MODE_AUTO if args.mode == "auto" else MODE_EXACT
-
-    corpus, levels = unit_rows(n, dim, 1234), icd_levels(n, 1235)
-    queries = unit_rows(nq, dim, 4321 + rank)
-    index = IcdIndex(corpus, levels, device=local_rank, max_nq=nq, max_k=max(k, 10))
-    dq = torch.from_numpy(queries).to(dev)
-    torch.cuda.synchronize(dev)
-
-    def step():
-        return index.search_reweighted(dq, k, mode)
-
-    for _ in range(args.warmup):
-        out = step()
-    torch.cuda.synchronize(dev)
-    index.set_profiling(True)
-    index.profile_summary()  # reset the event window
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    prof = index.profile_summary()
-    index.set_profiling(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    stats = index.stats()
-
-    if rank == 0:
-        adj, raw, ids, lv = (x.cpu().numpy() for x in out)
-        # parity / recall on a query sample against the CPU oracle
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle as orc
-        sample = np.arange(0, nq, max(1, nq // 64))[:64]
-        os_, oi = orc.flat_ip_topk(corpus, queries[sample], k)
-        want = orc.reweight(os_, oi, levels)
-        recall = float(np.mean([len(set(a) & set(b)) / k for a, b in zip(ids[sample], oi)]))
-        ids_exact = bool(np.array_equal(ids[sample], want[2]))
-        max_dscore = float(np.max(np.abs(raw[sample].astype(np.float64) - want[1].astype(np.float64))))
-
-        dom_ms = prof["ms_coarse"] if (mode == MODE_AUTO and stats["last_mode"] == MODE_AUTO) else prof["ms_exact"]
-        flops = 2.0 * nq * n * dim
-        achieved = flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-        peak = PEAK_TFLOPS_F16 if stats["last_mode"] == MODE_AUTO else 157.3
-        line = {
-            "metric": "queries_per_sec", "value": world * nq * args.steps / elapsed, "unit": "queries/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f16" if stats["last_mode"] == MODE_AUTO else "f32",
-            "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {nq} random fp32 768-d queries x {n}x768 corpus, top_k={k}, "
-                                   f"search only (pre-embedded, HBM-resident inputs), level reweight fused",
-                       "nq_per_gpu": nq, "corpus_rows": n, "dim": dim, "top_k": k, "mode": args.mode,
-                       "parallelism": f"query-sharded x{world}, corpus replicated" if world > 1 else "single GPU",
-                       "result_arithmetic": "fp32 canonical chain (bit-identical to the CPU oracle)"},
-            "recall_at_10": recall, "ids_exact": ids_exact, "max_abs_dscore": max_dscore,
-            "fallback_queries": int(stats["last_fallback"]), "coarse_chunks": int(stats["last_chunks"]),
-            "kernel_ms": {kname: round(v, 5) for kname, v in prof.items() if kname != "count"},
-            "roofline": {"bound": "mfma", "kernel": "coarse_flat_kernel" if stats["last_mode"] == MODE_AUTO else "exact_topk_kernel",
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": pmc_traffic("coarse_flat_kernel" if stats["last_mode"] == MODE_AUTO else "exact_topk_kernel", nq, n),
-                         "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r*_pmc_traffic.json)",
-                         "flops_per_launch": flops, "launch_ms": dom_ms, "launches_averaged": prof["count"]},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(corpus, levels, queries, k)
+    ctx = Ctx()
+    if args.workload == "rowshard":
+        line = run_rowshard(ctx, args)
+    else:
+        line = run_replicated(ctx, args)
+        if ctx.world > 1 and not args.no_rowshard:
+            rs = run_rowshard(ctx, args)
+            if line is not None:
+                line["rowshard"] = rs
+    if ctx.rank == 0:
         print(json.dumps(line), flush=True)
-    index.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if ctx.world > 1:
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

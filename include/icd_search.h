@@ -153,8 +153,12 @@ int icd_index_stats(icd_index *idx, icd_stats *out);
  * (the automatic choice gives every CU the same number of 128 x 128 tiles). */
 int icd_index_set_chunks(icd_index *idx, int32_t chunks);
 
-/* Diagnostic builds only (env ICD_COARSE_VAR=8): per-wave cycle sums of the coarse kernel,
- * [work-group][wave][4] = {wait+barrier, stage body, fused select, tiles}. */
+/* Test switch, process-wide, read by icd_index_create: 0 keeps the fp16 corpus copy in row order instead of the
+ * golden-ratio permutation (results are identical; only the share of certified queries changes). Default 1. */
+int icd_debug_set_permute(int32_t enabled);
+
+/* Diagnostic builds only (make ABLATE=1, env ICD_FLAT_VAR with bit 1024): per-wave cycle sums of the coarse kernel,
+ * [work-group][wave][8] = {LDS-DMA wait, barrier, stage body, fused select, tiles, ...}. */
 int icd_index_debug_counters(icd_index *idx, unsigned long long *out, int32_t count);
 
 int icd_index_set_profiling(icd_index *idx, int32_t enabled);

@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = (
     "icd_abi_version", "icd_last_error", "icd_device_count", "icd_index_create", "icd_index_destroy",
     "icd_index_search", "icd_index_search_reweighted", "icd_merge_topk", "icd_index_lookup_levels",
     "icd_index_stats", "icd_index_set_chunks", "icd_index_debug_counters", "icd_index_set_profiling",
-    "icd_index_last_profile", "icd_index_profile_summary",
+    "icd_index_last_profile", "icd_index_profile_summary", "icd_debug_set_permute",
 )
 
 
@@ -76,6 +76,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.icd_index_lookup_levels.argtypes = [vp, vp, i64, vp, vp]
     lib.icd_index_stats.argtypes = [vp, C.POINTER(_Stats)]
     lib.icd_index_set_chunks.argtypes = [vp, i32]
+    lib.icd_debug_set_permute.argtypes = [i32]
     lib.icd_index_debug_counters.argtypes = [vp, vp, i32]
     lib.icd_index_set_profiling.argtypes = [vp, i32]
     lib.icd_index_last_profile.argtypes = [vp, C.POINTER(_Profile)]

@@ -49,20 +49,38 @@ constexpr int CO_LIMIT = CO_CAP - 2 * CO_CHECK_EVERY;    // compact a query once
 constexpr int CO_LDS_BYTES = CO_RING_BYTES + CO_BM * CO_CAP * 8 + 4 * 256;
 
 // ---- fp32 -> fp16 images ---------------------------------------------------------------------------
-// One wave per row: converts with round-to-nearest-even, accumulates the row's squared norm in fp32,
-// flags rows whose fp16 image is unusable (non-finite input or |x| > 65504).
+// One wave per row. The fp16 image of a row is the row times a POWER OF TWO chosen so that its largest component
+// lands in [1, 2): scaling by 2^e is exact, so the image keeps fp16's 11 significant bits whatever the magnitude of
+// the input (unit-norm embeddings, rows scaled by 1e-30, rows scaled by 1e30 alike) and can neither overflow nor sink
+// into fp16's subnormal range as a whole. Queries get a scale per row (mode 0); the corpus gets ONE scale from its
+// largest component (mode 2 finds it, mode 1 applies it) because one coarse list holds scores of many rows.
+// Coarse scores are therefore in SCALED units 2^(e_query + e_corpus); they are only ever compared with each other and
+// with bounds of the same query, and finalize.hpp rescans the candidates from the unscaled fp32 data. The norms
+// reported here are norms of the scaled rows (they size the certificate's error bound, also in scaled units).
 struct ConvertArgs {
     const float *src;        // [rows][dim]
     _Float16 *dst;           // [rows_pad][dim]
     int rows, rows_pad, dim;
-    float *norm;             // nullable [rows]: L2 norm rounded up
-    unsigned char *bad;      // nullable [rows]
-    unsigned int *rmax_bits; // nullable: atomicMax of norm bits (norm >= 0)
+    int mode;                // 0: per-row scale; 1: fixed scale 2^fixed_exp; 2: scan only (amax_bits, any_bad)
+    int fixed_exp;
+    float *norm;             // nullable [rows]: L2 norm of the scaled row, rounded up
+    int *scale_exp;          // nullable [rows]: e of the row (mode 0)
+    unsigned char *bad;      // nullable [rows]: 1 = non-finite input
+    unsigned int *rmax_bits; // nullable: atomicMax of the scaled norm's bits (norm >= 0)
+    unsigned int *amax_bits; // nullable: atomicMax of max |x| bits over all rows (mode 2)
     unsigned int *any_bad;   // nullable: set to 1 if any row is bad
     unsigned int *zero_u32;  // nullable [rows_pad]: cleared (the coarse pass's shared per-query thresholds)
     long long perm_mul;      // with perm_mod > 0: dst row p holds src row (p * perm_mul) mod perm_mod (an affine permutation)
     int perm_mod;
 };
+
+// e with m * 2^e in [1, 2) for finite m > 0 (subnormals included); 0 otherwise
+__host__ __device__ inline int scale_exp_for(float m) {
+    if (!(m > 0.0f) || !(m <= 3.402823466e38f)) return 0;
+    int ex;
+    (void)frexpf(m, &ex);   // m = f * 2^ex, f in [0.5, 1)
+    return 1 - ex;
+}
 
 __global__ __launch_bounds__(256) void convert_rows_kernel(ConvertArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -71,32 +89,54 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(ConvertArgs a) {
     if (a.zero_u32 && lane == 0) a.zero_u32[row] = 0u;
     _Float16 *d = a.dst + (size_t)row * a.dim;
     if (row >= a.rows) {
-        for (int i = lane * 4; i < a.dim; i += 256) {
-            d[i] = (_Float16)0.0f; d[i + 1] = (_Float16)0.0f; d[i + 2] = (_Float16)0.0f; d[i + 3] = (_Float16)0.0f;
-        }
+        if (a.mode != 2)
+            for (int i = lane * 4; i < a.dim; i += 256) {
+                d[i] = (_Float16)0.0f; d[i + 1] = (_Float16)0.0f; d[i + 2] = (_Float16)0.0f; d[i + 3] = (_Float16)0.0f;
+            }
         return;
     }
     const int srow = a.perm_mod > 0 ? (int)(((long long)row * a.perm_mul) % a.perm_mod) : row;
     const float *s = a.src + (size_t)srow * a.dim;
-    float ss = 0.0f;
+    float m = 0.0f;
     bool bad = false;
     for (int i = lane * 4; i < a.dim; i += 256) {
         const float4 v = *reinterpret_cast<const float4 *>(s + i);
         const float f[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            bad |= !(fabsf(f[j]) <= 65504.0f);
-            ss = __builtin_fmaf(f[j], f[j], ss);
-            d[i + j] = (_Float16)f[j];
+            bad |= !(fabsf(f[j]) <= 3.402823466e38f);   // NaN and infinities
+            m = fmaxf(m, fabsf(f[j]));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    const bool anybad = __any(bad);
+    if (a.mode == 2) {
+        if (lane == 0) {
+            if (!anybad && a.amax_bits) atomicMax(a.amax_bits, __float_as_uint(m));
+            if (a.any_bad && anybad) atomicOr(a.any_bad, 1u);
+        }
+        return;
+    }
+    const int e = anybad ? 0 : (a.mode == 1 ? a.fixed_exp : scale_exp_for(m));
+    float ss = 0.0f;
+    for (int i = lane * 4; i < a.dim; i += 256) {
+        const float4 v = *reinterpret_cast<const float4 *>(s + i);
+        const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = ldexpf(f[j], e);   // exact (a component 2^126 below the row's largest flushes: far below fp16's grid)
+            ss = __builtin_fmaf(x, x, ss);
+            d[i + j] = (_Float16)x;
         }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
-    const bool anybad = __any(bad);
     if (lane == 0) {
         float nrm = sqrtf(ss) * 1.000001f;  // round up: it multiplies an error bound
         if (!(nrm == nrm)) nrm = INFINITY;
         if (a.norm) a.norm[row] = nrm;
+        if (a.scale_exp) a.scale_exp[row] = e;
         if (a.bad) a.bad[row] = anybad ? 1 : 0;
         if (a.rmax_bits) atomicMax(a.rmax_bits, __float_as_uint(nrm));
         if (a.any_bad && anybad) atomicOr(a.any_bad, 1u);

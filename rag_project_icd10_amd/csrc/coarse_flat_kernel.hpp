@@ -149,12 +149,15 @@ __device__ __forceinline__ float flush_emit_parallel(const char *smem, uint32_t 
 // VAR: bit flags of the stage variants (A/B builds instantiate several, `make ABLATE=1`; the product one is CF_PRODUCT_VAR)
 //   1    shared-threshold load issued two stages before the tile end (asm, counted wait) instead of a drained load after it
 //   2    LDS-DMA pieces one behind each of the four MFMAs that follow the barrier instead of a burst in front of them
+//   4    LDS-DMA pieces spread over the 16 MFMAs between two barriers, every wave in its own slots (piece i of wave w
+//        behind MFMA 4 i + w): the CU's address unit sees one piece per MFMA instead of sixteen at once
 //   8    query fragments pinned to accumulator registers
+//   16   select: one v_max3 tree + one scalar branch per FOUR score registers, predicated appends behind it
 //   32   ring of 3 stages, 64 ring of 6 stages (TIMING ONLY: the compaction scratch aliases the ring)
 //   128  A fragments read two k-steps ahead of their MFMAs instead of one
 //   256  TIMING ONLY: no s_barrier        512  TIMING ONLY: no wait for the LDS-DMA pieces
 //   1024 diagnostic: s_memtime stamps around the mid-stage wait, the barrier and the select (CoarseFlatArgs::dbg)
-constexpr int CF_PRODUCT_VAR = 0;
+constexpr int CF_PRODUCT_VAR = 1 + 2 + 8 + 128;   // measured: profiles/r02_ab_flat_variants.log
 __host__ __device__ constexpr int cf_ring_stages(int var) { return (var & 32) ? 3 : ((var & 64) ? 6 : CO_S); }
 __host__ __device__ constexpr int cf_lds_bytes(int var) {
     return cf_ring_stages(var) * CO_STAGE_BYTES + CO_BM * CO_CAP * 8 + ((var & 64) ? 0 : 4 * 256);
@@ -167,7 +170,9 @@ template <int D, int VAR = CF_PRODUCT_VAR>
 __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     constexpr bool EARLY_THR = (VAR & 1) != 0;
     constexpr bool DMA_SPREAD = (VAR & 2) != 0;
+    constexpr bool DMA_SLOTS = (VAR & 4) != 0;
     constexpr bool Q_AGPR = (VAR & 8) != 0;
+    constexpr bool MAXTREE4 = (VAR & 16) != 0;
     constexpr bool PF2 = (VAR & 128) != 0;
     constexpr bool NOBAR = (VAR & 256) != 0, NOVM = (VAR & 512) != 0, STAMPS = (VAR & 1024) != 0;
     constexpr int S = cf_ring_stages(VAR);            // ring slots
@@ -216,6 +221,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     const uint32_t wave_qbase = RING_BYTES + (uint32_t)(wave * 32) * Ops::QBYTES;
     const uint32_t wave_scratch = ((VAR & 64) ? 0u : RING_BYTES + (uint32_t)CO_BM * Ops::QBYTES) + (uint32_t)wave * 256u;
     unsigned long long st_vm = 0, st_bar = 0, st_body = 0, st_sel = 0, st_tiles = 0, st_prev = 0;   // (STAMPS)
+    unsigned long long st_comp[2] = {0, 0}, st_thr = 0, st_boot = 0;                              // compactions, their cycles
     const int last_tile = a.ctiles - 1;
 
     half8 qf[NF];
@@ -260,6 +266,19 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, ldst, 16, src_off[3], soff, 3072, 0);
         };
 
+        // one piece (DMA_SLOTS): slot j of the 16-MFMA window behind a barrier belongs to wave j & 3, piece j >> 2
+        auto issue_slot = [&](auto J, int g_tile, int g_ks, int ring_slot) {
+            constexpr int j = decltype(J)::value;
+            constexpr int i = j >> 2;
+            if (wave == (j & 3)) {
+                const int trow = min(g_tile, last_tile - t0);
+                char *dst = smem + ring_slot * CO_STAGE_BYTES + wave * 4096;
+                const uint32_t soff = (uint32_t)trow * (uint32_t)(CO_BN * D * 2) + (uint32_t)g_ks * (CO_BK * 2);
+                __attribute__((address_space(3))) void *ldst = (__attribute__((address_space(3))) void *)dst;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, ldst, 16, src_off[i], soff, i * 1024, 0);
+            }
+        };
+
         Sel2 st;
         Ops::init(st, wave_qbase + (uint32_t)c * Ops::QBYTES, h, (slot0 + wave * 32 + c) < a.nq);
         float boot1 = -INFINITY, boot2 = -INFINITY, boot3 = -INFINITY;   // bootstrap: the lane's three best scores so far
@@ -291,16 +310,50 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                 // between compactions (kept 16 + 2 x (16 + the 8 of one check interval) = 64 slots); only when some lane
                 // is past its quota does the wave run the full check (partner counts, compaction)
                 if (__builtin_amdgcn_ballot_w64(Ops::used(st, h) > CO_QUOTA) != 0ull)
-                    Ops::check(st, lane, smem, wave_qbase, wave_scratch, false, CO_LIMIT, nullptr, CO_QUOTA);
+                    Ops::check(st, lane, smem, wave_qbase, wave_scratch, false, CO_LIMIT, STAMPS ? st_comp : nullptr, CO_QUOTA);
+            }
+        };
+
+        // Four registers per scalar branch. A compare followed by its own branch costs far more than its two issue slots
+        // (the branch waits for the VALU result; measured ~70 cycles per register with the appends), and only ~13 % of the
+        // registers hold a passing score: the largest of four registers is compared once (two v_max3 + v_cmp + branch),
+        // and a group with a pass (~40 %) appends under predication, no further branches.
+        auto filter_grp4 = [&](const f32x16 (&pa)[4], auto G, uint32_t rowbase) {
+            constexpr int g = decltype(G)::value;
+            constexpr int t = g >> 2, r0 = (g & 3) * 4;
+            const float v0 = pa[t][r0], v1 = pa[t][r0 + 1], v2 = pa[t][r0 + 2], v3 = pa[t][r0 + 3];
+            float m;   // (asm: fmaxf on MFMA outputs makes hipcc canonicalise every operand with a v_max of its own)
+            asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4" : "=&v"(m) : "v"(v0), "v"(v1), "v"(v2), "v"(v3));
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(m > st.thr) != 0ull, 0)) {
+                asm volatile("" ::: "memory");
+                static_for<0, 4>([&](auto I) {
+                    constexpr int r = r0 + decltype(I)::value;
+                    constexpr uint32_t roff = (uint32_t)(t * 32 + (r & 3) + 8 * (r >> 2));
+                    const float v = pa[t][r];
+                    if (v > st.thr) {
+                        *reinterpret_cast<float *>(smem + st.aw) = v;
+                        *reinterpret_cast<uint32_t *>(smem + st.aw + Ops::ROW_OFF) = rowbase + roff;
+                        st.aw += st.inc;
+                    }
+                });
+            }
+            if constexpr ((4 * g + 3) % CO_CHECK_EVERY == CO_CHECK_EVERY - 1) {
+                if (__builtin_amdgcn_ballot_w64(Ops::used(st, h) > CO_QUOTA) != 0ull)
+                    Ops::check(st, lane, smem, wave_qbase, wave_scratch, false, CO_LIMIT, STAMPS ? st_comp : nullptr, CO_QUOTA);
             }
         };
 
         // prologue: stages 0..S-2 in flight, stage 0 published, its first fragments read
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (query fragment loads: the vmcnt accounting starts from zero)
 #pragma unroll
-        for (int p = 0; p < S - 1; ++p) issue_stage(p / KS, p % KS, p % S);
+        for (int p = 0; p < S - 2; ++p) issue_stage(p / KS, p % KS, p % S);
+        if constexpr (DMA_SLOTS) {   // stage S-2: the first half of its window (slots 0..7) here, the rest in stage 0's first half
+            static_for<0, 8>([&](auto J) { issue_slot(J, (S - 2) / KS, (S - 2) % KS, (S - 2) % S); });
+        } else {
+            issue_stage((S - 2) / KS, (S - 2) % KS, (S - 2) % S);
+        }
         half8 afn[4], bfn[4];
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(4 * (S - 2)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(DMA_SLOTS ? 4 * (S - 3) + 2 : 4 * (S - 2)) : "memory");
         read_frags(afn, 0, 0);
         if constexpr (PF2) read_frags(bfn, 0, 1);
         if constexpr (STAMPS) ICD_CF_STAMP(st_prev);
@@ -315,28 +368,45 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             static_for<0, KS>([&](auto KSI) {
                 constexpr int ks = decltype(KSI)::value;
                 constexpr int slot = ks % S, nslot = (ks + 1) % S;
-                auto mfma4 = [&](const half8 (&f)[4], int qi) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[t], qf[qi], acc[t], 0, 0, 0);
+                // (DMA_SLOTS: window slot base of the k-step's four MFMAs, -1 = none; the window opens at the mid-stage barrier)
+                auto mfma4 = [&](const half8 (&f)[4], int qi, auto BASE) {
+                    constexpr int base = decltype(BASE)::value;
+                    static_for<0, 4>([&](auto T) {
+                        constexpr int t = decltype(T)::value;
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[t], qf[qi], acc[t], 0, 0, 0);
+                        if constexpr (DMA_SLOTS && base >= 0) {
+                            // slots 0..7 carry stage g+S-1 (second half of stage g), slots 8..15 finish stage g+S-2 (first half)
+                            constexpr int nks = base < 8 ? ks + S - 1 : ks + S - 2;
+                            issue_slot(std::integral_constant<int, base + t>{}, tile + nks / KS, nks % KS, nks % S);
+                        }
+                    });
                 };
+                using NoSlot = std::integral_constant<int, -1>;
+                using Slot0 = std::integral_constant<int, DMA_SLOTS ? 0 : -1>;
+                using Slot4 = std::integral_constant<int, DMA_SLOTS ? 4 : -1>;
+                using Slot8 = std::integral_constant<int, DMA_SLOTS ? 8 : -1>;
+                using Slot12 = std::integral_constant<int, DMA_SLOTS ? 12 : -1>;
+                (void)sizeof(NoSlot);
                 // stage g = (tile, ks) was published by the previous mid-stage barrier; afn holds its k-step 0 (PF2: bfn its k-step 1)
                 half8 f1[4], f2[4], f3[4];
                 if constexpr (PF2) {
                     read_frags(f2, slot, 2);
-                    mfma4(afn, ks * 4 + 0);
+                    mfma4(afn, ks * 4 + 0, Slot8{});
                     read_frags(f3, slot, 3);
-                    mfma4(bfn, ks * 4 + 1);
+                    mfma4(bfn, ks * 4 + 1, Slot12{});
                 } else {
                     read_frags(f1, slot, 1);
-                    mfma4(afn, ks * 4 + 0);
+                    mfma4(afn, ks * 4 + 0, Slot8{});
                     read_frags(f2, slot, 2);
-                    mfma4(f1, ks * 4 + 1);
+                    mfma4(f1, ks * 4 + 1, Slot12{});
                 }
                 // pin: the reads go out before the MFMAs of the k-step in front of them
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                if constexpr (!DMA_SLOTS) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                }
                 // publish stage g+1: this wave's pieces of g+1 have landed when only the stages behind it are outstanding
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (STAMPS) {
@@ -359,22 +429,23 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                     asm volatile("global_load_dword %0, %1, off sc1" : "=v"(seen_early) : "v"(my_shared) : "memory");
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                {   // every wave is past stage g-1: its slot takes stage g+S-1
+                if constexpr (!DMA_SLOTS) {   // every wave is past stage g-1: its slot takes stage g+S-1
                     constexpr int nks = ks + S - 1;
                     issue_stage(tile + nks / KS, nks % KS, nks % S);
                 }
                 if constexpr (PF2) {
                     read_frags(afn, nslot, 0);
-                    mfma4(f2, ks * 4 + 2);
+                    mfma4(f2, ks * 4 + 2, Slot0{});
                     read_frags(bfn, nslot, 1);
-                    mfma4(f3, ks * 4 + 3);
+                    mfma4(f3, ks * 4 + 3, Slot4{});
                 } else {
                     read_frags(f3, slot, 3);
-                    mfma4(f2, ks * 4 + 2);
+                    mfma4(f2, ks * 4 + 2, Slot0{});
                     read_frags(afn, nslot, 0);
-                    mfma4(f3, ks * 4 + 3);
+                    mfma4(f3, ks * 4 + 3, Slot4{});
                 }
-                if constexpr (!DMA_SPREAD) {          // the four pieces in a burst behind the barrier
+                if constexpr (DMA_SLOTS) {
+                } else if constexpr (!DMA_SPREAD) {          // the four pieces in a burst behind the barrier
                     __builtin_amdgcn_sched_group_barrier(0x020, 4, 1);
                     __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
                     __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
@@ -402,7 +473,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             {
                 uint32_t seen;
                 if constexpr (EARLY_THR) {
-                    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(seen_early) : "i"(NOVM ? 0 : 4 * (S - 2)) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(seen_early) : "i"(NOVM ? 0 : (DMA_SLOTS ? 6 : 4 * (S - 2))) : "memory");
                     seen = seen_early;
                 } else {
                     seen = __hip_atomic_load(my_shared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -414,6 +485,8 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                     published = mine_key;
                 }
             }
+            unsigned long long ts_a = 0;
+            if constexpr (STAMPS) { ICD_CF_STAMP(ts_a); st_thr += ts_a - ts0; }
             // fused select of the finished tile (rows >= n exist only in the corpus's last tile)
             const int tile_row0 = (t0 + tile) * CO_BN;
             const uint32_t rowbase = (uint32_t)(tile_row0 + 4 * h);
@@ -443,7 +516,9 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                 const float thr0 = fminf(boot3, __uint_as_float(h ? sw[0] : sw[1]));
                 if (thr0 > st.thr) st.thr = thr0;   // (padding queries keep +inf)
             }
+            if constexpr (STAMPS) { unsigned long long ts_b; ICD_CF_STAMP(ts_b); st_boot += ts_b - ts_a; }
             if (tile_row0 + CO_BN > a.n) static_for<0, 64>([&](auto F) { filter_reg(acc, F, rowbase, std::true_type{}); });
+            else if constexpr (MAXTREE4) static_for<0, 16>([&](auto G) { filter_grp4(acc, G, rowbase); });
             else static_for<0, 64>([&](auto F) { filter_reg(acc, F, rowbase, std::false_type{}); });
             if constexpr (STAMPS) {
                 unsigned long long ts1;
@@ -483,7 +558,8 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     if constexpr (STAMPS) {
         if (lane == 0 && a.dbg) {
             unsigned long long *d = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
-            d[0] = st_vm; d[1] = st_bar; d[2] = st_body; d[3] = st_sel; d[4] = st_tiles;
+            d[0] = st_vm; d[1] = st_bar; d[2] = st_body; d[3] = st_sel; d[4] = st_tiles; d[5] = st_comp[0]; d[6] = st_comp[1];
+            d[7] = (st_thr << 32) | (st_boot & 0xffffffffull);
         }
     }
 }

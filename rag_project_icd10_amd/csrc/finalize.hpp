@@ -38,9 +38,11 @@ struct FinArgs {
     const float *queries;  // fp32 [*][dim]
     const float *corpus;   // fp32 [n][dim]
     int dim;
-    const float *qnorm;          // [query]
-    const unsigned char *qbad;   // [query] 1 = fp16 image unusable
-    float rmax, eps_rel;
+    const float *qnorm;          // [query] norm of the query's SCALED fp16 image (coarse_common.hpp)
+    const int *qexp;             // [query] its power-of-two scale exponent
+    const unsigned char *qbad;   // [query] 1 = fp16 image unusable (non-finite input)
+    float rmax, eps_rel;         // rmax: largest norm of the scaled corpus rows
+    int cexp;                    // the corpus's scale exponent
     int *nflag;    // fallback counter
     int *flagged;  // fallback list
     // level table
@@ -223,9 +225,11 @@ __global__ __launch_bounds__(256, (EWM == 1 && !DEEP) ? 7 : 1) void finalize_ker
     // issued first, consumed last: the query (rescoring operand) and its norm / usability flag travel while the
     // candidates are merged (a wave's life is a chain of dependent round trips; these need not be part of it)
     float qn_early = 0.0f;
+    int qexp_early = 0;
     unsigned char qbad_early = 0;
     if (RESCORE) {
         qn_early = a.qnorm[qidx];
+        qexp_early = a.qexp[qidx];
         qbad_early = a.qbad[qidx];
         const float *qsrc0 = a.queries + (size_t)qidx * a.dim;
         for (int d = lane * 4; d < a.dim; d += 256)
@@ -268,7 +272,14 @@ __global__ __launch_bounds__(256, (EWM == 1 && !DEEP) ? 7 : 1) void finalize_ker
             mine[e] = (e < EW && idx < nres) ? sorted[idx] : 0ull;
             coarse[e] = mine[e] != 0ull ? key_score(mine[e]) : -INFINITY;
         }
-        const float eps = a.eps_rel * qn_early * a.rmax;
+        // |coarse - canonical| <= eps for every row, in the coarse pass's scaled units 2^(qexp + cexp):
+        //   relative part: fp16 rounding of both operands (their images sit in fp16's normal range by construction; the
+        //   components that still underflow add at most 2^-25 sqrt(dim) (|q| + |c|), which both norms >= 1 turn into a
+        //   relative 3.3e-6: inside EPS_REL's margin) + fp32 accumulation of both chains;
+        //   absolute part: the canonical chain runs on the UNSCALED fp32 data, where a result in fp32's subnormal range
+        //   rounds to a multiple of 2^-149: <= dim * 2^-150 over the chain (2^-148 here), times the scale. For data
+        //   anywhere near unit norm this term is 0; for data scaled by ~1e-38 it takes over and nothing is certified.
+        const float eps = a.eps_rel * qn_early * a.rmax + ldexpf((float)a.dim, qexp_early + a.cexp - 148);
         bool certified;
         float L;
         if (nres >= k) {

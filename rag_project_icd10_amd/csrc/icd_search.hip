@@ -22,6 +22,7 @@ using namespace icd;
 namespace {
 
 thread_local std::string g_err = "";
+bool g_permute = true;   // test switch (icd_debug_set_permute): row order of the fp16 corpus copy
 
 int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -47,6 +48,18 @@ constexpr int COARSE_MAX_P = 32;     // P * KP <= FIN_MAX_CAND
 constexpr int NUM_EV = 6;
 constexpr int EV_RING = 128;         // profiled searches kept for icd_index_profile_summary
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device): every launcher keeps, per device, the
+// largest size it has configured and raises it when a launch needs more (two indexes of different dim share kernels).
+constexpr int MAX_DEVICES = 64;
+template <typename K>
+hipError_t ensure_dynamic_lds(K kern, int device, size_t bytes, int *configured /* [MAX_DEVICES] */) {
+    if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+    if ((size_t)configured[device] >= bytes) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) configured[device] = (int)bytes;
+    return e;
+}
+
 template <typename T>
 hipError_t dmalloc(T **p, size_t count) {
     return hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(count, 1) * sizeof(T));
@@ -62,7 +75,9 @@ struct icd_index {
     int dim = 0;
     int max_nq = 0, max_nq_pad = 0, max_k = 0;
     bool fast = false;
-    float rmax = 0.f;
+    float rmax = 0.f;        // largest row norm (unscaled; reported by icd_index_stats)
+    float rmax_scaled = 0.f; // largest norm of the scaled fp16 rows
+    int cexp = 0;            // fp16 corpus = fp32 corpus * 2^cexp
     int num_cu = 256;
     // corpus
     float *corpus = nullptr;
@@ -72,6 +87,7 @@ struct icd_index {
     float *qdev = nullptr;  // staging for host queries
     _Float16 *q16 = nullptr;
     float *qnorm = nullptr;
+    int *qexp = nullptr;
     unsigned char *qbad = nullptr;
     unsigned int *shared_thr = nullptr;   // [max_nq_pad] coarse pass: per-query threshold shared by its lists
     long long perm_mul = 0; int perm_mod = 0;   // row order of the fp16 corpus: position p holds row (p * perm_mul) mod perm_mod
@@ -105,7 +121,7 @@ bool valid(icd_index *idx) { return idx && idx->magic == 0x1CD10A3Du; }
 void free_all(icd_index *x) {
     if (!x) return;
     hipFree(x->corpus); hipFree(x->c16); hipFree(x->levels); hipFree(x->qdev); hipFree(x->q16);
-    hipFree(x->qnorm); hipFree(x->qbad); hipFree(x->shared_thr); hipFree(x->partc_s); hipFree(x->partc_r); hipFree(x->partc_b); hipFree(x->partx_s);
+    hipFree(x->qnorm); hipFree(x->qexp); hipFree(x->qbad); hipFree(x->shared_thr); hipFree(x->partc_s); hipFree(x->partc_r); hipFree(x->partc_b); hipFree(x->partx_s);
     hipFree(x->partx_r); hipFree(x->lists_s); hipFree(x->lists_r); hipFree(x->nflag); hipFree(x->flagged); hipFree(x->scratch_u32);
     hipFree(x->o_scores); hipFree(x->o_ids); hipFree(x->o_adj); hipFree(x->o_adj_raw);
     hipFree(x->o_adj_ids); hipFree(x->o_adj_lv);
@@ -146,11 +162,8 @@ template <int KP, int E, int NW>
 int launch_exact(icd_index *x, const ExactArgs &a, int mtiles, hipStream_t s) {
     auto kern = exact_topk_kernel<KP, E, NW>;
     const size_t lds = exact_lds_bytes<KP, E, NW>();
-    static thread_local int configured_dev = -1;
-    if (configured_dev != x->device) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured_dev = x->device;
-    }
+    static int configured[MAX_DEVICES] = {};   // (guarded by the caller's one-stream-per-handle contract; worst case a repeated call)
+    HIP_TRY(ensure_dynamic_lds(kern, x->device, (size_t)((int)lds), configured));
     hipLaunchKernelGGL(kern, dim3(mtiles * a.P), dim3(NW * 64), lds, s, a);
     HIP_TRY(hipGetLastError());
     return ICD_OK;
@@ -160,11 +173,8 @@ template <int D, int VAR = CF_PRODUCT_VAR>
 int launch_coarse_flat(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream_t s) {
     auto kern = coarse_flat_kernel<D, VAR>;
     constexpr int lds = cf_lds_bytes(VAR);
-    static thread_local int configured_dev = -1;
-    if (configured_dev != x->device) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        configured_dev = x->device;
-    }
+    static int configured[MAX_DEVICES] = {};   // (guarded by the caller's one-stream-per-handle contract; worst case a repeated call)
+    HIP_TRY(ensure_dynamic_lds(kern, x->device, (size_t)(lds), configured));
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, s, a);
     HIP_TRY(hipGetLastError());
     return ICD_OK;
@@ -204,11 +214,8 @@ int launch_stream(icd_index *x, const float *dq, const int *qlist, const int *nq
     auto kern = stream_topk_kernel<KP, E, QB>;
     const size_t lds = stream_lds_bytes<KP, E, QB>(x->dim, stages);
     if (lds > (size_t)LDS_LIMIT) return fail(ICD_ERR_INVALID, "stream kernel: dim=%d does not fit LDS with %d queries per pass", x->dim, QB);
-    static thread_local int configured_dev = -1;
-    if (configured_dev != x->device) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured_dev = x->device;
-    }
+    static int configured[MAX_DEVICES] = {};   // (guarded by the caller's one-stream-per-handle contract; worst case a repeated call)
+    HIP_TRY(ensure_dynamic_lds(kern, x->device, (size_t)((int)lds), configured));
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, s, a);
     HIP_TRY(hipGetLastError());
     ReduceArgs r{};
@@ -223,12 +230,8 @@ template <bool RESCORE, bool DEEP, int EWM>
 int launch_finalize_t(icd_index *x, const FinArgs &a, hipStream_t s) {
     auto kern = finalize_kernel<RESCORE, DEEP, EWM>;
     const size_t lds = 4 * fin_wave_lds_bytes(RESCORE, x->dim, a.lds_cand > 0 ? a.lds_cand : a.P * a.KP, EWM);
-    static thread_local int configured_dev = -1;
-    if (configured_dev != x->device) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(4 * fin_wave_lds_bytes(RESCORE, x->dim, FIN_MAX_CAND, EWM))));
-        configured_dev = x->device;
-    }
+    static int configured[MAX_DEVICES] = {};   // (guarded by the caller's one-stream-per-handle contract; worst case a repeated call)
+    HIP_TRY(ensure_dynamic_lds(kern, x->device, (size_t)((int)(4 * fin_wave_lds_bytes(RESCORE, x->dim, FIN_MAX_CAND, EWM))), configured));
     hipLaunchKernelGGL(kern, dim3((a.nq + 3) / 4), dim3(256), lds, s, a);
     HIP_TRY(hipGetLastError());
     return ICD_OK;
@@ -273,7 +276,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
 
     FinArgs f{};
     f.k = k; f.queries = dq; f.corpus = x->corpus; f.dim = x->dim; f.qnorm = x->qnorm; f.qbad = x->qbad;
-    f.rmax = x->rmax; f.eps_rel = EPS_REL; f.nflag = x->nflag; f.flagged = x->flagged;
+    f.qexp = x->qexp; f.rmax = x->rmax_scaled; f.cexp = x->cexp; f.eps_rel = EPS_REL; f.nflag = x->nflag; f.flagged = x->flagged;
     f.levels = x->levels; f.id_base = x->id_base;
     f.out_scores = o.scores; f.out_ids = o.ids; f.out_adj = o.adj; f.out_adj_raw = o.adj_raw;
     f.out_adj_ids = o.adj_ids; f.out_adj_levels = o.adj_lv;
@@ -382,8 +385,8 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     // ---- AUTO: prep -> coarse -> finalize(certify + rescore) -> exact fallback ------------------
     const int nq_pad = ((nq + 127) / 128) * 128;
     ConvertArgs cv{};
-    cv.src = dq; cv.dst = x->q16; cv.rows = nq; cv.rows_pad = nq_pad; cv.dim = x->dim;
-    cv.norm = x->qnorm; cv.bad = x->qbad; cv.zero_u32 = x->shared_thr;
+    cv.src = dq; cv.dst = x->q16; cv.rows = nq; cv.rows_pad = nq_pad; cv.dim = x->dim; cv.mode = 0;
+    cv.norm = x->qnorm; cv.scale_exp = x->qexp; cv.bad = x->qbad; cv.zero_u32 = x->shared_thr;
     hipLaunchKernelGGL(convert_rows_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, s, cv);
     HIP_TRY(hipGetLastError());
     rec(x, 1, s);
@@ -457,14 +460,14 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         x->last_chunks = P;
         const int nwg = (a.total_units + U - 1) / U;
         int rc;
-        if (x->dim == 1024) rc = launch_coarse_flat<1024>(x, a, nwg, s);
+        // (dim 1024: the query fragments alone are 256 registers: no pinning and no deeper fragment prefetch there)
+        if (x->dim == 1024) rc = launch_coarse_flat<1024, (CF_PRODUCT_VAR & 3)>(x, a, nwg, s);
 #ifdef ICD_ABLATE
         else if (const char *fv = getenv("ICD_FLAT_VAR")) {   // A/B builds: stage / select variants of the flat kernel
             const int v = atoi(fv);
             if (false) {}
 #define ICD_FV_CASE(V) else if (v == V) rc = launch_coarse_flat<768, V>(x, a, nwg, s);
-            ICD_FV_CASE(0) ICD_FV_CASE(11) ICD_FV_CASE(11 + 32) ICD_FV_CASE(11 + 64) ICD_FV_CASE(11 + 128) ICD_FV_CASE(11 + 64 + 128)
-            ICD_FV_CASE(11 + 256) ICD_FV_CASE(11 + 512) ICD_FV_CASE(11 + 256 + 512) ICD_FV_CASE(11 + 1024) ICD_FV_CASE(11 + 64 + 1024)
+            ICD_FV_CASE(0) ICD_FV_CASE(CF_PRODUCT_VAR) ICD_FV_CASE(CF_PRODUCT_VAR + 1024)
 #undef ICD_FV_CASE
             else return fail(ICD_ERR_INVALID, "ICD_FLAT_VAR=%d is not built", v);
         }
@@ -486,7 +489,14 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     // a sparse list (<= ST_MAX_ACTIVE queries), the fp32-MFMA kernel for a dense one. Both leave
     // [slot][p_sparse][KP] lists for the same finalize launch.
     int px = std::min(p_sparse, row_tiles);
-    if (px < p_sparse) return run_exact(x->flagged, x->nflag, px, true, false);   // tiny corpus: MFMA kernel only
+    if (px < p_sparse) {   // tiny corpus: MFMA kernel only. EVERY query may be flagged (all-zero queries, duplicate rows):
+        // the list count is sized against the workspace like a full exact run
+        px = fit_p(px, x->partx_cap, kpx);
+        if ((size_t)nq * px * kpx > x->partx_cap) return fail(ICD_ERR_INVALID, "workspace too small for nq=%d k=%d", nq, k);
+        const int tiles_per = (row_tiles + px - 1) / px;
+        px = (row_tiles + tiles_per - 1) / tiles_per;
+        return run_exact(x->flagged, x->nflag, px, true, false);
+    }
     return run_exact(x->flagged, x->nflag, p_sparse, true, stream_ok);
 }
 
@@ -562,23 +572,34 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
         // Row order of the fp16 copy: a corpus in code order keeps families of near-identical rows next to each
         // other, so ONE candidate list would collect a query's whole family, end on a bound inside it and fail the
         // certificate. An affine permutation with a golden-ratio stride spreads neighbours evenly over the lists;
-        // finalize maps list positions back with the same formula (no table). ICD_NO_PERMUTE=1 keeps the order (A/B).
-        if (n > 2 && !getenv("ICD_NO_PERMUTE")) {
+        // finalize maps list positions back with the same formula (no table). (icd_debug_set_permute(0) keeps the order:
+        // a process-wide test switch, read at create; results are identical either way.)
+        if (n > 2 && g_permute) {
             long long a_ = (long long)(0.6180339887498949 * (double)n) | 1;
             auto gcd = [](long long u, long long v) { while (v) { const long long t = u % v; u = v; v = t; } return u; };
             while (gcd(a_, n) != 1) a_ += 2;
             x->perm_mul = a_ % n; x->perm_mod = (int)n;
         }
+        // pass 1: largest component of the corpus -> ONE power-of-two scale for its fp16 image; pass 2: convert
         ConvertArgs cv{};
         cv.src = x->corpus; cv.dst = x->c16; cv.rows = (int)n; cv.rows_pad = x->n_pad; cv.dim = dim;
-        cv.rmax_bits = x->scratch_u32; cv.any_bad = x->scratch_u32 + 1;
+        cv.amax_bits = x->scratch_u32 + 2; cv.any_bad = x->scratch_u32 + 1; cv.mode = 2;
+        hipLaunchKernelGGL(convert_rows_kernel, dim3((x->n_pad + 3) / 4), dim3(256), 0, 0, cv);
+        CR_TRY(hipGetLastError());
+        unsigned hv[3] = {0, 0, 0};
+        CR_TRY(hipMemcpy(hv, x->scratch_u32, sizeof hv, hipMemcpyDeviceToHost));
+        float amax = 0.f;
+        memcpy(&amax, &hv[2], 4);
+        x->cexp = scale_exp_for(amax);
+        cv.mode = 1; cv.fixed_exp = x->cexp; cv.amax_bits = nullptr;
+        cv.rmax_bits = x->scratch_u32;
         cv.perm_mul = x->perm_mul; cv.perm_mod = x->perm_mod;
         hipLaunchKernelGGL(convert_rows_kernel, dim3((x->n_pad + 3) / 4), dim3(256), 0, 0, cv);
         CR_TRY(hipGetLastError());
-        unsigned hv[2] = {0, 0};
         CR_TRY(hipMemcpy(hv, x->scratch_u32, sizeof hv, hipMemcpyDeviceToHost));
-        memcpy(&x->rmax, &hv[0], 4);
-        x->fast = (hv[1] == 0) && std::isfinite(x->rmax);
+        memcpy(&x->rmax_scaled, &hv[0], 4);
+        x->rmax = ldexpf(x->rmax_scaled, -x->cexp);
+        x->fast = (hv[1] == 0) && std::isfinite(x->rmax_scaled);
         if (!x->fast) { hipFree(x->c16); x->c16 = nullptr; }
     }
     if (x->fast) {
@@ -590,6 +611,7 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
         CR_TRY(wsalloc(&x->partc_b, x->partc_cap / CO_KP));
     }
     CR_TRY(wsalloc(&x->qnorm, (size_t)x->max_nq_pad));
+    CR_TRY(wsalloc(&x->qexp, (size_t)x->max_nq_pad));
     CR_TRY(wsalloc(&x->qbad, (size_t)x->max_nq_pad));
     CR_TRY(wsalloc(&x->shared_thr, (size_t)x->max_nq_pad));
     CR_TRY(wsalloc(&x->qdev, (size_t)max_nq * dim));
@@ -702,11 +724,8 @@ int icd_merge_topk(int32_t device, const float *scores, const int64_t *ids, cons
     a.G = G; a.nq = (int)nq; a.k = k;
     a.out_adj = out_adj; a.out_raw = out_raw; a.out_ids = reinterpret_cast<long long *>(out_ids); a.out_levels = out_levels;
     const size_t lds = 4 * (1024 * 16 + 128 * 24);
-    static thread_local int configured_dev = -1;
-    if (configured_dev != device) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(merge_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured_dev = device;
-    }
+    static int configured[MAX_DEVICES] = {};   // (guarded by the caller's one-stream-per-handle contract; worst case a repeated call)
+    HIP_TRY(ensure_dynamic_lds(merge_topk_kernel, device, (size_t)((int)lds), configured));
     hipLaunchKernelGGL(merge_topk_kernel, dim3(((int)nq + 3) / 4), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a);
     HIP_TRY(hipGetLastError());
     return ICD_OK;
@@ -737,6 +756,11 @@ int icd_index_stats(icd_index *idx, icd_stats *out) {
     out->last_nq = idx->last_nq;
     out->last_fallback = idx->h_nflag ? *idx->h_nflag : 0;
     out->last_chunks = idx->last_chunks; out->last_mode = idx->last_mode;
+    return ICD_OK;
+}
+
+int icd_debug_set_permute(int32_t enabled) {
+    g_permute = enabled != 0;
     return ICD_OK;
 }
 

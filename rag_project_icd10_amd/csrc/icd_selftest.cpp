@@ -162,10 +162,13 @@ static void bench(int64_t n, int64_t nq, int dim, int k, int iters, int chunks, 
     if (getenv("ICD_FLAT_VAR") && (atoi(getenv("ICD_FLAT_VAR")) & 1024)) {
         std::vector<unsigned long long> c(8192);
         CHECK_RC(icd_index_debug_counters(idx, c.data(), (int)c.size()));
-        double vm = 0, bar = 0, body = 0, sel = 0, tiles = 0; int cnt = 0;
-        for (size_t i = 0; i + 7 < c.size(); i += 8) if (c[i + 4]) { vm += c[i]; bar += c[i + 1]; body += c[i + 2]; sel += c[i + 3]; tiles += c[i + 4]; ++cnt; }
-        printf("   stamps (avg per wave over %d waves, cycles per tile): dma wait=%.0f barrier=%.0f body=%.0f select=%.0f tiles/wave=%.1f\n",
-               cnt, vm / tiles, bar / tiles, body / tiles, sel / tiles, tiles / cnt);
+        double vm = 0, bar = 0, body = 0, sel = 0, tiles = 0, nc = 0, cc = 0, thr = 0, boot = 0; int cnt = 0;
+        for (size_t i = 0; i + 7 < c.size(); i += 8) if (c[i + 4]) {
+            vm += c[i]; bar += c[i + 1]; body += c[i + 2]; sel += c[i + 3]; tiles += c[i + 4]; nc += c[i + 5]; cc += c[i + 6];
+            thr += (double)(c[i + 7] >> 32); boot += (double)(c[i + 7] & 0xffffffffull); ++cnt;
+        }
+        printf("   stamps (avg per wave over %d waves, cycles per tile): dma wait=%.0f barrier=%.0f body=%.0f select=%.0f (thr exchange %.0f, bootstrap %.0f, compactions %.2f x %.0f = %.0f) tiles/wave=%.1f\n",
+               cnt, vm / tiles, bar / tiles, body / tiles, sel / tiles, thr / tiles, boot / tiles, nc / tiles, nc ? cc / nc : 0.0, cc / tiles, tiles / cnt);
     }
     if (verify) {
         // parity of a query sample of the big run against the oracle (AUTO mode)

@@ -8,7 +8,7 @@ O=$GRAFT_REPO_ROOT/gpurun_out/ab_flat.log
 for rep in $(seq $ROUNDS); do
   for v in $VARS; do
     echo "### VAR=$v" >> $O
-    ICD_FLAT_VAR=$v timeout 120 ./icd_selftest --oracle $GRAFT_REPO_ROOT/oracle/libicd_oracle.so --skip-cases --bench --iters 20 2>&1 | grep -E "mode=auto|parity|FAIL" >> $O
+    ICD_FLAT_VAR=$v timeout 120 ./icd_selftest --oracle $GRAFT_REPO_ROOT/oracle/libicd_oracle.so --skip-cases --bench --iters 20 2>&1 | grep -E "mode=auto|parity|FAIL|stamps" >> $O
   done
 done
 cat $O

@@ -5,7 +5,8 @@
 
 Every case draws (rows, queries, dim, k, data kind, mode, id_base), searches through the C ABI and compares ids (exact),
 scores (bit-identical) and the reweighted outputs with oracle/ on a query sample. Data kinds: gaussian unit rows,
-clustered rows (near ties: forces the exact fallback), rows with exact duplicates, a batch whose fp16 image overflows.
+clustered rows (near ties: forces the exact fallback), rows with exact duplicates, a batch whose fp16 image overflows,
+corpora and batches scaled far below fp16's normal range ("tiny").
 """
 import argparse
 import os
@@ -48,13 +49,18 @@ def main():
         n = int(rng.choice([1, 7, 127, 128, 129, 1000, 4097, 20000, 37000, 100003]))
         nq = int(rng.choice([1, 2, 9, 16, 17, 64, 65, 128, 129, 1000, 3000]))
         k = int(rng.choice([1, 5, 10, 10, 10, 12, 13, 50, 100]))
-        kind = str(rng.choice(["gauss", "gauss", "clustered", "dups", "overflow", "zeros", "scaled"]))
+        kind = str(rng.choice(["gauss", "gauss", "clustered", "dups", "overflow", "zeros", "scaled", "tiny", "tiny"]))
         mode = MODE_AUTO if rng.random() < 0.8 else MODE_EXACT
         id_base = int(rng.choice([0, 0, 5_000_000_000]))
         if n * dim > 100003 * 768 or (n >= 100000 and nq > 1000):
             nq = min(nq, 1000)
-        corpus = rows(rng, n, dim, "gauss" if kind in ("overflow", "zeros", "scaled") else kind)
-        queries = rows(rng, nq, dim, "gauss" if kind in ("overflow", "dups", "zeros", "scaled") else kind)
+        corpus = rows(rng, n, dim, "gauss" if kind in ("overflow", "zeros", "scaled", "tiny") else kind)
+        queries = rows(rng, nq, dim, "gauss" if kind in ("overflow", "dups", "zeros", "scaled", "tiny") else kind)
+        if kind == "tiny":        # whole corpus / batch far below fp16's normal range (2^-14), or only parts of them
+            corpus *= np.float32(10.0 ** rng.uniform(-30, -4))
+            if rng.random() < 0.5:
+                corpus[rng.random(n) < 0.5] *= np.float32(1e-5)
+            queries *= (10.0 ** rng.uniform(-8, 0, (nq, 1))).astype(np.float32)
         if kind == "zeros":       # all-zero queries and rows: every score ties at 0, ids must come out row-ascending
             queries[rng.random(nq) < 0.3] = 0.0
             corpus[rng.random(n) < 0.2] = 0.0

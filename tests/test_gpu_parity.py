@@ -151,7 +151,7 @@ def _family_corpus(nfam, per, dim, seed):
     return np.ascontiguousarray(x, dtype=np.float32), np.ascontiguousarray(q, dtype=np.float32)
 
 
-def test_corpus_in_code_order_stays_on_the_fast_path(oracle, monkeypatch):
+def test_corpus_in_code_order_stays_on_the_fast_path(oracle):
     """A query's whole family is contiguous in the corpus. The fp16 copy is stored in a permuted row order so the family
     spreads over the candidate lists; without it one list holds the family, ends on a bound inside it and the
     certificate fails for most queries (results stay exact either way)."""
@@ -161,10 +161,14 @@ def test_corpus_in_code_order_stays_on_the_fast_path(oracle, monkeypatch):
     st = _check(oracle, idx, corpus, levels, queries, 10, MODE_AUTO)
     idx.close()
     assert st["last_mode"] == MODE_AUTO and st["last_fallback"] <= 256 // 8
-    monkeypatch.setenv("ICD_NO_PERMUTE", "1")
-    idx = IcdIndex(corpus, levels, max_nq=256, max_k=10)
-    st2 = _check(oracle, idx, corpus, levels, queries, 10, MODE_AUTO)
-    idx.close()
+    from rag_project_icd10_amd import _native
+    _native.load_library().icd_debug_set_permute(0)   # test switch: fp16 copy in row order
+    try:
+        idx = IcdIndex(corpus, levels, max_nq=256, max_k=10)
+        st2 = _check(oracle, idx, corpus, levels, queries, 10, MODE_AUTO)
+        idx.close()
+    finally:
+        _native.load_library().icd_debug_set_permute(1)
     assert st2["last_fallback"] >= st["last_fallback"]
 
 
@@ -219,14 +223,74 @@ def test_unnormalised_and_nonfinite_inputs(oracle):
     queries = (rng.standard_normal((33, 768)) * 5).astype(np.float32)
     idx = IcdIndex(corpus, levels, max_nq=64, max_k=10)
     _check(oracle, idx, corpus, levels, queries, 10, MODE_AUTO)   # error bound scales with ||q|| * rmax
-    queries[3, 10] = 1e6                                          # not representable in fp16 -> exact fallback
-    st = _check(oracle, idx, corpus, levels, queries, 10, MODE_AUTO)
-    assert st["last_fallback"] >= 1
+    queries[3, 10] = 1e6                                          # beyond fp16's range: the query's own power-of-two scale absorbs it
+    _check(oracle, idx, corpus, levels, queries, 10, MODE_AUTO)
     idx.close()
-    corpus[17, 5] = 7e4                                           # corpus not representable in fp16
+    corpus[17, 5] = 7e4                                           # beyond fp16's range: the corpus scale absorbs it
+    idx = IcdIndex(corpus, levels, max_nq=64, max_k=10)
+    assert idx.stats()["fast_path"] == 1
+    _check(oracle, idx, corpus, levels, queries[:5], 10, MODE_AUTO)
+    idx.close()
+    corpus[18, 6] = np.nan                                        # non-finite corpus: no fp16 copy, exact kernels only
     idx = IcdIndex(corpus, levels, max_nq=64, max_k=10)
     assert idx.stats()["fast_path"] == 0
-    _check(oracle, idx, corpus, levels, queries[:8], 10, MODE_AUTO)
+    _check(oracle, idx, corpus, levels, queries[:5], 10, MODE_AUTO)
+    idx.close()
+
+
+@pytest.mark.parametrize("cscale,qscale", [(1e-5, 1.0), (1e-6, 1.0), (1e-30, 1e-6), (1.0, 1e-6), (1e-3, 1e-5), (1e12, 1e10), (3e-38, 1.0)])
+def test_tiny_and_huge_norms_stay_exact(oracle, cscale, qscale):
+    """The fp16 images are power-of-two scaled (queries per row, the corpus as a whole), so data far below fp16's normal
+    range (2^-14) or above its largest value keeps 11 significant bits and the certificate's relative error bound holds;
+    round 1 converted unscaled and certified wrong top-k for a corpus scaled by 1e-5. Near fp32's own underflow
+    (3e-38) the canonical chain itself rounds on the subnormal grid: the bound's absolute term takes over, nothing is
+    certified, results still come from the exact kernels."""
+    corpus, levels = unit_rows(20000, 768, 500) * np.float32(cscale), icd_levels(20000, 501)
+    queries = unit_rows(300, 768, 502) * np.float32(qscale)
+    idx = IcdIndex(corpus, levels, max_nq=300, max_k=10)
+    assert idx.stats()["fast_path"] == 1
+    st = _check(oracle, idx, corpus, levels, queries, 10, MODE_AUTO)
+    assert st["last_mode"] == MODE_AUTO
+    if cscale * qscale > 1e-30:
+        assert st["last_fallback"] <= 30                     # certified on the fast path, not rescued by the fallback
+    _check(oracle, idx, corpus, levels, queries[:5], 10, MODE_AUTO)
+    idx.close()
+
+
+def test_mixed_magnitudes_within_one_corpus_and_batch(oracle):
+    """only SOME rows / queries are tiny: the corpus scale comes from its largest component, so the tiny rows' fp16
+    images do sink into the subnormal range - covered by the bound's absolute term relative to the scaled norms"""
+    rng = np.random.default_rng(510)
+    corpus, levels = unit_rows(20000, 768, 511), icd_levels(20000, 512)
+    corpus[::3] *= np.float32(1e-6)
+    corpus[1::7] *= np.float32(1e-3)
+    corpus[:, :96] *= np.float32(1e-5)                        # subnormal-sized components inside normal rows
+    queries = unit_rows(400, 768, 513) * (10.0 ** rng.uniform(-6, 2, (400, 1))).astype(np.float32)
+    queries[::5] *= -1.0
+    idx = IcdIndex(corpus, levels, max_nq=400, max_k=10)
+    st = _check(oracle, idx, corpus, levels, queries, 10, MODE_AUTO)
+    assert st["last_mode"] == MODE_AUTO and st["fast_path"] == 1
+    _check(oracle, idx, corpus, levels, queries, 5, MODE_EXACT)
+    idx.close()
+
+
+def test_every_query_flagged_on_a_small_corpus_fits_the_workspace():
+    """n < 4096 rows, a full batch of all-zero queries (every score ties at 0 -> every query fails the
+    certificate): the fallback's fp32-MFMA kernel runs over the whole batch and its list count must be sized against
+    the workspace (it used to write nq * 24 * 16 entries into a 2 M-entry buffer)."""
+    n, nq, k = 3000, 16384, 10
+    corpus, levels = unit_rows(n, 768, 520), icd_levels(n, 521)
+    idx = IcdIndex(corpus, levels, max_nq=nq, max_k=k)
+    queries = np.zeros((nq, 768), np.float32)
+    queries[::1000] = unit_rows(17, 768, 522)
+    s, i = idx.search(queries, k, MODE_AUTO)
+    st = idx.stats()
+    zero = np.ones(nq, bool)
+    zero[::1000] = False
+    assert (s[zero] == 0).all() and (i[zero] == np.arange(k)).all()          # ties: row id ascending
+    assert st["last_fallback"] >= zero.sum()
+    s2, i2 = idx.search(queries[::1000], k, MODE_EXACT)
+    assert np.array_equal(i[::1000], i2) and _bits(s[::1000]) == _bits(s2)
     idx.close()
 
 
