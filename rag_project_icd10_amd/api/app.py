@@ -14,8 +14,11 @@ from contextlib import asynccontextmanager
 
 from fastapi import FastAPI, HTTPException
 
+from ..dotenv_lite import load_dotenv
 from .icd_models import (DiagnosisMatch, EmbeddingRequest, EmbeddingResponse, HealthCheckResponse,
                          QueryRequest, QueryResponse, convert_numpy_types)
+
+load_dotenv()   # main.py:11 of the reference; existing environment variables win
 
 logger = logging.getLogger(__name__)
 

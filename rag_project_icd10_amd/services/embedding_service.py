@@ -29,6 +29,9 @@ from typing import Any, Dict, List, Optional
 import numpy as np
 import torch
 
+from ..dotenv_lite import load_dotenv
+
+load_dotenv()   # the reference does this at import (python-dotenv); existing environment variables win
 logger = logging.getLogger(__name__)
 
 DEFAULT_MODEL = "intfloat/multilingual-e5-large-instruct"  # reference default (:26)
@@ -50,18 +53,67 @@ class _CharTokenizer:
 
 
 class _Encoder(torch.nn.Module):
-    """HF BertModel + masked mean pooling + L2 normalisation."""
+    """HF BertModel + pooling (masked mean, or the [CLS] token) + L2 normalisation."""
 
-    def __init__(self, bert):
+    def __init__(self, bert, pooling: str = "mean"):
         super().__init__()
         self.bert = bert
+        self.pooling = pooling
 
     @torch.no_grad()
     def forward(self, input_ids, attention_mask):
         hidden = self.bert(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state
-        mask = attention_mask.unsqueeze(-1).to(hidden.dtype)
-        pooled = (hidden * mask).sum(1) / mask.sum(1).clamp(min=1e-9)
+        if self.pooling == "cls":
+            pooled = hidden[:, 0]
+        else:
+            mask = attention_mask.unsqueeze(-1).to(hidden.dtype)
+            pooled = (hidden * mask).sum(1) / mask.sum(1).clamp(min=1e-9)
         return torch.nn.functional.normalize(pooled.float(), p=2, dim=1)
+
+
+class UnsupportedPoolingError(ValueError):
+    """the checkpoint asks for a sentence-transformers pooling mode this restatement does not implement"""
+
+
+def _sentence_transformers_config(name: str) -> Dict[str, Any]:
+    """What SentenceTransformer(name) would read next to the weights: `sentence_bert_config.json` (max_seq_length) and the
+    pooling module's config.json (modules.json names its directory, `1_Pooling` by convention). Returns {} when the
+    model is not a local sentence-transformers checkpoint. Raises on a pooling mode this restatement does not implement
+    (the embeddings would silently differ from the reference's)."""
+    import json
+    base = name if os.path.isdir(name) else None
+    if base is None:
+        try:
+            from huggingface_hub import snapshot_download
+            base = snapshot_download(name, local_files_only=True)
+        except Exception:
+            return {}
+    out: Dict[str, Any] = {}
+    sb = os.path.join(base, "sentence_bert_config.json")
+    if os.path.exists(sb):
+        with open(sb, encoding="utf-8") as f:
+            msl = json.load(f).get("max_seq_length")
+        if msl:
+            out["max_seq_length"] = int(msl)
+    pool_dir = "1_Pooling"
+    mods = os.path.join(base, "modules.json")
+    if os.path.exists(mods):
+        with open(mods, encoding="utf-8") as f:
+            for m in json.load(f):
+                if str(m.get("type", "")).endswith("Pooling"):
+                    pool_dir = m.get("path", pool_dir)
+    pc = os.path.join(base, pool_dir, "config.json")
+    if os.path.exists(pc):
+        with open(pc, encoding="utf-8") as f:
+            cfg = json.load(f)
+        on = sorted(k for k, v in cfg.items() if k.startswith("pooling_mode_") and v is True)
+        if on == ["pooling_mode_mean_tokens"]:
+            out["pooling"] = "mean"
+        elif on == ["pooling_mode_cls_token"]:
+            out["pooling"] = "cls"
+        else:
+            raise UnsupportedPoolingError(f"unsupported sentence-transformers pooling {on} in {pc}: only mean_tokens and cls_token are implemented")
+    return out
 
 
 class EmbeddingService:
@@ -107,6 +159,11 @@ class EmbeddingService:
             tok = AutoTokenizer.from_pretrained(name, local_files_only=True)
             bert = AutoModel.from_pretrained(name, local_files_only=True)
             self.max_seq_length = int(min(getattr(tok, "model_max_length", 512), 512))
+            st_cfg = _sentence_transformers_config(name)   # raises on an unsupported pooling mode (never synthetic then)
+            self.max_seq_length = int(st_cfg.get("max_seq_length", self.max_seq_length))
+            pooling = st_cfg.get("pooling", "mean")
+        except UnsupportedPoolingError:
+            raise
         except Exception as exc:
             if not self._allow_synthetic:
                 logger.error("模型加载失败: %s", exc)
@@ -122,10 +179,12 @@ class EmbeddingService:
             tok = None
             self.synthetic = True
             self.max_seq_length = 128
+            pooling = "mean"
         self._tokenizer = tok
         self._char_tok = _CharTokenizer(bert.config.vocab_size, self.max_seq_length) if tok is None else None
         dtype = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[os.getenv("ICD_EMBEDDING_DTYPE", "fp32")]
-        self.model = _Encoder(bert).eval().to(self.device)
+        self.pooling = pooling
+        self.model = _Encoder(bert, pooling).eval().to(self.device)
         if dtype != torch.float32:
             self.model.bert.to(dtype)
         self._dim = int(bert.config.hidden_size)
@@ -251,6 +310,7 @@ class EmbeddingService:
             "max_seq_length": self.max_seq_length,
             "embedding_dimension": self._dim,
             "synthetic": self.synthetic,
+            "pooling": self.pooling,
         }
 
     def test_embedding(self, test_text: str = "测试文本") -> Dict[str, Any]:

@@ -19,6 +19,9 @@ from typing import Any, Dict, List
 
 import numpy as np
 
+from ..dotenv_lite import load_dotenv
+
+load_dotenv()   # the reference does this at import (python-dotenv); existing environment variables win
 logger = logging.getLogger(__name__)
 
 

@@ -1,0 +1,73 @@
+"""Encoder on ROCm against the same seeded weights on the CPU in fp32 (rows a3-a5 of SURVEY.md section 8): the three
+ways a string reaches the GPU forward - encode_query (one string, the replayed HIP-graph bucket), encode_batch (batch 32,
+`/embed`), encode_query_batch (batch 256, length-sorted, the corpus build) - must give the embedding the plain eager CPU
+forward gives: max |delta| <= 1e-5 per component, unit norms. Weights are the seeded synthetic BERT-base (no checkpoint
+offline: numerical parity with sentence-transformers itself stays unpinned)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def services():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    os.environ["EMBEDDING_MODEL_NAME"] = "shibing624/text2vec-base-chinese"
+    os.environ.pop("ICD_EMBEDDING_DTYPE", None)
+    from rag_project_icd10_amd.services.embedding_service import EmbeddingService
+    gpu = EmbeddingService(allow_synthetic=True, device="cuda")
+    cpu = EmbeddingService(allow_synthetic=True, device="cpu")
+    for (n1, p1), (n2, p2) in zip(gpu.model.state_dict().items(), cpu.model.state_dict().items()):
+        assert n1 == n2 and torch.equal(p1.cpu(), p2)                    # same seeded weights on both devices
+    return gpu, cpu
+
+
+def _strings():
+    texts = [l.rstrip("\n") for l in open(os.path.join(GOLDEN, "diagnosis_strings.txt"), encoding="utf-8")][:300]
+    return texts + ["", " ", "肺", "x" * 128, "高血压" * 60, "Possible 肺炎?"]   # empty, one token, > max_seq_length
+
+
+def test_encode_query_graph_bucket_matches_cpu(services):
+    gpu, cpu = services
+    for t in _strings()[:40] + _strings()[-6:]:
+        a, b = gpu.encode_query(t), cpu.encode_query(t)
+        assert a.shape == (768,) and a.dtype == np.float32
+        assert np.max(np.abs(a - b)) <= TOL, t
+        assert abs(np.linalg.norm(a) - 1.0) <= 1e-5
+    assert gpu._graphs, "the one-string path should have captured a HIP graph"
+    again = gpu.encode_query(_strings()[3])                                # a replay gives the same bits as the first replay
+    assert np.array_equal(again, gpu.encode_query(_strings()[3]))
+
+
+def test_encode_batch_32_matches_cpu(services):
+    gpu, cpu = services
+    texts = _strings()[:100] + _strings()[-6:]
+    a = np.asarray(gpu.encode_batch(texts, show_progress=False), dtype=np.float64)
+    b = np.asarray(cpu.encode_batch(texts, show_progress=False), dtype=np.float64)
+    assert a.shape == (len(texts), 768)
+    assert np.max(np.abs(a - b)) <= TOL
+    assert np.max(np.abs(np.linalg.norm(a, axis=1) - 1.0)) <= 1e-5
+    one = gpu.encode_single(texts[7])                                      # batching does not change a row
+    assert np.max(np.abs(one - a[7])) <= TOL
+
+
+def test_encode_query_batch_256_matches_cpu_and_stays_on_device(services):
+    import torch
+    gpu, cpu = services
+    texts = _strings()
+    dev = gpu.encode_query_batch(texts, batch_size=256, to_device=True)
+    assert dev.is_cuda and dev.dtype == torch.float32 and dev.shape == (len(texts), 768)
+    a = dev.cpu().numpy()
+    b = cpu.encode_query_batch(texts, batch_size=256)
+    assert np.max(np.abs(a - b)) <= TOL
+    assert np.max(np.abs(np.linalg.norm(a, axis=1) - 1.0)) <= 1e-5
+    for i in (0, 17, len(texts) - 6, len(texts) - 3):                      # the batch row == the one-at-a-time call
+        assert np.max(np.abs(a[i] - gpu.encode_query(texts[i]))) <= TOL

@@ -112,7 +112,7 @@ def test_dense_fallback_list_takes_the_mfma_exact_kernel(oracle):
     100 of them: stream_topk in 13 passes of 8"""
     corpus, levels = unit_rows(3000, 768, 95), icd_levels(3000, 96)
     queries = unit_rows(900, 768, 97)
-    queries[::3, 11] = 1e6        # 300 queries whose fp16 image overflows
+    queries[::3] = 0.0            # 300 all-zero queries: every score ties at 0, the certificate cannot separate a top-k
     idx = IcdIndex(corpus, levels, max_nq=900, max_k=10)
     st = _check(oracle, idx, corpus, levels, queries, 10, MODE_AUTO)
     assert st["last_fallback"] == 300
@@ -122,11 +122,11 @@ def test_dense_fallback_list_takes_the_mfma_exact_kernel(oracle):
 
 
 def test_every_query_flagged_in_a_large_batch(oracle):
-    """all 6000 queries fail certification (fp16 image overflows): the dense fallback's partial lists must be sized
-    for the whole batch (its list count is fitted to the workspace, independently of the sparse path's 32 lists)"""
-    corpus, levels = unit_rows(2000, 768, 98), icd_levels(2000, 99)
+    """all 6000 queries fail certification (the corpus is 10 distinct rows, 200 copies each: every candidate list
+    overflows with exact ties): the dense fallback's partial lists must be sized for the whole batch (its list count is
+    fitted to the workspace, independently of the sparse path's 32 lists); ties come out row id ascending"""
+    corpus, levels = np.repeat(unit_rows(10, 768, 98), 200, axis=0), icd_levels(2000, 99)
     queries = unit_rows(6000, 768, 100)
-    queries[:, 7] = 1e6
     idx = IcdIndex(corpus, levels, max_nq=6000, max_k=10)
     s, i = idx.search(queries, 10, MODE_AUTO)
     st = idx.stats()

@@ -156,3 +156,43 @@ def test_api_surface_with_stub_services():
         r = client.post("/query", json={"text": "x"})
         assert r.status_code == 500 and "服务未就绪" in r.json()["detail"]                     # 503 swallowed into 500 (main.py:361-363)
         assert client.post("/embed", json={"texts": ["a"]}).status_code == 500
+
+
+def test_sentence_transformers_checkpoint_config_is_honoured(tmp_path):
+    """a local sentence-transformers checkpoint: max_seq_length from sentence_bert_config.json, pooling from
+    1_Pooling/config.json (mean / cls); any other pooling mode must raise instead of embedding differently"""
+    from transformers import BertConfig, BertModel, BertTokenizerFast
+    from rag_project_icd10_amd.services.embedding_service import EmbeddingService
+    d = tmp_path / "st_model"
+    d.mkdir()
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "query", ":", "passage"] + [chr(c) for c in range(0x4e00, 0x4e00 + 200)]
+    (d / "vocab.txt").write_text("\n".join(vocab), encoding="utf-8")
+    BertTokenizerFast(str(d / "vocab.txt"), do_lower_case=True).save_pretrained(str(d))
+    BertModel(BertConfig(vocab_size=len(vocab), hidden_size=32, num_hidden_layers=1, num_attention_heads=2, intermediate_size=64,
+                         max_position_embeddings=64), add_pooling_layer=False).save_pretrained(str(d))
+    (d / "sentence_bert_config.json").write_text(json.dumps({"max_seq_length": 12, "do_lower_case": False}))
+    (d / "modules.json").write_text(json.dumps([{"idx": 0, "name": "0", "path": "", "type": "sentence_transformers.models.Transformer"},
+                                                {"idx": 1, "name": "1", "path": "1_Pooling", "type": "sentence_transformers.models.Pooling"}]))
+    (d / "1_Pooling").mkdir()
+    pool = {"word_embedding_dimension": 32, "pooling_mode_cls_token": False, "pooling_mode_mean_tokens": True,
+            "pooling_mode_max_tokens": False, "pooling_mode_mean_sqrt_len_tokens": False}
+    (d / "1_Pooling" / "config.json").write_text(json.dumps(pool))
+    os.environ["EMBEDDING_MODEL_NAME"] = str(d)
+    try:
+        emb = EmbeddingService(allow_synthetic=False, device="cpu")
+        info = emb.get_model_info()
+        assert info["max_seq_length"] == 12 and info["pooling"] == "mean" and info["synthetic"] is False
+        long_text = "".join(chr(0x4e00 + i) for i in range(60))
+        assert len(emb._tokenize(["query: " + long_text])[0]) == 12          # truncated at the checkpoint's max_seq_length
+        v_mean = emb.encode_query(long_text)
+        pool.update(pooling_mode_cls_token=True, pooling_mode_mean_tokens=False)
+        (d / "1_Pooling" / "config.json").write_text(json.dumps(pool))
+        emb_cls = EmbeddingService(allow_synthetic=False, device="cpu")
+        assert emb_cls.get_model_info()["pooling"] == "cls"
+        assert not np.allclose(emb_cls.encode_query(long_text), v_mean, atol=1e-4)
+        pool.update(pooling_mode_cls_token=False, pooling_mode_max_tokens=True)
+        (d / "1_Pooling" / "config.json").write_text(json.dumps(pool))
+        with pytest.raises(ValueError):
+            EmbeddingService(allow_synthetic=True, device="cpu")              # not even with synthetic weights allowed
+    finally:
+        os.environ["EMBEDDING_MODEL_NAME"] = "shibing624/text2vec-base-chinese"
