@@ -196,3 +196,29 @@ def test_sentence_transformers_checkpoint_config_is_honoured(tmp_path):
             EmbeddingService(allow_synthetic=True, device="cpu")              # not even with synthetic weights allowed
     finally:
         os.environ["EMBEDDING_MODEL_NAME"] = "shibing624/text2vec-base-chinese"
+
+
+def test_corpus_store_survives_a_torn_append(tmp_path):
+    """an append that died after extending the data files but before its manifest: the surplus bytes are cut on the next
+    load / append, so later rows do not shift against their metadata; a file shorter than committed raises"""
+    st = CorpusStore.open(str(tmp_path), "icd10", 4)
+    rows = [{"code": f"B{i}", "preferred_zh": "乙", "level": 1 + i % 3} for i in range(6)]
+    st.append(rows[:3], np.arange(12, dtype=np.float32).reshape(3, 4))
+    d = os.path.join(str(tmp_path), "icd10")
+    with open(os.path.join(d, "corpus.f32"), "ab") as f:           # the torn append: two rows of vectors, one level, half a line
+        np.full(8, 99, np.float32).tofile(f)
+    with open(os.path.join(d, "levels.i32"), "ab") as f:
+        np.asarray([7], np.int32).tofile(f)
+    with open(os.path.join(d, "meta.jsonl"), "ab") as f:
+        f.write(b'{"code": "TORN"')
+    st2 = CorpusStore.open(str(tmp_path), "icd10", 4)
+    assert st2.count == 3 and os.path.getsize(os.path.join(d, "corpus.f32")) == 3 * 4 * 4
+    st2.append(rows[3:], np.arange(12, 24, dtype=np.float32).reshape(3, 4))
+    st3 = CorpusStore.open(str(tmp_path), "icd10", 4)
+    assert st3.count == 6 and [r["code"] for r in st3.records] == [f"B{i}" for i in range(6)]
+    assert np.array_equal(st3.matrix(), np.arange(24, dtype=np.float32).reshape(6, 4))
+    assert st3.levels().tolist() == [1, 2, 3, 1, 2, 3]
+    with open(os.path.join(d, "corpus.f32"), "r+b") as f:
+        f.truncate(5 * 4 * 4)
+    with pytest.raises(ValueError):
+        CorpusStore.open(str(tmp_path), "icd10", 4)
