@@ -147,6 +147,27 @@ int icd_merge_topk(int32_t device, const float *scores, const int64_t *ids, cons
 int icd_index_lookup_levels(icd_index *idx, const int64_t *ids, int64_t count, int32_t *out_levels,
                             void *stream);
 
+/*
+ * Hierarchical rescoring of a batch of hit lists, device side: the string-free arithmetic of
+ * HierarchicalSimilarityService.batch_calculate_similarities (services/hierarchical_similarity_service.py:475-518,
+ * 243-291, 575) and of the uncertainty boost (services/uncertainty_diagnosis_service.py:190-238) for hits shaped as
+ * MilvusService.search returns them, for nq queries at once. IEEE double in the reference's evaluation order:
+ * bit-identical to the Python doubles.
+ *   adj, ids        [nq][k] outputs of icd_index_search_reweighted (device pointers), k <= 128
+ *   row_tags        [n_rows] one byte per corpus row: bits 0-3 index of the code's first letter in the chapter table
+ *                   A,B,C,E,I,J,K,N,S (15 = none), bit 7 = the code matches \.9\d*$
+ *   q_params        [nq][12] per query, computed from its text on the host: uncertainty weight (0 = none), context
+ *                   relevance, exact-match flag, the nine chapter boosts
+ *   weights         [7] factor weights hierarchy/entity/coherence/category/context, the coherence value, the level term
+ *   outputs         [nq][k] in the final order (enhanced score descending, stable): index of the hit in search order,
+ *                   enhanced score, the record's score after the uncertainty boost, the vector_similarity and
+ *                   hierarchy_boost factors, the applied uncertainty boost
+ */
+int icd_hier_rescore(int32_t device, const double *adj, const int64_t *ids, int64_t nq, int32_t k, int64_t id_base,
+                     int64_t n_rows, const uint8_t *row_tags, const double *q_params, const double *weights,
+                     int32_t *out_order, double *out_enhanced, double *out_score, double *out_vs, double *out_hb,
+                     double *out_boost, void *stream);
+
 int icd_index_stats(icd_index *idx, icd_stats *out);
 
 /* Tuning knob / test hook (0 = automatic): aim for about `chunks` candidate lists per query in the coarse pass

@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = (
     "icd_index_search", "icd_index_search_reweighted", "icd_merge_topk", "icd_index_lookup_levels",
     "icd_index_stats", "icd_index_set_chunks", "icd_index_debug_counters", "icd_index_set_profiling",
     "icd_index_last_profile", "icd_index_profile_summary", "icd_debug_set_permute",
+    "icd_hier_rescore",
 )
 
 
@@ -77,6 +78,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.icd_index_stats.argtypes = [vp, C.POINTER(_Stats)]
     lib.icd_index_set_chunks.argtypes = [vp, i32]
     lib.icd_debug_set_permute.argtypes = [i32]
+    lib.icd_hier_rescore.argtypes = [i32, vp, vp, i64, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.icd_index_debug_counters.argtypes = [vp, vp, i32]
     lib.icd_index_set_profiling.argtypes = [vp, i32]
     lib.icd_index_last_profile.argtypes = [vp, C.POINTER(_Profile)]
@@ -307,6 +309,28 @@ def _profile_summary(self) -> dict:
 
 
 IcdIndex.profile_summary = _profile_summary
+
+
+def hier_rescore(adj, ids, row_tags, q_params, weights, id_base: int = 0):
+    """Device-side hierarchical rescoring of a batch of hit lists (icd_hier_rescore). adj f64 [nq,k], ids i64 [nq,k],
+    row_tags u8 [n_rows], q_params f64 [nq,12] are tensors on one GPU; weights: 7 Python floats. Returns
+    (order i32, enhanced f64, score f64, vs f64, hb f64, boost f64), each [nq,k], in the final order."""
+    import torch
+    lib = load_library()
+    nq, k = adj.shape
+    dev = adj.device
+    adj = adj.to(torch.float64).contiguous()
+    ids = ids.to(torch.int64).contiguous()
+    row_tags = row_tags.to(torch.uint8).contiguous()
+    q_params = q_params.to(device=dev, dtype=torch.float64).contiguous()
+    assert q_params.shape == (nq, 12) and row_tags.device == dev
+    w = (C.c_double * 7)(*[float(x) for x in weights])
+    order = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    outs = [torch.empty((nq, k), dtype=torch.float64, device=dev) for _ in range(5)]
+    _check(lib, lib.icd_hier_rescore(dev.index, adj.data_ptr(), ids.data_ptr(), nq, k, int(id_base), row_tags.numel(),
+                                     row_tags.data_ptr(), q_params.data_ptr(), C.cast(w, C.c_void_p), order.data_ptr(),
+                                     *[t.data_ptr() for t in outs], _current_stream_ptr(dev.index)))
+    return (order, *outs)
 
 
 def merge_topk(scores, ids, levels, k: int):

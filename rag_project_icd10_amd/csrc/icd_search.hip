@@ -15,6 +15,7 @@
 #include "coarse_flat_kernel.hpp"
 #include "exact_kernel.hpp"
 #include "finalize.hpp"
+#include "hier_kernel.hpp"
 #include "stream_kernel.hpp"
 
 using namespace icd;
@@ -727,6 +728,28 @@ int icd_merge_topk(int32_t device, const float *scores, const int64_t *ids, cons
     static int configured[MAX_DEVICES] = {};   // (guarded by the caller's one-stream-per-handle contract; worst case a repeated call)
     HIP_TRY(ensure_dynamic_lds(merge_topk_kernel, device, (size_t)((int)lds), configured));
     hipLaunchKernelGGL(merge_topk_kernel, dim3(((int)nq + 3) / 4), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a);
+    HIP_TRY(hipGetLastError());
+    return ICD_OK;
+}
+
+int icd_hier_rescore(int32_t device, const double *adj, const int64_t *ids, int64_t nq, int32_t k, int64_t id_base,
+                     int64_t n_rows, const uint8_t *row_tags, const double *q_params, const double *weights,
+                     int32_t *out_order, double *out_enhanced, double *out_score, double *out_vs, double *out_hb,
+                     double *out_boost, void *stream) {
+    if (!adj || !ids || !row_tags || !q_params || !weights) return fail(ICD_ERR_INVALID, "input pointer is NULL");
+    if (!out_order || !out_enhanced || !out_score || !out_vs || !out_hb || !out_boost) return fail(ICD_ERR_INVALID, "output pointer is NULL");
+    if (k <= 0 || k > HIER_MAX_K) return fail(ICD_ERR_INVALID, "k=%d (1..%d)", k, HIER_MAX_K);
+    if (nq < 0 || nq > 0x7FFFFFFF || n_rows < 0) return fail(ICD_ERR_INVALID, "nq=%lld n_rows=%lld", (long long)nq, (long long)n_rows);
+    if (nq == 0) return ICD_OK;
+    HIP_TRY(hipSetDevice(device));
+    HierArgs a{};
+    a.adj = adj; a.ids = reinterpret_cast<const long long *>(ids); a.nq = (int)nq; a.k = k; a.id_base = id_base; a.n_rows = n_rows;
+    a.row_tags = row_tags; a.q_params = q_params;
+    a.w_hb = weights[0]; a.w_em = weights[1]; a.w_sc = weights[2]; a.w_ca = weights[3]; a.w_cr = weights[4];
+    a.sc_value = weights[5]; a.level_term = weights[6];
+    a.out_order = out_order; a.out_enhanced = out_enhanced; a.out_score = out_score; a.out_vs = out_vs; a.out_hb = out_hb;
+    a.out_boost = out_boost;
+    hipLaunchKernelGGL(hier_rescore_kernel, dim3(((int)nq + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     HIP_TRY(hipGetLastError());
     return ICD_OK;
 }

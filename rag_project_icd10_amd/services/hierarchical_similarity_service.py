@@ -275,6 +275,68 @@ class HierarchicalSimilarityService:
         results.sort(key=lambda item: item[1], reverse=True)
         return results
 
+    # ---- additive: a whole batch of queries, arithmetic on the device ---------
+    CHAPTER_ORDER = tuple(_CHAPTERS)   # index of a code's first letter in this tuple = low bits of a row tag
+
+    @classmethod
+    def row_tag(cls, code: str) -> int:
+        """One byte per corpus row for the device-side rescoring: bits 0-3 = index of the code's first letter in
+        CHAPTER_ORDER (15 = not a chapter of the table), bit 7 = the code matches the uncertainty service's `\\.9\\d*$`."""
+        from .uncertainty_diagnosis_service import _CODE_DOT9
+        c = code[0] if code else ""
+        tag = cls.CHAPTER_ORDER.index(c) if c in cls.CHAPTER_ORDER else 15
+        return tag | (0x80 if _CODE_DOT9.search(code or "") else 0)
+
+    def query_params(self, query_text: str) -> List[float]:
+        """The twelve per-query numbers of the device-side rescoring: everything batch_calculate_similarities derives from
+        the QUERY STRING alone when the hits are live-shaped (no top-level preferred_zh / level / parent_code /
+        semantic_text) and no entities are supplied: the uncertainty weight (0 = no marker), the context
+        relevance against an empty title, the exact-match flag (an empty clean query equals the empty title), and the
+        category-semantic boost of each of the nine chapters. Same values as the per-candidate methods return (they are
+        what the slow path below calls); the common case - no marker, no chapter keyword in the text - is decided by
+        two precompiled alternations instead of ~65 substring tests."""
+        import re
+        cls = type(self)
+        if getattr(cls, "_kw_any", None) is None:
+            from .uncertainty_diagnosis_service import _MARKER_GROUPS
+            cls._kw_any = re.compile("|".join(re.escape(k) for _n, kws, _w in _CHAPTERS.values() for k in kws))
+            cls._marker_any = re.compile("|".join(re.escape(m.lower()) for _t, _w, _d, ms in _MARKER_GROUPS for m in ms))
+        if cls._marker_any.search(query_text.lower()):
+            found = self.uncertainty_service.detect_uncertainty(query_text)
+            clean, weight = found["clean_text"], float(found["uncertainty_weight"])
+        else:
+            clean, weight = query_text, 0.0
+        cr = self._calculate_context_relevance(clean, {})
+        exact = 1.0 if "" == clean.strip() else 0.0
+        lowered = clean.lower()
+        cats = [0.0] * len(self.CHAPTER_ORDER)
+        if cls._kw_any.search(lowered):
+            for ci, c in enumerate(self.CHAPTER_ORDER):   # _calculate_category_semantic_boost with no entities, inlined
+                info = self.main_categories[c]
+                kws = info.get("keywords", [])
+                hits = 0
+                for kw in kws:
+                    if kw in lowered:
+                        hits += 1
+                if hits > 0:
+                    cats[ci] = float(min(0.0 + (hits / len(kws)) * 0.3 * info.get("semantic_weight", 1.0), 0.4))
+        return [weight, float(cr), exact] + cats
+
+    def device_weights(self) -> List[float]:
+        w = self.factor_weights
+        return [w["hierarchy_boost"], w["entity_match_score"], w["semantic_coherence"], w["category_alignment"],
+                w["context_relevance"], 0.3 if self.embedding_service else 0.5, self._get_level_boost_factor(1) * 0.3]
+
+    def rescore_live_hits_batch(self, queries: List[str], adj, ids, row_tags, id_base: int = 0):
+        """batch_calculate_similarities(q, {}, hits) for every query of a batch whose hits are still device tensors
+        (adj f64 [nq, k] and ids i64 [nq, k] from MilvusService.search_batch; row_tags from MilvusService.row_tags()).
+        Returns device tensors [nq, k] in the final order: (order, enhanced, score, vector_similarity, hierarchy_boost,
+        uncertainty_boost) - see include/icd_search.h icd_hier_rescore. Bit-identical to the per-query Python method."""
+        import torch
+        from .._native import hier_rescore
+        qp = torch.tensor([self.query_params(q) for q in queries], dtype=torch.float64)
+        return hier_rescore(adj, ids, row_tags, qp, self.device_weights(), id_base=id_base)
+
     # ---- explanation / tuning --------------------------------------------------------------------------
     def get_similarity_explanation(self, factors: SimilarityFactors) -> Dict[str, Any]:
         labels = {

@@ -41,6 +41,7 @@ class MilvusService:
         self.client: Optional[CorpusStore] = None
         self._index = None          # rag_project_icd10_amd._native.IcdIndex
         self._index_rows = 0
+        self._row_tags = None
         self._connect()
         self._setup_collection()
 
@@ -121,7 +122,21 @@ class MilvusService:
             self._index.close()
         self._index = None
         self._index_rows = 0
+        self._row_tags = None
         self._loaded = False
+
+    def row_tags(self):
+        """uint8 [n] on the index's GPU: what the device-side hierarchical rescoring needs to know about each row's code
+        (HierarchicalSimilarityService.row_tag); built on first use after a load."""
+        index = self._ready_index()
+        if index is None:
+            raise RuntimeError(f"collection {self.collection_name} is empty or missing")
+        if getattr(self, "_row_tags", None) is None or self._row_tags.numel() != self.client.count:
+            import torch
+            from .hierarchical_similarity_service import HierarchicalSimilarityService as H
+            tags = np.fromiter((H.row_tag(r.get("code") or "") for r in self.client.records), dtype=np.uint8, count=self.client.count)
+            self._row_tags = torch.from_numpy(tags).to(torch.device("cuda", self.config["milvus"]["gpu_device"]))
+        return self._row_tags
 
     # ---- writes -------------------------------------------------------------------------------------------
     def insert_records(self, records: List[Dict[str, Any]], embeddings: List[np.ndarray]) -> bool:

@@ -52,6 +52,56 @@ class MultiDiagnosisService:
                                         "avg_extraction_confidence": sum(confs) / len(confs),
                                         "extraction_method": "simple", "drug_filtering_enabled": False}}
 
+    def match_diagnoses_batch(self, diagnoses: List[str], top_k: int = 5, vectors=None) -> List[DiagnosisMatch]:
+        """Additive (row N2): embed -> search(2 top_k) -> level reweight -> hierarchical rescoring for MANY diagnosis
+        strings with everything between the tokenizer and the final top_k on the GPU: one encoder batch, one search_batch,
+        one rescoring launch; only the top_k winners per string come back and become Candidate objects. Same results as
+        _match_from_hits(d, milvus.search(encode_query(d), 2 top_k), top_k) per string (tests/test_gpu_parity.py)."""
+        from .hierarchical_similarity_service import SimilarityFactors
+        if not diagnoses:
+            return []
+        if vectors is None:
+            vectors = self.embedding_service.encode_query_batch(diagnoses, to_device=True)
+        hs = self.hierarchical_similarity
+        adj, raw, ids, _lv = self.milvus_service.search_batch(vectors, top_k * 2)
+        order, enh, score, vs, hb, boost = hs.rescore_live_hits_batch(diagnoses, adj, ids, self.milvus_service.row_tags())
+        # winners only: gather on the device, one copy to the host
+        import torch
+        kk = min(top_k, order.shape[1])
+        o = order[:, :kk].long().clamp(min=0)
+        h_ids = torch.gather(ids, 1, o).cpu().numpy()
+        h_raw = torch.gather(raw, 1, o).cpu().numpy()
+        h_adj = torch.gather(adj, 1, o).cpu().numpy()
+        h_ord, h_enh, h_vs, h_hb, h_boost = (t[:, :kk].cpu().numpy() for t in (order, enh, vs, hb, boost))
+        recs = self.milvus_service.client.records
+        sc = 0.3 if hs.embedding_service else 0.5
+        qps = [hs.query_params(d) for d in diagnoses]   # (cheap; [1] is the context relevance the factors report)
+        out = []
+        for q, diagnosis in enumerate(diagnoses):
+            cands = []
+            ok = True
+            for j in range(kk):
+                if h_ord[q, j] < 0:
+                    break
+                rec = recs[int(h_ids[q, j])]
+                s = float(h_enh[q, j])
+                if not s >= 0.0:      # Candidate.score has ge=0 (api/icd_models.py): the reference's match then degrades to
+                    ok = False        # an empty one (SURVEY a21); checked here because model_construct skips validation
+                    break
+                cands.append(Candidate.model_construct(
+                    code=rec.get("code", ""), title=rec.get("preferred_zh", ""), score=s,
+                    level=1, parent_code="",   # live hits carry level / parent_code under "metadata": top-level defaults (F8)
+                    enhanced_score=s,
+                    original_score=float(h_adj[q, j]) if h_boost[q, j] > 0 else float(h_raw[q, j]),
+                    similarity_factors=SimilarityFactors(float(h_vs[q, j]), float(h_hb[q, j]), 0.0, sc, 0.0, qps[q][1])))
+            if not ok:
+                logger.error("match failed for %s: negative score", diagnosis)
+                cands = []
+            conf = self._calculate_match_confidence(cands) if cands else 0.0
+            out.append(DiagnosisMatch.model_construct(diagnosis_text=diagnosis, candidates=cands, match_confidence=conf,
+                                                      confidence_metrics=None, confidence_factors=None, confidence_level=None))
+        return out
+
     def _match_from_hits(self, diagnosis: str, hits: List[Dict[str, Any]], top_k: int) -> DiagnosisMatch:
         try:
             rescored = self.hierarchical_similarity.batch_calculate_similarities(diagnosis, {}, hits)

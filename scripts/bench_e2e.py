@@ -56,6 +56,8 @@ def main():
     assert ms.load_collection()
     t_build = time.perf_counter() - t0
     hs = HierarchicalSimilarityService(embedding_service=es)
+    from rag_project_icd10_amd.services.multi_diagnosis_service import MultiDiagnosisService
+    md = MultiDiagnosisService(es, ms)
 
     def sync():
         if torch.cuda.is_available():
@@ -82,7 +84,20 @@ def main():
         for q, h in zip(strings, hits):
             hs.batch_calculate_similarities(q, {}, h)
         st["hierarchical_rescoring_host_ms"] = (time.perf_counter() - t) * 1e3
-        del ids
+        # row N2: the same rescoring with its arithmetic on the device (per-query string rules on the host, one launch)
+        t = time.perf_counter()
+        a2, r2, i2, l2 = ms.search_batch(qv, top_k=2 * k)
+        outs = hs.rescore_live_hits_batch(strings, a2, i2, ms.row_tags())
+        sync()
+        st["search_2k_plus_hierarchical_rescoring_device_ms"] = (time.perf_counter() - t) * 1e3
+        t = time.perf_counter()
+        qp = [hs.query_params(q) for q in strings]
+        st["of_which_query_string_rules_host_ms"] = (time.perf_counter() - t) * 1e3
+        t = time.perf_counter()
+        md.match_diagnoses_batch(strings, top_k=k, vectors=qv)
+        sync()
+        st["match_diagnoses_batch_total_ms"] = (time.perf_counter() - t) * 1e3
+        del ids, qp, outs
         return st, hits
 
     batched()   # warm-up (kernel load, allocator)

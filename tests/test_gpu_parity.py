@@ -320,10 +320,9 @@ def test_full_size_config2_properties(oracle):
     assert all(len(set(r)) == k for r in i[::97])                              # no duplicate ids
     s2, i2 = idx.search(queries, k, MODE_AUTO)
     assert np.array_equal(i, i2) and _bits(s) == _bits(s2)                     # idempotent
-    sample = np.arange(0, nq, 53)
-    os_, oi = oracle.flat_ip_topk(corpus, queries[sample], k)                  # oracle on a sample
-    assert np.array_equal(i[sample], oi) and _bits(s[sample]) == _bits(os_)
-    recall = np.mean([len(set(a) & set(b)) / k for a, b in zip(i[sample], oi)])
+    os_, oi = oracle.flat_ip_topk(corpus, queries, k)                          # the oracle on EVERY query of the batch
+    assert np.array_equal(i, oi) and _bits(s) == _bits(os_)
+    recall = np.mean([len(set(a) & set(b)) / k for a, b in zip(i, oi)])
     assert recall == 1.0                                                       # recall@10 vs the exact reference
     se, ie = idx.search(queries[:1024], k, MODE_EXACT)                         # fast path == exact kernel
     assert np.array_equal(ie, i[:1024]) and _bits(se) == _bits(s[:1024])
@@ -409,6 +408,92 @@ def test_sharded_search_single_rank_nccl(oracle):
         idx.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_query_sharded_search_single_rank_nccl_and_config3_share(oracle):
+    """BASELINE configs[3]: the corpus replicated, the query batch sharded over the ranks (QUERY_SHARD over the HIP index,
+    RCCL group of one rank here; two ranks in tests/test_sharded_cpu.py), at the per-GPU share of the config: 125 000
+    queries x 37 000 rows. The oracle checks a query sample; the rest is covered by properties (sorted, valid ids,
+    reweighted order consistent with the raw hits, idempotent, agreement with the plain index call)."""
+    import torch
+    import torch.distributed as dist
+    from rag_project_icd10_amd.sharded import QUERY_SHARD, ShardedSearch
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29613"
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        n, nq, k = 37000, 125000, 10
+        corpus, levels = unit_rows(n, 768, 1234), icd_levels(n, 1235)
+        g = torch.Generator(device="cuda")
+        g.manual_seed(4321)
+        dq = torch.randn((nq, 768), generator=g, device="cuda", dtype=torch.float32)
+        dq /= dq.norm(dim=1, keepdim=True)
+        idx = IcdIndex(corpus, levels, max_nq=nq, max_k=k)
+        eng = ShardedSearch.from_index(idx, QUERY_SHARD)
+        adj, raw, ids, lv = eng.search_reweighted(dq, k, gather=True)
+        st = idx.stats()
+        assert st["last_mode"] == MODE_AUTO and st["last_nq"] == nq and st["last_fallback"] <= nq // 100
+        assert adj.shape == (nq, k) and bool((ids >= 0).all()) and bool((ids < n).all())
+        assert bool((adj[:, 1:] <= adj[:, :-1]).all())                               # reweighted order
+        tl = torch.from_numpy(levels).cuda()
+        w = torch.tensor([1.0, 1.2, 1.0, 0.8], dtype=torch.float64, device="cuda")
+        assert torch.equal(lv.long(), tl[ids].long()) and torch.equal(adj, raw.double() * w[lv.long()])   # adj = raw x weight(level)
+        a2, r2, i2, l2 = idx.search_reweighted(dq, k)                               # same as the plain call, idempotent
+        assert torch.equal(i2, ids) and torch.equal(a2, adj)
+        sample = torch.arange(0, nq, 977, device="cuda")
+        qs = dq[sample].cpu().numpy()
+        os_, oi = oracle.flat_ip_topk(corpus, qs, k)
+        want = oracle.reweight(os_, oi, levels)
+        assert np.array_equal(ids[sample].cpu().numpy(), want[2]) and _bits(adj[sample].cpu().numpy()) == _bits(want[0])
+        assert _bits(raw[sample].cpu().numpy()) == _bits(want[1])
+        idx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config2_shape_batched_equals_one_at_a_time(tmp_path, monkeypatch):
+    """BASELINE configs[2] at its stated size: the 1 000 golden diagnosis strings -> encoder on ROCm -> search over
+    40 474 rows -> level reweight -> hierarchical rescoring. The batched path (one encoder batch, one search_batch, the
+    device-side rescoring) must return what the reference's call shape returns (encode_query + search + the golden-pinned
+    batch_calculate_similarities, one string at a time)."""
+    from conftest import GOLDEN
+    monkeypatch.setenv("MILVUS_DB_PATH", str(tmp_path / "db"))
+    monkeypatch.setenv("MILVUS_COLLECTION_NAME", "icd10_cfg2")
+    monkeypatch.setenv("EMBEDDING_MODEL_NAME", "shibing624/text2vec-base-chinese")
+    monkeypatch.setenv("ICD_EMBEDDING_ALLOW_SYNTHETIC", "1")
+    from rag_project_icd10_amd.services.embedding_service import EmbeddingService
+    from rag_project_icd10_amd.services.milvus_service import MilvusService
+    from rag_project_icd10_amd.services.multi_diagnosis_service import MultiDiagnosisService
+    strings = [l.strip() for l in open(os.path.join(GOLDEN, "diagnosis_strings.txt"), encoding="utf-8") if l.strip()]
+    assert len(strings) == 1000
+    n = 40474
+    es = EmbeddingService()
+    ms = MilvusService(embedding_service=es)
+    corpus, levels = unit_rows(n, 768, 1234), icd_levels(n, 1235)
+    letters = "ABCEIJKNSZ"
+    for s0 in range(0, n, 128):
+        recs = [{"code": f"{letters[i % 10]}{i % 100:02d}.{(i // 7) % 10}" + ("9" if i % 11 == 0 else ""), "preferred_zh": f"合成疾病{i}",
+                 "level": int(levels[i]), "parent_code": "", "category_path": "", "semantic_text": f"合成疾病{i}"}
+                for i in range(s0, min(n, s0 + 128))]
+        assert ms.insert_records(recs, list(corpus[s0:s0 + 128]))
+    assert ms.load_collection()
+    md = MultiDiagnosisService(es, ms)
+    k = 10
+    strings = strings + ["待查", "？", " 疑似 ", "肺炎待查", "高血压 糖尿病 肿瘤 感染"]    # empty clean query (exact-match rule), markers, chapter keywords
+    vecs = es.encode_query_batch(strings, to_device=True)                           # (encoder batch-vs-single parity: test_encoder_gpu.py)
+    batched = md.match_diagnoses_batch(strings, top_k=k, vectors=vecs)              # additive entry point (row N2)
+    assert len(batched) == len(strings)
+    assert sum(1 for m in batched if m.candidates) >= len(strings) - 5
+    hv = vecs.cpu().numpy()
+    for i in list(range(0, 1000, 9)) + list(range(995, len(strings))):              # the reference call shape on a sample
+        hits = ms.search(hv[i], top_k=k * 2)
+        one = md._match_from_hits(strings[i], hits, k)
+        got = batched[i]
+        assert [c.code for c in got.candidates] == [c.code for c in one.candidates], strings[i]
+        for a, b in zip(got.candidates, one.candidates):
+            assert a.score == b.score and a.enhanced_score == b.enhanced_score and a.original_score == b.original_score
+            assert a.similarity_factors == b.similarity_factors and a.title == b.title
+        assert got.match_confidence == one.match_confidence
 
 
 def test_services_end_to_end_on_gpu(oracle, tmp_path, monkeypatch):
