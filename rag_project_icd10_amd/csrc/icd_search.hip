@@ -192,16 +192,43 @@ inline bool stream_fits(int kp, int qb, int dim) {
     return (size_t)qb * dim * 4 + (size_t)4 * 2 * ST_STAGE_BYTES + (size_t)4 * qb * 64 * e * 8 <= (size_t)LDS_LIMIT;
 }
 
+// List counts after every reduction level of the streaming kernel's 4 * nwg per-wave lists: a reduce wave merges at most
+// per_max lists, the last level must leave p_final lists (p_final = 0: as few as one more level gives), and the number
+// of levels must be ODD because the levels ping-pong between the two list workspaces and finalize reads the second one.
+// (Round 1 sized the sweep so that ONE level sufficed: 16 work-groups at k > 16, 4 at k > 64 - a 0.45 / 1.6 ms fallback
+// for a single uncertified query at k = 64 / 100, profiles/r02_shapes_before.log. Now the sweep always fills the chip.)
+inline int plan_reduce_levels(int nlists, int per_max, int p_final, int p_cap, int *plan /* [8] */) {
+    for (int first_per = per_max; first_per >= 2; --first_per) {
+        int cnt = 0, cur = nlists;
+        bool first = true;
+        const int target = p_final > 0 ? p_final : p_cap;
+        while (cur > per_max * target && cnt < 7) {
+            const int per = first ? first_per : per_max;
+            first = false;
+            cur = (cur + per - 1) / per;
+            plan[cnt++] = cur;
+        }
+        if (cnt >= 7) continue;
+        if (first && first_per < per_max && cur > first_per * target) continue;   // (a smaller first fan-in only as the single level)
+        plan[cnt++] = p_final > 0 ? p_final : std::max(1, (cur + (first ? first_per : per_max) - 1) / (first ? first_per : per_max));
+        if (cnt % 2 == 1) return cnt;
+    }
+    return 0;
+}
+
 template <int KP, int E, int QB>
 int launch_stream(icd_index *x, const float *dq, const int *qlist, const int *nq_ptr, int nq, int max_active,
                   int p_out, int *p_used, hipStream_t s) {
     const int n = (int)x->n;
     const int per_max = FIN_MAX_CAND / KP;                       // lists one reduce wave can merge
     const int p_cap = FIN_MAX_CAND / KP;                         // lists finalize<false> can merge
-    const int nwg_max = std::max(1, std::min(256, per_max * (p_out > 0 ? p_out : p_cap) / 4));
+    const int nwg_max = std::max(1, std::min(x->num_cu, 256));
     int rows_per_wg = ((n + nwg_max - 1) / nwg_max + 255) / 256 * 256;
     const int nwg = (n + rows_per_wg - 1) / rows_per_wg;
-    if (p_out <= 0) p_out = std::max(1, (4 * nwg + per_max - 1) / per_max);
+    int plan[8];
+    const int levels = plan_reduce_levels(4 * nwg, per_max, p_out, p_cap, plan);
+    if (levels <= 0) return fail(ICD_ERR_INVALID, "stream kernel: no reduction plan for %d lists (KP=%d, P=%d)", 4 * nwg, KP, p_out);
+    p_out = plan[levels - 1];
     if (p_used) *p_used = p_out;
     StreamArgs a{};
     a.corpus = x->corpus; a.queries = dq; a.qlist = qlist; a.nq_ptr = nq_ptr; a.nq = std::min(nq, max_active);
@@ -212,6 +239,10 @@ int launch_stream(icd_index *x, const float *dq, const int *qlist, const int *nq
     while (stages > 2 && stream_lds_bytes<KP, E, QB>(x->dim, stages) > (size_t)LDS_LIMIT) --stages;
     a.ring_stages = stages;
     if ((size_t)a.nq * 4 * nwg * KP > x->lists_cap) return fail(ICD_ERR_INVALID, "stream workspace too small");
+    for (int l = 0; l < levels; ++l) {
+        const size_t cap = (l % 2 == 0) ? x->partx_cap + (size_t)128 * FIN_MAX_CAND : x->lists_cap;
+        if ((size_t)a.nq * plan[l] * KP > cap) return fail(ICD_ERR_INVALID, "stream workspace too small for reduction level %d", l);
+    }
     auto kern = stream_topk_kernel<KP, E, QB>;
     const size_t lds = stream_lds_bytes<KP, E, QB>(x->dim, stages);
     if (lds > (size_t)LDS_LIMIT) return fail(ICD_ERR_INVALID, "stream kernel: dim=%d does not fit LDS with %d queries per pass", x->dim, QB);
@@ -219,11 +250,17 @@ int launch_stream(icd_index *x, const float *dq, const int *qlist, const int *nq
     HIP_TRY(ensure_dynamic_lds(kern, x->device, (size_t)((int)lds), configured));
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, s, a);
     HIP_TRY(hipGetLastError());
-    ReduceArgs r{};
-    r.list_scores = x->lists_s; r.list_rows = x->lists_r; r.nlists = 4 * nwg; r.KP = KP; r.P_out = p_out;
-    r.nq_ptr = nq_ptr; r.nq = a.nq; r.max_active = max_active; r.part_scores = x->partx_s; r.part_rows = x->partx_r;
-    hipLaunchKernelGGL(reduce_lists_kernel, dim3((a.nq * p_out + 3) / 4), dim3(256), 4 * 512 * 8, s, r);
-    HIP_TRY(hipGetLastError());
+    int nlists = 4 * nwg;
+    for (int l = 0; l < levels; ++l) {   // lists -> partx -> lists -> ... -> partx
+        ReduceArgs r{};
+        r.list_scores = (l % 2 == 0) ? x->lists_s : x->partx_s; r.list_rows = (l % 2 == 0) ? x->lists_r : x->partx_r;
+        r.part_scores = (l % 2 == 0) ? x->partx_s : x->lists_s; r.part_rows = (l % 2 == 0) ? x->partx_r : x->lists_r;
+        r.nlists = nlists; r.KP = KP; r.P_out = plan[l];
+        r.nq_ptr = nq_ptr; r.nq = a.nq; r.max_active = max_active;
+        hipLaunchKernelGGL(reduce_lists_kernel, dim3((a.nq * plan[l] + 3) / 4), dim3(256), 4 * 512 * 8, s, r);
+        HIP_TRY(hipGetLastError());
+        nlists = plan[l];
+    }
     return ICD_OK;
 }
 
@@ -295,7 +332,9 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     // How many flagged queries still go to the streaming kernel: it re-reads the corpus once per 8 queries (~35 us at
     // 37k rows), the fp32-MFMA kernel needs ~1.4 ms for ANY count up to a few thousand (one 128-query tile per
     // work-group, 16 chunks at most: few CUs busy), so the crossover is near 300; the list workspace caps it by k.
-    const int sparse_max = (int)std::min<size_t>(ST_FALLBACK_MAX_ACTIVE, x->lists_cap / ((size_t)1024 * kpx));
+    // (the first reduction level leaves at most 512 lists per slot in the second workspace)
+    const int sparse_max = (int)std::min<size_t>(std::min<size_t>(ST_FALLBACK_MAX_ACTIVE, x->lists_cap / ((size_t)1024 * kpx)),
+                                                 kpx == 16 ? (size_t)ST_FALLBACK_MAX_ACTIVE : x->partx_cap / ((size_t)512 * kpx));
     auto run_stream = [&](const int *qlist, const int *nq_ptr, int nqs, int p_out, int *p_used) -> int {
         int qb = nq_ptr ? 8 : (nqs <= 1 ? 1 : (nqs <= 2 ? 2 : (nqs <= 4 ? 4 : 8)));
         while (qb > 1 && !stream_fits(kpx, qb, x->dim)) qb >>= 1;
@@ -617,6 +656,8 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     CR_TRY(wsalloc(&x->shared_thr, (size_t)x->max_nq_pad));
     CR_TRY(wsalloc(&x->qdev, (size_t)max_nq * dim));
     x->partx_cap = std::max<size_t>((size_t)x->max_nq_pad * 2 * exact_kp_for(max_k), (size_t)1 << 21);
+    if (exact_kp_for(max_k) > 16)   // multi-level reduction of the streaming kernel's lists: ST_MAX_ACTIVE slots x 512 lists
+        x->partx_cap = std::max<size_t>(x->partx_cap, (size_t)ST_MAX_ACTIVE * 512 * exact_kp_for(max_k));
     // (+ one query tile of the widest layout: the device-chosen chunk count of the fallback rounds the slot count up)
     CR_TRY(wsalloc(&x->partx_s, x->partx_cap + (size_t)128 * FIN_MAX_CAND));
     CR_TRY(wsalloc(&x->partx_r, x->partx_cap + (size_t)128 * FIN_MAX_CAND));
