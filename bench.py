@@ -128,7 +128,7 @@ def pmc_traffic(kernel, nq, n):
     try:
         d = json.load(open(files[-1]))
         for name, v in d.items():
-            if name.startswith(kernel):
+            if kernel in name:
                 return float(v["traffic_bytes"]), os.path.relpath(files[-1], ROOT)
     except Exception:
         return None, None

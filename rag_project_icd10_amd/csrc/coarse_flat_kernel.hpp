@@ -152,7 +152,7 @@ __device__ __forceinline__ float flush_emit_parallel(const char *smem, uint32_t 
 //   4    LDS-DMA pieces spread over the 16 MFMAs between two barriers, every wave in its own slots (piece i of wave w
 //        behind MFMA 4 i + w): the CU's address unit sees one piece per MFMA instead of sixteen at once
 //   8    query fragments pinned to accumulator registers
-//   16   select: one v_max3 tree + one scalar branch per FOUR score registers, predicated appends behind it
+//   16   select: branch-free step per score register (EXEC narrowed to the passing lanes around the append)
 //   32   ring of 3 stages, 64 ring of 6 stages (TIMING ONLY: the compaction scratch aliases the ring)
 //   128  A fragments read two k-steps ahead of their MFMAs instead of one
 //   256  TIMING ONLY: no s_barrier        512  TIMING ONLY: no wait for the LDS-DMA pieces
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     constexpr bool DMA_SPREAD = (VAR & 2) != 0;
     constexpr bool DMA_SLOTS = (VAR & 4) != 0;
     constexpr bool Q_AGPR = (VAR & 8) != 0;
-    constexpr bool MAXTREE4 = (VAR & 16) != 0;
+    constexpr bool NOBRANCH = (VAR & 16) != 0;
     constexpr bool PF2 = (VAR & 128) != 0;
     constexpr bool NOBAR = (VAR & 256) != 0, NOVM = (VAR & 512) != 0, STAMPS = (VAR & 1024) != 0;
     constexpr int S = cf_ring_stages(VAR);            // ring slots
@@ -314,30 +314,26 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             }
         };
 
-        // Four registers per scalar branch. A compare followed by its own branch costs far more than its two issue slots
-        // (the branch waits for the VALU result; measured ~70 cycles per register with the appends), and only ~13 % of the
-        // registers hold a passing score: the largest of four registers is compared once (two v_max3 + v_cmp + branch),
-        // and a group with a pass (~40 %) appends under predication, no further branches.
-        auto filter_grp4 = [&](const f32x16 (&pa)[4], auto G, uint32_t rowbase) {
-            constexpr int g = decltype(G)::value;
-            constexpr int t = g >> 2, r0 = (g & 3) * 4;
-            const float v0 = pa[t][r0], v1 = pa[t][r0 + 1], v2 = pa[t][r0 + 2], v3 = pa[t][r0 + 3];
-            float m;   // (asm: fmaxf on MFMA outputs makes hipcc canonicalise every operand with a v_max of its own)
-            asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4" : "=&v"(m) : "v"(v0), "v"(v1), "v"(v2), "v"(v3));
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(m > st.thr) != 0ull, 0)) {
-                asm volatile("" ::: "memory");
-                static_for<0, 4>([&](auto I) {
-                    constexpr int r = r0 + decltype(I)::value;
-                    constexpr uint32_t roff = (uint32_t)(t * 32 + (r & 3) + 8 * (r >> 2));
-                    const float v = pa[t][r];
-                    if (v > st.thr) {
-                        *reinterpret_cast<float *>(smem + st.aw) = v;
-                        *reinterpret_cast<uint32_t *>(smem + st.aw + Ops::ROW_OFF) = rowbase + roff;
-                        st.aw += st.inc;
-                    }
-                });
-            }
-            if constexpr ((4 * g + 3) % CO_CHECK_EVERY == CO_CHECK_EVERY - 1) {
+        // Branch-free select step (VAR & 16): compare, narrow EXEC to the passing lanes, append, restore EXEC - seven
+        // instructions for EVERY register, against compare + branch (cheap when no lane passes, ~150 cycles through the
+        // out-of-line append block when one does: a third of the registers late in a list).
+        auto filter_nobranch = [&](const f32x16 (&pa)[4], auto F, uint32_t rowbase) {
+            constexpr int f = decltype(F)::value;
+            constexpr int t = f >> 4, r = f & 15;
+            constexpr uint32_t roff = (uint32_t)(t * 32 + (r & 3) + 8 * (r >> 2));
+            const float v = pa[t][r];
+            uint32_t row;
+            unsigned long long sv;
+            asm volatile("v_cmp_gt_f32 vcc, %[v], %[thr]\n\t"
+                         "s_and_saveexec_b64 %[sv], vcc\n\t"
+                         "v_add_u32 %[row], %[ro], %[rb]\n\t"
+                         "ds_write2st64_b32 %[aw], %[v], %[row] offset1:1\n\t"
+                         "v_add_u32 %[aw], %[aw], %[inc]\n\t"
+                         "s_mov_b64 exec, %[sv]"
+                         : [aw] "+v"(st.aw), [row] "=&v"(row), [sv] "=&s"(sv)
+                         : [v] "v"(v), [thr] "v"(st.thr), [rb] "v"(rowbase), [ro] "i"(roff), [inc] "v"(st.inc)
+                         : "vcc", "memory");
+            if constexpr (r % CO_CHECK_EVERY == CO_CHECK_EVERY - 1) {
                 if (__builtin_amdgcn_ballot_w64(Ops::used(st, h) > CO_QUOTA) != 0ull)
                     Ops::check(st, lane, smem, wave_qbase, wave_scratch, false, CO_LIMIT, STAMPS ? st_comp : nullptr, CO_QUOTA);
             }
@@ -518,7 +514,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             }
             if constexpr (STAMPS) { unsigned long long ts_b; ICD_CF_STAMP(ts_b); st_boot += ts_b - ts_a; }
             if (tile_row0 + CO_BN > a.n) static_for<0, 64>([&](auto F) { filter_reg(acc, F, rowbase, std::true_type{}); });
-            else if constexpr (MAXTREE4) static_for<0, 16>([&](auto G) { filter_grp4(acc, G, rowbase); });
+            else if constexpr (NOBRANCH) static_for<0, 64>([&](auto F) { filter_nobranch(acc, F, rowbase); });
             else static_for<0, 64>([&](auto F) { filter_reg(acc, F, rowbase, std::false_type{}); });
             if constexpr (STAMPS) {
                 unsigned long long ts1;

@@ -42,4 +42,24 @@ ICD_HD inline int flat_workgroup_of_block(int w, int G, int T) {
     return rT + jj / qT + (jj % qT) * T;
 }
 
+
+// List counts after every reduction level of the streaming kernel's 4 * nwg per-wave lists: a reduce wave merges at most
+// per_max lists, the last level must leave p_final lists (p_final = 0: as few as one more level gives), and the number
+// of levels must be ODD because the levels ping-pong between the two list workspaces and finalize reads the second one.
+// (Round 1 sized the sweep so that ONE level sufficed: 16 work-groups at k > 16, 4 at k > 64 - a 0.45 / 1.6 ms fallback
+// for a single uncertified query at k = 64 / 100, profiles/r02_shapes_before.log. Now the sweep always fills the chip.)
+ICD_HD inline int plan_reduce_levels(int nlists, int per_max, int p_final, int p_cap, int *plan /* [8] */) {
+    const int target = p_final > 0 ? p_final : p_cap;
+    int levels = 1;
+    long long reach = (long long)per_max * target;          // lists that `levels` levels can bring down to `target`
+    while (reach < nlists) { reach *= per_max; ++levels; }
+    const bool extra = levels % 2 == 0;                      // an even count gets one more level, of fan-in 2, in front
+    if (levels + (extra ? 1 : 0) > 8) return 0;
+    int cnt = 0, cur = nlists;
+    if (extra) { cur = (cur + 1) / 2; plan[cnt++] = cur; }
+    for (int l = 1; l < levels; ++l) { cur = (cur + per_max - 1) / per_max; plan[cnt++] = cur; }
+    plan[cnt++] = p_final > 0 ? p_final : ((cur + per_max - 1) / per_max > 1 ? (cur + per_max - 1) / per_max : 1);
+    return cnt;
+}
+
 }  // namespace icd

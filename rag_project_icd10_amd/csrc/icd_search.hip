@@ -192,30 +192,6 @@ inline bool stream_fits(int kp, int qb, int dim) {
     return (size_t)qb * dim * 4 + (size_t)4 * 2 * ST_STAGE_BYTES + (size_t)4 * qb * 64 * e * 8 <= (size_t)LDS_LIMIT;
 }
 
-// List counts after every reduction level of the streaming kernel's 4 * nwg per-wave lists: a reduce wave merges at most
-// per_max lists, the last level must leave p_final lists (p_final = 0: as few as one more level gives), and the number
-// of levels must be ODD because the levels ping-pong between the two list workspaces and finalize reads the second one.
-// (Round 1 sized the sweep so that ONE level sufficed: 16 work-groups at k > 16, 4 at k > 64 - a 0.45 / 1.6 ms fallback
-// for a single uncertified query at k = 64 / 100, profiles/r02_shapes_before.log. Now the sweep always fills the chip.)
-inline int plan_reduce_levels(int nlists, int per_max, int p_final, int p_cap, int *plan /* [8] */) {
-    for (int first_per = per_max; first_per >= 2; --first_per) {
-        int cnt = 0, cur = nlists;
-        bool first = true;
-        const int target = p_final > 0 ? p_final : p_cap;
-        while (cur > per_max * target && cnt < 7) {
-            const int per = first ? first_per : per_max;
-            first = false;
-            cur = (cur + per - 1) / per;
-            plan[cnt++] = cur;
-        }
-        if (cnt >= 7) continue;
-        if (first && first_per < per_max && cur > first_per * target) continue;   // (a smaller first fan-in only as the single level)
-        plan[cnt++] = p_final > 0 ? p_final : std::max(1, (cur + (first ? first_per : per_max) - 1) / (first ? first_per : per_max));
-        if (cnt % 2 == 1) return cnt;
-    }
-    return 0;
-}
-
 template <int KP, int E, int QB>
 int launch_stream(icd_index *x, const float *dq, const int *qlist, const int *nq_ptr, int nq, int max_active,
                   int p_out, int *p_used, hipStream_t s) {
@@ -507,7 +483,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             const int v = atoi(fv);
             if (false) {}
 #define ICD_FV_CASE(V) else if (v == V) rc = launch_coarse_flat<768, V>(x, a, nwg, s);
-            ICD_FV_CASE(0) ICD_FV_CASE(CF_PRODUCT_VAR) ICD_FV_CASE(CF_PRODUCT_VAR + 1024)
+            ICD_FV_CASE(0) ICD_FV_CASE(CF_PRODUCT_VAR) ICD_FV_CASE(CF_PRODUCT_VAR + 16) ICD_FV_CASE(CF_PRODUCT_VAR + 1024) ICD_FV_CASE(CF_PRODUCT_VAR + 16 + 1024)
 #undef ICD_FV_CASE
             else return fail(ICD_ERR_INVALID, "ICD_FLAT_VAR=%d is not built", v);
         }

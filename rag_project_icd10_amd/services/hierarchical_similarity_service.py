@@ -327,14 +327,16 @@ class HierarchicalSimilarityService:
         return [w["hierarchy_boost"], w["entity_match_score"], w["semantic_coherence"], w["category_alignment"],
                 w["context_relevance"], 0.3 if self.embedding_service else 0.5, self._get_level_boost_factor(1) * 0.3]
 
-    def rescore_live_hits_batch(self, queries: List[str], adj, ids, row_tags, id_base: int = 0):
+    def rescore_live_hits_batch(self, queries: List[str], adj, ids, row_tags, id_base: int = 0, q_params=None):
         """batch_calculate_similarities(q, {}, hits) for every query of a batch whose hits are still device tensors
         (adj f64 [nq, k] and ids i64 [nq, k] from MilvusService.search_batch; row_tags from MilvusService.row_tags()).
         Returns device tensors [nq, k] in the final order: (order, enhanced, score, vector_similarity, hierarchy_boost,
         uncertainty_boost) - see include/icd_search.h icd_hier_rescore. Bit-identical to the per-query Python method."""
         import torch
         from .._native import hier_rescore
-        qp = torch.tensor([self.query_params(q) for q in queries], dtype=torch.float64)
+        if q_params is None:
+            q_params = [self.query_params(q) for q in queries]
+        qp = torch.tensor(q_params, dtype=torch.float64)
         return hier_rescore(adj, ids, row_tags, qp, self.device_weights(), id_base=id_base)
 
     # ---- explanation / tuning --------------------------------------------------------------------------

@@ -63,43 +63,42 @@ class MultiDiagnosisService:
         if vectors is None:
             vectors = self.embedding_service.encode_query_batch(diagnoses, to_device=True)
         hs = self.hierarchical_similarity
+        qps = [hs.query_params(d) for d in diagnoses]   # ([1] is the context relevance the factors report)
         adj, raw, ids, _lv = self.milvus_service.search_batch(vectors, top_k * 2)
-        order, enh, score, vs, hb, boost = hs.rescore_live_hits_batch(diagnoses, adj, ids, self.milvus_service.row_tags())
-        # winners only: gather on the device, one copy to the host
+        order, enh, score, vs, hb, boost = hs.rescore_live_hits_batch(diagnoses, adj, ids, self.milvus_service.row_tags(),
+                                                                       q_params=qps)
+        # winners only: gather on the device, one copy to the host, plain Python lists for the object loop
         import torch
         kk = min(top_k, order.shape[1])
         o = order[:, :kk].long().clamp(min=0)
-        h_ids = torch.gather(ids, 1, o).cpu().numpy()
-        h_raw = torch.gather(raw, 1, o).cpu().numpy()
-        h_adj = torch.gather(adj, 1, o).cpu().numpy()
-        h_ord, h_enh, h_vs, h_hb, h_boost = (t[:, :kk].cpu().numpy() for t in (order, enh, vs, hb, boost))
+        h_ids = torch.gather(ids, 1, o).tolist()
+        h_raw = torch.gather(raw, 1, o).double().tolist()
+        h_adj = torch.gather(adj, 1, o).tolist()
+        h_ord, h_enh, h_vs, h_hb, h_boost = (t[:, :kk].tolist() for t in (order, enh, vs, hb, boost))
         recs = self.milvus_service.client.records
         sc = 0.3 if hs.embedding_service else 0.5
-        qps = [hs.query_params(d) for d in diagnoses]   # (cheap; [1] is the context relevance the factors report)
         out = []
         for q, diagnosis in enumerate(diagnoses):
             cands = []
-            ok = True
-            for j in range(kk):
-                if h_ord[q, j] < 0:
-                    break
-                rec = recs[int(h_ids[q, j])]
-                s = float(h_enh[q, j])
-                if not s >= 0.0:      # Candidate.score has ge=0 (api/icd_models.py): the reference's match then degrades to
-                    ok = False        # an empty one; checked here because model_construct skips validation
-                    break
-                cands.append(Candidate.model_construct(
-                    code=rec.get("code", ""), title=rec.get("preferred_zh", ""), score=s,
-                    level=1, parent_code="",   # live hits carry level / parent_code under "metadata": top-level defaults (F8)
-                    enhanced_score=s,
-                    original_score=float(h_adj[q, j]) if h_boost[q, j] > 0 else float(h_raw[q, j]),
-                    similarity_factors=SimilarityFactors(float(h_vs[q, j]), float(h_hb[q, j]), 0.0, sc, 0.0, qps[q][1])))
-            if not ok:
-                logger.error("match failed for %s: negative score", diagnosis)
-                cands = []
-            conf = self._calculate_match_confidence(cands) if cands else 0.0
-            out.append(DiagnosisMatch.model_construct(diagnosis_text=diagnosis, candidates=cands, match_confidence=conf,
-                                                      confidence_metrics=None, confidence_factors=None, confidence_level=None))
+            try:
+                ctx = qps[q][1]
+                for j in range(kk):
+                    if h_ord[q][j] < 0:
+                        break
+                    rec = recs[h_ids[q][j]]
+                    s = h_enh[q][j]
+                    # live hits carry level / parent_code under "metadata": the top-level defaults apply (F8). One validated
+                    # construction (pydantic's compiled validator is faster than model_construct); a negative score fails
+                    # Candidate's ge=0 and degrades the whole match to an empty one, like the reference's
+                    cands.append(Candidate(
+                        code=rec.get("code", ""), title=rec.get("preferred_zh", ""), score=s, level=1, parent_code="",
+                        enhanced_score=s, original_score=h_adj[q][j] if h_boost[q][j] > 0 else h_raw[q][j],
+                        similarity_factors=SimilarityFactors(h_vs[q][j], h_hb[q][j], 0.0, sc, 0.0, ctx)))
+                out.append(DiagnosisMatch(diagnosis_text=diagnosis, candidates=cands,
+                                          match_confidence=self._calculate_match_confidence(cands)))
+            except Exception as exc:
+                logger.error("match failed for %s: %s", diagnosis, exc)
+                out.append(DiagnosisMatch(diagnosis_text=diagnosis, candidates=[], match_confidence=0.0))
         return out
 
     def _match_from_hits(self, diagnosis: str, hits: List[Dict[str, Any]], top_k: int) -> DiagnosisMatch:

@@ -79,6 +79,26 @@ int main() {
             }
             ++cases;
         }
+    // reduction plan of the streaming kernel's per-wave lists: odd number of levels (the levels ping-pong between two
+    // workspaces and finalize reads the second), fan-in <= per_max at every level, the requested final list count (or as few
+    // as possible), at most 512 lists after the first of several levels (workspace sizing)
+    for (int m : {32, 8, 4})
+        for (int pf : {0, m})
+            for (int n = 1; n <= 1024; ++n) {
+                int plan[8];
+                const int c = plan_reduce_levels(n, m, pf, m, plan);
+                bool ok = c > 0 && c <= 8 && c % 2 == 1;
+                int cur = n;
+                for (int i = 0; i < c && ok; ++i) {
+                    const int per = (cur + plan[i] - 1) / plan[i];
+                    if (per > m || plan[i] < 1 || (i == 0 && c > 1 && plan[0] > 512)) ok = false;
+                    cur = plan[i];
+                }
+                if (ok && pf > 0 && plan[c - 1] != pf) ok = false;
+                if (ok && pf == 0 && plan[c - 1] > m) ok = false;
+                if (!ok) { printf("bad reduction plan: nlists=%d per_max=%d p_final=%d\n", n, m, pf); return 1; }
+                ++cases;
+            }
     printf("flat_partition: %d cases ok\n", cases);
     return 0;
 }
