@@ -149,17 +149,22 @@ __device__ __forceinline__ float flush_emit_parallel(const char *smem, uint32_t 
 // VAR: bit flags of the stage variants (A/B builds instantiate several, `make ABLATE=1`; the product one is CF_PRODUCT_VAR)
 //   1    shared-threshold load issued two stages before the tile end (asm, counted wait) instead of a drained load after it
 //   2    LDS-DMA pieces one behind each of the four MFMAs that follow the barrier instead of a burst in front of them
+//   4    LDS-DMA pieces spread over the 16 MFMAs between two barriers, every wave in its own slots (piece i of wave w
+//        behind MFMA 4 i + w): the CU's address unit sees one piece per MFMA instead of sixteen at once
 //   8    query fragments pinned to accumulator registers
+//   16   select: branch-free step per score register (every lane writes, the passing lanes advance their pointer)
+//   32   ring of 3 stages, 64 ring of 6 stages (TIMING ONLY: the compaction scratch aliases the ring)
 //   128  A fragments read two k-steps ahead of their MFMAs instead of one
+//   256  TIMING ONLY: no s_barrier        512  TIMING ONLY: no wait for the LDS-DMA pieces
 //   1024 diagnostic: s_memtime stamps around the mid-stage wait, the barrier and the select (CoarseFlatArgs::dbg)
-//   TIMING ONLY (the results are not the scores; they size the parts of the kernel, profiles/r02_coarse_loop_decomposition.log):
-//   256 no s_barrier   512 no wait for the LDS-DMA pieces   4096 thresholds at +inf (nothing passes)
-//   8192 no select at all   16384 no LDS-DMA inside the tile loop
-// Variants that were measured and dropped (per-wave DMA slots, branch-free select, 3/6-stage rings, select deferred into
-// the next tile's MFMA gaps, 16x16x32 MFMA shape) live in experiments/r02_flat_variants/ with their logs.
+//   2048 deferred select: a finished tile's 64 score registers are copied out of the accumulators and filtered one
+//        register behind every third MFMA of the NEXT tile (an MFMA holds the SIMD's vector issue for 8 of its 32
+//        cycles: a compare + scalar branch in the gap is nearly free), the last tile's in an epilogue
 constexpr int CF_PRODUCT_VAR = 1 + 2 + 8 + 128;   // measured: profiles/r02_ab_flat_variants.log
-__host__ __device__ constexpr int cf_ring_stages(int) { return CO_S; }
-__host__ __device__ constexpr int cf_lds_bytes(int var) { return cf_ring_stages(var) * CO_STAGE_BYTES + CO_BM * CO_CAP * 8 + 4 * 256; }
+__host__ __device__ constexpr int cf_ring_stages(int var) { return (var & 32) ? 3 : ((var & 64) ? 6 : CO_S); }
+__host__ __device__ constexpr int cf_lds_bytes(int var) {
+    return cf_ring_stages(var) * CO_STAGE_BYTES + CO_BM * (CO_CAP * 8 + ((var & 16) ? 4 : 0)) + ((var & 64) ? 0 : 4 * 256);
+}
 #define ICD_CF_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); \
     __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -168,16 +173,21 @@ template <int D, int VAR = CF_PRODUCT_VAR>
 __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     constexpr bool EARLY_THR = (VAR & 1) != 0;
     constexpr bool DMA_SPREAD = (VAR & 2) != 0;
+    constexpr bool DMA_SLOTS = (VAR & 4) != 0;
     constexpr bool Q_AGPR = (VAR & 8) != 0;
+    constexpr bool NOBRANCH = (VAR & 16) != 0;
     constexpr bool PF2 = (VAR & 128) != 0;
     constexpr bool NOBAR = (VAR & 256) != 0, NOVM = (VAR & 512) != 0, STAMPS = (VAR & 1024) != 0;
-    constexpr bool NOPASS = (VAR & 4096) != 0, NOSEL = (VAR & 8192) != 0, NODMA = (VAR & 16384) != 0;
+    constexpr bool DEFER = (VAR & 2048) != 0;
+    constexpr bool NOSEL = (VAR & 8192) != 0;   // TIMING ONLY: no select steps at all
+    constexpr bool SHAPE16 = (VAR & 32768) != 0;  // TIMING ONLY: two v_mfma_f32_16x16x32_f16 per fragment pair (results are NOT the scores)
+    constexpr bool NODMA = (VAR & 16384) != 0;  // TIMING ONLY: no LDS-DMA inside the tile loop (the ring keeps its prologue content)
     constexpr int S = cf_ring_stages(VAR);            // ring slots
     constexpr int VM_MID = NOVM ? 63 : 4 * (S - 3);   // LDS-DMA pieces that may stay in flight at the mid-stage wait
     constexpr int KS = D / CO_BK;      // stages per tile
     constexpr int NF = D / 16;         // query fragments per lane
     static_assert(KS % S == 0, "ring slot must be a compile-time function of the stage");
-    using Ops = Sel2Ops<CO_KP>;
+    using Ops = Sel2Ops<CO_KP, (VAR & 16) ? 4 : 0>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     };
     constexpr uint32_t RING_BYTES = (uint32_t)S * CO_STAGE_BYTES;
     const uint32_t wave_qbase = RING_BYTES + (uint32_t)(wave * 32) * Ops::QBYTES;
-    const uint32_t wave_scratch = RING_BYTES + (uint32_t)CO_BM * Ops::QBYTES + (uint32_t)wave * 256u;
+    const uint32_t wave_scratch = ((VAR & 64) ? 0u : RING_BYTES + (uint32_t)CO_BM * Ops::QBYTES) + (uint32_t)wave * 256u;
     unsigned long long st_vm = 0, st_bar = 0, st_body = 0, st_sel = 0, st_tiles = 0, st_prev = 0;   // (STAMPS)
     unsigned long long st_comp[2] = {0, 0}, st_thr = 0, st_boot = 0;                              // compactions, their cycles
     const int last_tile = a.ctiles - 1;
@@ -263,8 +273,21 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, ldst, 16, src_off[3], soff, 3072, 0);
         };
 
+        // one piece (DMA_SLOTS): slot j of the 16-MFMA window behind a barrier belongs to wave j & 3, piece j >> 2
+        auto issue_slot = [&](auto J, int g_tile, int g_ks, int ring_slot) {
+            constexpr int j = decltype(J)::value;
+            constexpr int i = j >> 2;
+            if (wave == (j & 3)) {
+                const int trow = min(g_tile, last_tile - t0);
+                char *dst = smem + ring_slot * CO_STAGE_BYTES + wave * 4096;
+                const uint32_t soff = (uint32_t)trow * (uint32_t)(CO_BN * D * 2) + (uint32_t)g_ks * (CO_BK * 2);
+                __attribute__((address_space(3))) void *ldst = (__attribute__((address_space(3))) void *)dst;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, ldst, 16, src_off[i], soff, i * 1024, 0);
+            }
+        };
+
         Sel2 st;
-        Ops::init(st, wave_qbase + (uint32_t)c * Ops::QBYTES, h, (slot0 + wave * 32 + c) < a.nq && !NOPASS);
+        Ops::init(st, wave_qbase + (uint32_t)c * Ops::QBYTES, h, (slot0 + wave * 32 + c) < a.nq && !(VAR & 4096));   // (4096: TIMING ONLY, nothing passes)
         float boot1 = -INFINITY, boot2 = -INFINITY, boot3 = -INFINITY;   // bootstrap: the lane's three best scores so far
         // (a third of the list at most: 6 rows above the level per boot_tiles tiles -> >= 18 in the whole list)
         const int boot_tiles = ntiles >= CO_BOOT_MIN_TILES ? min(a.boot_tiles, ntiles / 3) : 0;
@@ -298,13 +321,81 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             }
         };
 
+        // Branch-free select step (VAR & 16): EVERY lane writes its score and row to its next free slot, and only the
+        // lanes whose score passes advance their pointer (a slot written without advancing is overwritten by the next
+        // write): ds_write2st64 + v_add (row) + v_cmp + v_cndmask + v_add per register, no scalar branch - against
+        // compare + branch, which is cheap when no lane passes and ~120 cycles through the out-of-line append block when
+        // one does (a third of the registers). The slot behind a lane's last entry must exist: the per-lane quota is one
+        // lower here (15 + the 8 of a check interval = 23 of the side's 24 slots).
+        constexpr int QUOTA = NOBRANCH ? CO_QUOTA - 1 : CO_QUOTA;
+        auto filter_nobranch = [&](const f32x16 (&pa)[4], auto F, uint32_t rowbase, auto GUARD) {
+            constexpr int f = decltype(F)::value;
+            constexpr int t = f >> 4, r = f & 15;
+            constexpr uint32_t roff = (uint32_t)(t * 32 + (r & 3) + 8 * (r >> 2));
+            float v = pa[t][r];
+            if constexpr (decltype(GUARD)::value) {
+                if ((int)(rowbase + roff) >= a.n) v = -INFINITY;
+            }
+            *reinterpret_cast<float *>(smem + st.aw) = v;
+            *reinterpret_cast<uint32_t *>(smem + st.aw + Ops::ROW_OFF) = rowbase + roff;
+            st.aw += (v > st.thr) ? st.inc : 0u;
+            if constexpr (r % CO_CHECK_EVERY == CO_CHECK_EVERY - 1) {
+                if (__builtin_amdgcn_ballot_w64(Ops::used(st, h) > QUOTA) != 0ull)
+                    Ops::check(st, lane, smem, wave_qbase, wave_scratch, false, CO_LIMIT, STAMPS ? st_comp : nullptr, QUOTA);
+            }
+        };
+
+        // Deferred select (VAR & 2048): the previous tile's scores, filtered between the MFMAs of the current one.
+        // A list starts with nothing pending: -inf never passes (a fresh threshold is -inf, padding queries' +inf).
+        float sel[DEFER ? 64 : 1];
+        uint32_t sel_rowbase = 0u;
+        if constexpr (DEFER) {
+#pragma unroll
+            for (int f = 0; f < 64; ++f) sel[f] = -INFINITY;
+        }
+        auto filter_sel = [&](auto F) {
+            constexpr int f = decltype(F)::value;
+            constexpr int t = f >> 4, r = f & 15;
+            constexpr uint32_t roff = (uint32_t)(t * 32 + (r & 3) + 8 * (r >> 2));
+            const float v = sel[DEFER ? f : 0];
+            const bool pass = v > st.thr;
+            if constexpr (NOBRANCH) {
+                *reinterpret_cast<float *>(smem + st.aw) = v;
+                *reinterpret_cast<uint32_t *>(smem + st.aw + Ops::ROW_OFF) = sel_rowbase + roff;
+                st.aw += pass ? st.inc : 0u;
+            } else if (__builtin_expect(__builtin_amdgcn_ballot_w64(pass) != 0ull, 0)) {
+                asm volatile("" ::: "memory");
+                if (pass) {
+                    *reinterpret_cast<float *>(smem + st.aw) = v;
+                    *reinterpret_cast<uint32_t *>(smem + st.aw + Ops::ROW_OFF) = sel_rowbase + roff;
+                    st.aw += st.inc;
+                }
+            }
+            if constexpr (r % CO_CHECK_EVERY == CO_CHECK_EVERY - 1) {
+                if (__builtin_amdgcn_ballot_w64(Ops::used(st, h) > QUOTA) != 0ull)
+                    Ops::check(st, lane, smem, wave_qbase, wave_scratch, false, CO_LIMIT, STAMPS ? st_comp : nullptr, QUOTA);
+            }
+        };
+        auto issue_piece = [&](auto I, int g_tile, int g_ks, int ring_slot) {
+            constexpr int i = decltype(I)::value;
+            const int trow = min(g_tile, last_tile - t0);
+            char *dst = smem + ring_slot * CO_STAGE_BYTES + wave * 4096;
+            const uint32_t soff = (uint32_t)trow * (uint32_t)(CO_BN * D * 2) + (uint32_t)g_ks * (CO_BK * 2);
+            __attribute__((address_space(3))) void *ldst = (__attribute__((address_space(3))) void *)dst;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, ldst, 16, src_off[i], soff, i * 1024, 0);
+        };
+
         // prologue: stages 0..S-2 in flight, stage 0 published, its first fragments read
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (query fragment loads: the vmcnt accounting starts from zero)
 #pragma unroll
         for (int p = 0; p < S - 2; ++p) issue_stage(p / KS, p % KS, p % S);
-        issue_stage((S - 2) / KS, (S - 2) % KS, (S - 2) % S);
+        if constexpr (DMA_SLOTS) {   // stage S-2: the first half of its window (slots 0..7) here, the rest in stage 0's first half
+            static_for<0, 8>([&](auto J) { issue_slot(J, (S - 2) / KS, (S - 2) % KS, (S - 2) % S); });
+        } else {
+            issue_stage((S - 2) / KS, (S - 2) % KS, (S - 2) % S);
+        }
         half8 afn[4], bfn[4];
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(4 * (S - 2)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(DMA_SLOTS ? 4 * (S - 3) + 2 : 4 * (S - 2)) : "memory");
         read_frags(afn, 0, 0);
         if constexpr (PF2) read_frags(bfn, 0, 1);
         if constexpr (STAMPS) ICD_CF_STAMP(st_prev);
@@ -316,31 +407,67 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+            typedef float f32x4_t __attribute__((ext_vector_type(4)));
+            f32x4_t a16[SHAPE16 ? 8 : 1];
+            if constexpr (SHAPE16) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a16[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
             static_for<0, KS>([&](auto KSI) {
                 constexpr int ks = decltype(KSI)::value;
                 constexpr int slot = ks % S, nslot = (ks + 1) % S;
-                auto mfma4 = [&](const half8 (&f)[4], int qi) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[t], qf[qi], acc[t], 0, 0, 0);
+                // (DMA_SLOTS: window slot base of the k-step's four MFMAs, -1 = none; the window opens at the mid-stage barrier)
+                auto mfma4 = [&](const half8 (&f)[4], auto QI, auto BASE) {
+                    constexpr int base = decltype(BASE)::value;
+                    constexpr int qi = decltype(QI)::value;
+                    static_for<0, 4>([&](auto T) {
+                        constexpr int t = decltype(T)::value;
+                        if constexpr (SHAPE16) {
+                            a16[2 * t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[t], qf[qi], a16[2 * t], 0, 0, 0);
+                            a16[2 * t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[t], qf[(qi + 1) % NF], a16[2 * t + 1], 0, 0, 0);   // (a different B: not foldable into the first)
+                        } else
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[t], qf[qi], acc[t], 0, 0, 0);
+                        if constexpr (DEFER) {
+                            if constexpr ((qi & 3) == 2) {   // the k-step behind the mid-stage barrier: one LDS-DMA piece per MFMA
+                                constexpr int nks = ks + S - 1;
+                                issue_piece(T, tile + nks / KS, nks % KS, nks % S);
+                            }
+                            constexpr int m = qi * 4 + t;    // MFMA number inside the tile, 0..191
+                            if constexpr (m % 3 == 2 && !NOSEL) filter_sel(std::integral_constant<int, m / 3>{});
+                        }
+                        if constexpr (DMA_SLOTS && base >= 0) {
+                            // slots 0..7 carry stage g+S-1 (second half of stage g), slots 8..15 finish stage g+S-2 (first half)
+                            constexpr int nks = base < 8 ? ks + S - 1 : ks + S - 2;
+                            issue_slot(std::integral_constant<int, base + t>{}, tile + nks / KS, nks % KS, nks % S);
+                        }
+                    });
                 };
+                using NoSlot = std::integral_constant<int, -1>;
+                using Slot0 = std::integral_constant<int, DMA_SLOTS ? 0 : -1>;
+                using Slot4 = std::integral_constant<int, DMA_SLOTS ? 4 : -1>;
+                using Slot8 = std::integral_constant<int, DMA_SLOTS ? 8 : -1>;
+                using Slot12 = std::integral_constant<int, DMA_SLOTS ? 12 : -1>;
+                (void)sizeof(NoSlot);
                 // stage g = (tile, ks) was published by the previous mid-stage barrier; afn holds its k-step 0 (PF2: bfn its k-step 1)
                 half8 f1[4], f2[4], f3[4];
                 if constexpr (PF2) {
                     read_frags(f2, slot, 2);
-                    mfma4(afn, ks * 4 + 0);
+                    mfma4(afn, std::integral_constant<int, ks * 4 + 0>{}, Slot8{});
                     read_frags(f3, slot, 3);
-                    mfma4(bfn, ks * 4 + 1);
+                    mfma4(bfn, std::integral_constant<int, ks * 4 + 1>{}, Slot12{});
                 } else {
                     read_frags(f1, slot, 1);
-                    mfma4(afn, ks * 4 + 0);
+                    mfma4(afn, std::integral_constant<int, ks * 4 + 0>{}, Slot8{});
                     read_frags(f2, slot, 2);
-                    mfma4(f1, ks * 4 + 1);
+                    mfma4(f1, std::integral_constant<int, ks * 4 + 1>{}, Slot12{});
                 }
                 // pin: the reads go out before the MFMAs of the k-step in front of them
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                if constexpr (!DMA_SLOTS && !DEFER) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                }
                 // publish stage g+1: this wave's pieces of g+1 have landed when only the stages behind it are outstanding
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (STAMPS) {
@@ -363,22 +490,23 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                     asm volatile("global_load_dword %0, %1, off sc1" : "=v"(seen_early) : "v"(my_shared) : "memory");
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (!NODMA) {   // every wave is past stage g-1: its slot takes stage g+S-1
+                if constexpr (!DMA_SLOTS && !DEFER && !NODMA) {   // every wave is past stage g-1: its slot takes stage g+S-1
                     constexpr int nks = ks + S - 1;
                     issue_stage(tile + nks / KS, nks % KS, nks % S);
                 }
                 if constexpr (PF2) {
                     read_frags(afn, nslot, 0);
-                    mfma4(f2, ks * 4 + 2);
+                    mfma4(f2, std::integral_constant<int, ks * 4 + 2>{}, Slot0{});
                     read_frags(bfn, nslot, 1);
-                    mfma4(f3, ks * 4 + 3);
+                    mfma4(f3, std::integral_constant<int, ks * 4 + 3>{}, Slot4{});
                 } else {
                     read_frags(f3, slot, 3);
-                    mfma4(f2, ks * 4 + 2);
+                    mfma4(f2, std::integral_constant<int, ks * 4 + 2>{}, Slot0{});
                     read_frags(afn, nslot, 0);
-                    mfma4(f3, ks * 4 + 3);
+                    mfma4(f3, std::integral_constant<int, ks * 4 + 3>{}, Slot4{});
                 }
-                if constexpr (!DMA_SPREAD) {          // the four pieces in a burst behind the barrier
+                if constexpr (DMA_SLOTS || DEFER) {
+                } else if constexpr (!DMA_SPREAD) {          // the four pieces in a burst behind the barrier
                     __builtin_amdgcn_sched_group_barrier(0x020, 4, 1);
                     __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
                     __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
@@ -396,6 +524,12 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
+            if constexpr (SHAPE16) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] = a16[2 * t + (r >> 3)][r & 3] + (float)(r >> 2);
+            }
             unsigned long long ts0 = 0;
             if constexpr (STAMPS) ICD_CF_STAMP(ts0);
             // Threshold sharing between the lists of a query (they are swept by different work-groups at the same
@@ -406,7 +540,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             {
                 uint32_t seen;
                 if constexpr (EARLY_THR) {
-                    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(seen_early) : "i"(NOVM ? 0 : 4 * (S - 2)) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(seen_early) : "i"(NOVM ? 0 : (DMA_SLOTS ? 6 : 4 * (S - 2))) : "memory");
                     seen = seen_early;
                 } else {
                     seen = __hip_atomic_load(my_shared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -450,16 +584,35 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                 if (thr0 > st.thr) st.thr = thr0;   // (padding queries keep +inf)
             }
             if constexpr (STAMPS) { unsigned long long ts_b; ICD_CF_STAMP(ts_b); st_boot += ts_b - ts_a; }
+            if constexpr (DEFER) {   // hand the tile to the next tile's MFMA gaps (rows >= n never pass)
+                const bool ragged = tile_row0 + CO_BN > a.n;
+                static_for<0, 64>([&](auto F) {
+                    constexpr int f = decltype(F)::value;
+                    constexpr int t = f >> 4, r = f & 15;
+                    constexpr uint32_t roff = (uint32_t)(t * 32 + (r & 3) + 8 * (r >> 2));
+                    sel[DEFER ? f : 0] = (ragged && (int)(rowbase + roff) >= a.n) ? -INFINITY : acc[t][r];
+                });
+                sel_rowbase = rowbase;
+            } else
             if constexpr (NOSEL) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(acc[t]));
-            } else if (tile_row0 + CO_BN > a.n) static_for<0, 64>([&](auto F) { filter_reg(acc, F, rowbase, std::true_type{}); });
+                for (int t = 0; t < 4; ++t) asm volatile("" :: "v"(acc[t]));
+            } else if constexpr (NOBRANCH) {
+                if (tile_row0 + CO_BN > a.n) static_for<0, 64>([&](auto F) { filter_nobranch(acc, F, rowbase, std::true_type{}); });
+                else static_for<0, 64>([&](auto F) { filter_nobranch(acc, F, rowbase, std::false_type{}); });
+            } else
+            if (tile_row0 + CO_BN > a.n) static_for<0, 64>([&](auto F) { filter_reg(acc, F, rowbase, std::true_type{}); });
             else static_for<0, 64>([&](auto F) { filter_reg(acc, F, rowbase, std::false_type{}); });
             if constexpr (STAMPS) {
                 unsigned long long ts1;
                 ICD_CF_STAMP(ts1);
                 st_sel += ts1 - ts0; st_prev += ts1 - ts0; st_tiles += 1;
             }
+        }
+        if constexpr (DEFER && !NOSEL) static_for<0, 64>([&](auto F) { filter_sel(F); });   // the last tile's scores
+        if constexpr (DEFER && NOSEL) {
+#pragma unroll
+            for (int f = 0; f < 64; ++f) asm volatile("" :: "v"(sel[f]));
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead stages
         asm volatile("" ::"v"(afn[0]), "v"(afn[1]), "v"(afn[2]), "v"(afn[3]));
@@ -474,7 +627,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             const int slot = slot0 + wave * 32 + c;
             const bool store = slot < a.nq;
             const size_t o = ((size_t)min(slot, a.nq - 1) * a.P + ord) * CO_KP;
-            const float bound = flush_emit_parallel<CO_KP>(smem, wave_qbase + (uint32_t)c * Ops::QBYTES, h, c, nlo, nhi, st.thr,
+            const float bound = flush_emit_parallel<CO_KP>(smem, wave_qbase + (uint32_t)c * Ops::QBYTES, h, NOBRANCH ? 0 : c, nlo, nhi, st.thr,
                                                            store, a.part_scores + o, a.part_rows + o);
             if (store && h == 0) {
                 a.bounds[(size_t)slot * a.P + ord] = bound;

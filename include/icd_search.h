@@ -168,6 +168,29 @@ int icd_hier_rescore(int32_t device, const double *adj, const int64_t *ids, int6
                      int32_t *out_order, double *out_enhanced, double *out_score, double *out_vs, double *out_hb,
                      double *out_boost, void *stream);
 
+/* SURVEY.md row N3, score statistics. Replaces np.mean / np.std / np.var / max over the candidates' scores in
+ * MultiDimensionalConfidenceService._assess_model_uncertainty (services/multidimensional_confidence_service.py:936-963)
+ * and ._calculate_prediction_variance (:1087-1099), for nq queries at once, bit-identical to numpy's float64 results.
+ *   scores   [nq][k] device doubles (icd_hier_rescore's out_enhanced, or out_adj of a search), k <= 128
+ *   order    nullable [nq][k] device: entry j of a query exists iff order[j] >= 0 (icd_hier_rescore's out_order)
+ *   use      statistics over the first min(use, existing) entries of every query (the request's top_k)
+ *   out      [nq][6] device doubles: mean, std, var, max, model_uncertainty, prediction_variance
+ */
+int icd_score_stats(int32_t device, const double *scores, const int32_t *order, int64_t nq, int32_t k, int32_t use,
+                    double *out, void *stream);
+
+/* SURVEY.md row N3, semantic coherence. Replaces sklearn cosine_similarity([q], [c])[0][0] in
+ * MultiDimensionalConfidenceService._calculate_semantic_factors (:273-280) for nq query vectors at once: rows
+ * normalised in double, then their dot product (equal to sklearn's to 1e-14; the summation order differs).
+ *   x        [nq][dim] device fp32 query vectors
+ *   y        device fp32: [nq][dim] with y_stride = dim, or ONE row shared by every query with y_stride = 0 (the live
+ *            /query path embeds the empty string as "the candidate": services/multi_diagnosis_service.py:178-186 hands
+ *            the confidence service records without 'preferred_zh')
+ *   out      [nq] device doubles
+ */
+int icd_cosine_rows(int32_t device, const float *x, const float *y, int64_t y_stride, int64_t nq, int32_t dim,
+                    double *out, void *stream);
+
 int icd_index_stats(icd_index *idx, icd_stats *out);
 
 /* Tuning knob / test hook (0 = automatic): aim for about `chunks` candidate lists per query in the coarse pass

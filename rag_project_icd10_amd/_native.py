@@ -27,6 +27,8 @@ EXPORTED_SYMBOLS = (
     "icd_index_stats", "icd_index_set_chunks", "icd_index_debug_counters", "icd_index_set_profiling",
     "icd_index_last_profile", "icd_index_profile_summary", "icd_debug_set_permute",
     "icd_hier_rescore",
+    "icd_score_stats",
+    "icd_cosine_rows",
 )
 
 
@@ -79,6 +81,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.icd_index_set_chunks.argtypes = [vp, i32]
     lib.icd_debug_set_permute.argtypes = [i32]
     lib.icd_hier_rescore.argtypes = [i32, vp, vp, i64, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.icd_score_stats.argtypes = [i32, vp, vp, i64, i32, i32, vp, vp]
+    lib.icd_cosine_rows.argtypes = [i32, vp, vp, i64, i64, i32, vp, vp]
     lib.icd_index_debug_counters.argtypes = [vp, vp, i32]
     lib.icd_index_set_profiling.argtypes = [vp, i32]
     lib.icd_index_last_profile.argtypes = [vp, C.POINTER(_Profile)]
@@ -331,6 +335,45 @@ def hier_rescore(adj, ids, row_tags, q_params, weights, id_base: int = 0):
                                      row_tags.data_ptr(), q_params.data_ptr(), C.cast(w, C.c_void_p), order.data_ptr(),
                                      *[t.data_ptr() for t in outs], _current_stream_ptr(dev.index)))
     return (order, *outs)
+
+
+def score_stats(scores, order=None, use=None):
+    """Row N3 (icd_score_stats): numpy-identical mean / std / var / max of every query's first `use` scores, plus the
+    confidence service's model_uncertainty and prediction_variance. scores f64 [nq,k] on a GPU, order i32 [nq,k] or None
+    (entries with order < 0 do not exist). Returns f64 [nq,6]."""
+    import torch
+    lib = load_library()
+    nq, k = scores.shape
+    dev = scores.device
+    scores = scores.to(torch.float64).contiguous()
+    if order is not None:
+        order = order.to(device=dev, dtype=torch.int32).contiguous()
+        assert order.shape == (nq, k)
+    out = torch.empty((nq, 6), dtype=torch.float64, device=dev)
+    _check(lib, lib.icd_score_stats(dev.index, scores.data_ptr(), order.data_ptr() if order is not None else None, nq, k,
+                                    int(k if use is None else use), out.data_ptr(), _current_stream_ptr(dev.index)))
+    return out
+
+
+def cosine_rows(x, y):
+    """Row N3 (icd_cosine_rows): sklearn-style cosine of every row of x (f32 [nq,dim] on a GPU) with the matching row of
+    y ([nq,dim]) or with the single row y ([dim]); returns f64 [nq]."""
+    import torch
+    lib = load_library()
+    nq, dim = x.shape
+    dev = x.device
+    x = x.to(torch.float32).contiguous()
+    y = y.to(device=dev, dtype=torch.float32).contiguous()
+    if y.dim() == 1:
+        assert y.shape[0] == dim
+        stride = 0
+    else:
+        assert y.shape == (nq, dim)
+        stride = dim
+    out = torch.empty((nq,), dtype=torch.float64, device=dev)
+    _check(lib, lib.icd_cosine_rows(dev.index, x.data_ptr(), y.data_ptr(), stride, nq, dim, out.data_ptr(),
+                                    _current_stream_ptr(dev.index)))
+    return out
 
 
 def merge_topk(scores, ids, levels, k: int):

@@ -16,6 +16,7 @@
 #include "exact_kernel.hpp"
 #include "finalize.hpp"
 #include "hier_kernel.hpp"
+#include "stats_kernel.hpp"
 #include "stream_kernel.hpp"
 
 using namespace icd;
@@ -483,7 +484,9 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             const int v = atoi(fv);
             if (false) {}
 #define ICD_FV_CASE(V) else if (v == V) rc = launch_coarse_flat<768, V>(x, a, nwg, s);
-            ICD_FV_CASE(0) ICD_FV_CASE(CF_PRODUCT_VAR) ICD_FV_CASE(CF_PRODUCT_VAR + 16) ICD_FV_CASE(CF_PRODUCT_VAR + 1024) ICD_FV_CASE(CF_PRODUCT_VAR + 16 + 1024)
+            ICD_FV_CASE(0) ICD_FV_CASE(CF_PRODUCT_VAR) ICD_FV_CASE(CF_PRODUCT_VAR + 1024) ICD_FV_CASE(CF_PRODUCT_VAR + 4096)
+            ICD_FV_CASE(CF_PRODUCT_VAR + 8192) ICD_FV_CASE(CF_PRODUCT_VAR + 8192 + 256) ICD_FV_CASE(CF_PRODUCT_VAR + 8192 + 512)
+            ICD_FV_CASE(CF_PRODUCT_VAR + 8192 + 16384 + 512) ICD_FV_CASE(CF_PRODUCT_VAR + 8192 + 16384 + 768)
 #undef ICD_FV_CASE
             else return fail(ICD_ERR_INVALID, "ICD_FLAT_VAR=%d is not built", v);
         }
@@ -767,6 +770,34 @@ int icd_hier_rescore(int32_t device, const double *adj, const int64_t *ids, int6
     a.out_order = out_order; a.out_enhanced = out_enhanced; a.out_score = out_score; a.out_vs = out_vs; a.out_hb = out_hb;
     a.out_boost = out_boost;
     hipLaunchKernelGGL(hier_rescore_kernel, dim3(((int)nq + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    HIP_TRY(hipGetLastError());
+    return ICD_OK;
+}
+
+int icd_score_stats(int32_t device, const double *scores, const int32_t *order, int64_t nq, int32_t k, int32_t use,
+                    double *out, void *stream) {
+    if (!scores || !out) return fail(ICD_ERR_INVALID, "pointer is NULL");
+    if (k <= 0 || k > STATS_MAX_K || use <= 0) return fail(ICD_ERR_INVALID, "k=%d (1..%d) use=%d", k, STATS_MAX_K, use);
+    if (nq < 0 || nq > 0x7FFFFFFF) return fail(ICD_ERR_INVALID, "nq=%lld", (long long)nq);
+    if (nq == 0) return ICD_OK;
+    HIP_TRY(hipSetDevice(device));
+    StatsArgs a{};
+    a.scores = scores; a.order = order; a.nq = (int)nq; a.k = k; a.use = use; a.out = out;
+    hipLaunchKernelGGL(score_stats_kernel, dim3(((int)nq + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), a);
+    HIP_TRY(hipGetLastError());
+    return ICD_OK;
+}
+
+int icd_cosine_rows(int32_t device, const float *x, const float *y, int64_t y_stride, int64_t nq, int32_t dim,
+                    double *out, void *stream) {
+    if (!x || !y || !out) return fail(ICD_ERR_INVALID, "pointer is NULL");
+    if (dim <= 0 || (y_stride != 0 && y_stride != dim)) return fail(ICD_ERR_INVALID, "dim=%d y_stride=%lld (0 or dim)", dim, (long long)y_stride);
+    if (nq < 0 || nq > 0x7FFFFFFF) return fail(ICD_ERR_INVALID, "nq=%lld", (long long)nq);
+    if (nq == 0) return ICD_OK;
+    HIP_TRY(hipSetDevice(device));
+    CosArgs a{};
+    a.x = x; a.y = y; a.y_stride = y_stride; a.nq = (int)nq; a.dim = dim; a.out = out;
+    hipLaunchKernelGGL(cosine_rows_kernel, dim3(((int)nq + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     HIP_TRY(hipGetLastError());
     return ICD_OK;
 }

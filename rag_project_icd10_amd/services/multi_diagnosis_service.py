@@ -13,9 +13,12 @@ from __future__ import annotations
 import logging
 from typing import Any, Dict, List
 
+import numpy as np
+
 from ..api.icd_models import Candidate, DiagnosisMatch
 from ..tools.text_processor import DiagnosisTextProcessor
 from .hierarchical_similarity_service import HierarchicalSimilarityService
+from .multidimensional_confidence_service import MultiDimensionalConfidenceService
 
 logger = logging.getLogger(__name__)
 
@@ -28,6 +31,9 @@ class MultiDiagnosisService:
         self.hierarchical_similarity = HierarchicalSimilarityService(embedding_service=embedding_service,
                                                                      ner_service=None)
         self.text_processor = DiagnosisTextProcessor(embedding_service=embedding_service)
+        # row N3: only the embedding cosine and the score statistics of the reference's confidence service
+        self.confidence_service = MultiDimensionalConfidenceService(
+            embedding_service=embedding_service, hierarchical_similarity_service=self.hierarchical_similarity)
 
     def match_multiple_diagnoses(self, text: str, top_k: int = 5) -> Dict[str, Any]:
         enhanced = self.text_processor.extract_diagnoses_enhanced(text)
@@ -52,11 +58,15 @@ class MultiDiagnosisService:
                                         "avg_extraction_confidence": sum(confs) / len(confs),
                                         "extraction_method": "simple", "drug_filtering_enabled": False}}
 
-    def match_diagnoses_batch(self, diagnoses: List[str], top_k: int = 5, vectors=None) -> List[DiagnosisMatch]:
+    def match_diagnoses_batch(self, diagnoses: List[str], top_k: int = 5, vectors=None,
+                              confidence_statistics: bool = False) -> List[DiagnosisMatch]:
         """Additive (row N2): embed -> search(2 top_k) -> level reweight -> hierarchical rescoring for MANY diagnosis
         strings with everything between the tokenizer and the final top_k on the GPU: one encoder batch, one search_batch,
         one rescoring launch; only the top_k winners per string come back and become Candidate objects. Same results as
-        _match_from_hits(d, milvus.search(encode_query(d), 2 top_k), top_k) per string (tests/test_gpu_parity.py)."""
+        _match_from_hits(d, milvus.search(encode_query(d), 2 top_k), top_k) per string (tests/test_gpu_parity.py).
+        confidence_statistics=True (row N3) also fills DiagnosisMatch.confidence_factors with the three numbers of the
+        reference's confidence service that are in scope - semantic_coherence (the live shape: cosine with the embedding
+        of the empty string), model_uncertainty, prediction_variance - computed for the whole batch in two launches."""
         from .hierarchical_similarity_service import SimilarityFactors
         if not diagnoses:
             return []
@@ -77,6 +87,14 @@ class MultiDiagnosisService:
         h_ord, h_enh, h_vs, h_hb, h_boost = (t[:, :kk].tolist() for t in (order, enh, vs, hb, boost))
         recs = self.milvus_service.client.records
         sc = 0.3 if hs.embedding_service else 0.5
+        conf = None
+        if confidence_statistics:
+            cs = self.confidence_service
+            stats = cs.score_statistics_batch(enh, order, top_k=kk).tolist()
+            qv = vectors if torch.is_tensor(vectors) else torch.as_tensor(np.asarray(vectors, dtype=np.float32))
+            coh = cs.semantic_coherence_batch(qv.to(adj.device)).tolist()
+            conf = [{"semantic_coherence": coh[q], "model_uncertainty": stats[q][4], "prediction_variance": stats[q][5]}
+                    for q in range(len(diagnoses))]
         out = []
         for q, diagnosis in enumerate(diagnoses):
             cands = []
@@ -95,7 +113,8 @@ class MultiDiagnosisService:
                         enhanced_score=s, original_score=h_adj[q][j] if h_boost[q][j] > 0 else h_raw[q][j],
                         similarity_factors=SimilarityFactors(h_vs[q][j], h_hb[q][j], 0.0, sc, 0.0, ctx)))
                 out.append(DiagnosisMatch(diagnosis_text=diagnosis, candidates=cands,
-                                          match_confidence=self._calculate_match_confidence(cands)))
+                                          match_confidence=self._calculate_match_confidence(cands),
+                                          confidence_factors=conf[q] if conf is not None else None))
             except Exception as exc:
                 logger.error("match failed for %s: %s", diagnosis, exc)
                 out.append(DiagnosisMatch(diagnosis_text=diagnosis, candidates=[], match_confidence=0.0))

@@ -97,7 +97,17 @@ def main():
         md.match_diagnoses_batch(strings, top_k=k, vectors=qv)
         sync()
         st["match_diagnoses_batch_total_ms"] = (time.perf_counter() - t) * 1e3
-        del ids, qp, outs
+        # row N3: the confidence service's cosine + score statistics for the batch (two launches), alone and inside the match
+        t = time.perf_counter()
+        stats = md.confidence_service.score_statistics_batch(outs[1], outs[0], top_k=k)
+        coh = md.confidence_service.semantic_coherence_batch(qv)
+        sync()
+        st["confidence_statistics_device_ms"] = (time.perf_counter() - t) * 1e3
+        t = time.perf_counter()
+        md.match_diagnoses_batch(strings, top_k=k, vectors=qv, confidence_statistics=True)
+        sync()
+        st["match_diagnoses_batch_with_confidence_statistics_ms"] = (time.perf_counter() - t) * 1e3
+        del ids, qp, outs, stats, coh
         return st, hits
 
     batched()   # warm-up (kernel load, allocator)

@@ -51,3 +51,11 @@ def oracle():
     import oracle as orc  # noqa
     orc.build()
     return orc
+
+
+@pytest.fixture(scope="session")
+def confidence_oracle():
+    """oracle/confidence_oracle.py (row N3), imported the way `oracle` is: as a top-level module from oracle/"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import confidence_oracle as co  # noqa
+    return co
