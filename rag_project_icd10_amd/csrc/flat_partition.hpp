@@ -12,6 +12,8 @@
 
 namespace icd {
 
+constexpr int FLAT_SPARE_TILES = 7;   // zero tiles allocated behind the fp16 corpus image (plan_flat_tiles may sweep them)
+
 // number of lists a run of `len` tiles is cut into
 ICD_HD inline int flat_lists_of_run(int len, int list_tiles) { return (len + list_tiles - 1) / list_tiles; }
 
@@ -27,6 +29,37 @@ ICD_HD inline int flat_first_ordinal(int m, int w, int ctiles, int U, int list_t
     return ord;
 }
 
+
+// Work-groups l and l + T start on the same corpus tile, T = ctiles / gcd(U mod ctiles, ctiles): they stream the same
+// tiles at the same time and, placed on one XCD (flat_workgroup_of_block), share its L2.
+ICD_HD inline int flat_class_period(int U, int ctiles) {
+    int g = U % ctiles, h = ctiles;   // gcd(0, c) = c
+    while (g) { const int t = h % g; h = g; g = t; }
+    return ctiles / h;
+}
+
+// Tiles per work-group U and the corpus tile count to sweep (ctiles_min .. ctiles_min + spare; the tiles past the corpus
+// are zero rows that never pass the select). The smallest U leaves every CU the same number of tiles, but when it is
+// coprime to the tile count no two work-groups ever stream the same tile together and every XCD fetches the corpus for
+// itself (measured: 40 474 rows = 317 tiles, U = 98: 0.771 ms; 320 tiles, U = 100: 0.721 ms, the rate of the 37 000-row
+// case). Cost model: time ~ U, +7 % when classes have fewer than two members, +3 % below four.
+struct FlatPlan { int ctiles, U; };
+ICD_HD inline FlatPlan plan_flat_tiles(int mtc, int ctiles_min, int spare, int num_cu) {
+    FlatPlan best{ctiles_min, 1};
+    double best_cost = 1e300;
+    for (int ce = ctiles_min; ce <= ctiles_min + spare; ++ce) {
+        const long long units = (long long)mtc * ce;
+        const int umin = (int)((units + num_cu - 1) / num_cu) > 1 ? (int)((units + num_cu - 1) / num_cu) : 1;
+        const int umax = umin + (umin / 16 > 1 ? umin / 16 : 1);
+        for (int U = umin; U <= umax; ++U) {
+            const int nwg = (int)((units + U - 1) / U);
+            const int members = nwg / flat_class_period(U, ce);
+            const double cost = (double)U * (members >= 4 ? 1.0 : (members >= 2 ? 1.03 : 1.07));
+            if (cost < best_cost - 1e-9) { best_cost = cost; best.ctiles = ce; best.U = U; }
+        }
+    }
+    return best;
+}
 
 // work-group index of hardware block `w` of a grid of G: every XCD (blockIdx mod 8) gets a contiguous stretch of the
 // class-major order of the logical indices (class = index mod T: work-groups of a class start on the same corpus

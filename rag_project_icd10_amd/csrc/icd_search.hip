@@ -409,12 +409,16 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     rec(x, 1, s);
 
     const int mtc = nq_pad / 128;
-    const int ctiles = x->n_pad / 128;
+    // corpus tiles to sweep and tiles per work-group (flat_partition.hpp: a few zero tiles behind the corpus buy a tile
+    // count that shares a factor with U, i.e. work-groups that stream the same tiles together)
+    const int ctiles_min = (int)((x->n + 127) / 128);
+    const FlatPlan plan = plan_flat_tiles(mtc, ctiles_min, x->n_pad / 128 - ctiles_min, x->num_cu);
+    const int ctiles = plan.ctiles;
     int pc = 0;
     {
         // ---- product: flat partition of the (query tile x corpus tile) grid over the CUs (coarse_flat_kernel.hpp) ----
         CoarseFlatArgs a{};
-        a.q16 = x->q16; a.c16 = x->c16; a.nq = nq; a.n = (int)x->n; a.n_pad = x->n_pad; a.ctiles = ctiles;
+        a.q16 = x->q16; a.c16 = x->c16; a.nq = nq; a.n = (int)x->n; a.n_pad = ctiles * 128; a.ctiles = ctiles;
         a.total_units = mtc * ctiles;
         // A query's lists should number at least two of comparable length: the certificate compares against the
         // largest score any list may have dropped, and with one list that is the query's own 16th best (8 % of
@@ -427,7 +431,12 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         // of the whole corpus or the list's bound lands inside the window: fewer tiles for larger k (measured at
         // k = 48 with 8 tiles: 1.6 % of the queries uncertified).
         a.boot_tiles = std::max(1, std::min(CO_BOOT_TILES, 96 / std::max(1, k)));
-        int U = std::max(1, (a.total_units + x->num_cu - 1) / x->num_cu);
+        int U = plan.U;
+#ifdef ICD_ABLATE
+        if (const char *e = getenv("ICD_FLAT_U")) U = std::max(U, atoi(e));   // A/B: tiles per work-group
+        if (const char *e = getenv("ICD_FLAT_LIST")) a.list_tiles = std::max(1, atoi(e));   // A/B: tiles per list
+        if (const char *e = getenv("ICD_FLAT_BOOT")) a.boot_tiles = std::max(0, atoi(e));   // A/B: bootstrap tiles
+#endif
         if (x->chunks_override > 0) {   // test hook: about `chunks` lists per query
             U = std::max(1, (ctiles + x->chunks_override - 1) / x->chunks_override);
             a.list_tiles = ctiles;
@@ -452,9 +461,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             return fail(ICD_ERR_INVALID, "coarse workspace too small for nq=%d (lists per query %d)", nq, P);
         a.units_per_wg = U; a.P = P;
         {
-            int g = U % ctiles, h2 = ctiles;   // gcd(U mod ctiles, ctiles); gcd(0, c) = c
-            while (g) { const int t = h2 % g; h2 = g; g = t; }
-            a.pos_period = ctiles / h2;
+            a.pos_period = flat_class_period(U, ctiles);
             // A class of work-groups that stream the same tiles should have about a dozen members per XCD-local
             // group: many more and they all hit the same L2 channel at the same time (measured slower), so large
             // classes are split into sub-classes (l mod T s also start on the same tile).
@@ -554,7 +561,7 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     icd_index *x = new (std::nothrow) icd_index();
     if (!x) return fail(ICD_ERR_NOMEM, "host allocation failed");
     x->device = device; x->n = n; x->id_base = id_base; x->dim = dim;
-    x->n_pad = (int)(((n + 127) / 128) * 128);
+    x->n_pad = (int)(((n + 127) / 128 + FLAT_SPARE_TILES) * 128);   // (zero tiles behind the fp16 image: plan_flat_tiles)
     x->max_nq = max_nq; x->max_nq_pad = ((max_nq + 127) / 128) * 128; x->max_k = max_k;
     x->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const bool fast_dim = (dim == 768 || dim == 1024);

@@ -99,6 +99,29 @@ int main() {
                 if (!ok) { printf("bad reduction plan: nlists=%d per_max=%d p_final=%d\n", n, m, pf); return 1; }
                 ++cases;
             }
+    // tile planner: U never below the balanced minimum nor more than ~6 % (+1) above it, the swept tile count inside the
+    // allocation, the class period consistent with gcd; the planned partition itself is a valid one; the two measured cases
+    for (int mtc : {1, 2, 3, 8, 40, 79, 128, 782, 977})
+        for (int ct : {1, 2, 3, 33, 100, 289, 290, 317, 320, 1000, 9766, 78125})
+            for (int spare : {0, 7})
+                for (int cus : {1, 8, 256}) {
+                    const FlatPlan p = plan_flat_tiles(mtc, ct, spare, cus);
+                    const long long units = (long long)mtc * p.ctiles;
+                    const long long umin = (units + cus - 1) / cus > 1 ? (units + cus - 1) / cus : 1;
+                    bool ok = p.ctiles >= ct && p.ctiles <= ct + spare && p.U >= umin && p.U <= umin + (umin / 16 > 1 ? umin / 16 : 1);
+                    const int T = flat_class_period(p.U, p.ctiles);
+                    ok = ok && T >= 1 && p.ctiles % T == 0 && ((long long)p.U * T) % p.ctiles == 0;
+                    if (!ok) { printf("bad tile plan: mtc=%d ctiles=%d spare=%d cus=%d -> ctiles=%d U=%d\n", mtc, ct, spare, cus, p.ctiles, p.U); return 1; }
+                    if (units <= 400000 && check(mtc, p.ctiles, p.U, (p.ctiles + 1) / 2)) { printf("planned partition invalid\n"); return 1; }
+                    ++cases;
+                }
+    {
+        const FlatPlan a = plan_flat_tiles(79, 290, 7, 256), b = plan_flat_tiles(79, 317, 7, 256);
+        if (a.ctiles != 290 || a.U != 90 || b.ctiles != 319 || b.U != 99) {
+            printf("tile plan changed: 37 000 rows -> (%d, %d), 40 474 rows -> (%d, %d)\n", a.ctiles, a.U, b.ctiles, b.U);
+            return 1;
+        }
+    }
     printf("flat_partition: %d cases ok\n", cases);
     return 0;
 }
