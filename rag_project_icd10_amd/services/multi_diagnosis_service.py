@@ -4,8 +4,9 @@ hot path, reduced to the parts that are in scope.
 Follows the reference's services/multi_diagnosis_service.py: match_multiple_diagnoses (:51-125) and
 _match_single_diagnosis_enhanced steps 2-4 (:152-175); match confidence is the reference's own
 original formula _calculate_match_confidence (:276-304). NOT reproduced (out of scope, SURVEY.md
-section 2): the NER model (query_entities is {}), the semantic-boundary splitter (delimiter split
-only) and the 12-factor confidence service. Difference by design (row N2): all diagnoses of a
+section 2): the semantic-boundary splitter (delimiter split only) and the 12-factor confidence service beyond row
+N3's pieces. The NER service (row N4) is optional: without one, query_entities is {}; the all-device batch path
+(match_diagnoses_batch) never uses entities. Difference by design (row N2): all diagnoses of a
 request are embedded in ONE encoder batch and searched in ONE search_batch call.
 """
 from __future__ import annotations
@@ -24,12 +25,15 @@ logger = logging.getLogger(__name__)
 
 
 class MultiDiagnosisService:
-    def __init__(self, embedding_service, milvus_service):
+    def __init__(self, embedding_service, milvus_service, ner_service=None):
+        """ner_service: a MedicalNERService (row N4) or None. The reference always builds one (:28); here it is opt-in
+        because its weights are not available offline - with one given, the per-request path extracts the entities of
+        all diagnoses of a request in ONE classifier batch and hands them to the rescoring like the reference (:147-158)."""
         self.embedding_service = embedding_service
         self.milvus_service = milvus_service
-        self.ner_service = None
+        self.ner_service = ner_service
         self.hierarchical_similarity = HierarchicalSimilarityService(embedding_service=embedding_service,
-                                                                     ner_service=None)
+                                                                     ner_service=ner_service)
         self.text_processor = DiagnosisTextProcessor(embedding_service=embedding_service)
         # row N3: only the embedding cosine and the score statistics of the reference's confidence service
         self.confidence_service = MultiDimensionalConfidenceService(
@@ -51,7 +55,9 @@ class MultiDiagnosisService:
         except Exception as exc:
             logger.error("batch search failed: %s", exc)
             hit_lists = [[] for _ in diagnoses]
-        matches = [self._match_from_hits(d, hits, top_k) for d, hits in zip(diagnoses, hit_lists)]
+        entities = self.ner_service.extract_medical_entities_batch(diagnoses, filter_drugs=True) if self.ner_service \
+            else [{} for _ in diagnoses]
+        matches = [self._match_from_hits(d, hits, top_k, ents) for d, hits, ents in zip(diagnoses, hit_lists, entities)]
         return {"original_text": text, "extracted_diagnoses": diagnoses, "matches": matches,
                 "total_matches": sum(len(m.candidates) for m in matches), "processing_mode": mode,
                 "extraction_metadata": {"enhanced_results_count": len(enhanced),
@@ -120,9 +126,10 @@ class MultiDiagnosisService:
                 out.append(DiagnosisMatch(diagnosis_text=diagnosis, candidates=[], match_confidence=0.0))
         return out
 
-    def _match_from_hits(self, diagnosis: str, hits: List[Dict[str, Any]], top_k: int) -> DiagnosisMatch:
+    def _match_from_hits(self, diagnosis: str, hits: List[Dict[str, Any]], top_k: int,
+                         query_entities: Dict[str, Any] = None) -> DiagnosisMatch:
         try:
-            rescored = self.hierarchical_similarity.batch_calculate_similarities(diagnosis, {}, hits)
+            rescored = self.hierarchical_similarity.batch_calculate_similarities(diagnosis, query_entities or {}, hits)
             candidates = []
             for rec, score, factors in rescored[:top_k]:
                 cand = Candidate(code=rec.get("code", ""), title=rec.get("title", ""), score=float(score))

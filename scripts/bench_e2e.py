@@ -58,6 +58,11 @@ def main():
     hs = HierarchicalSimilarityService(embedding_service=es)
     from rag_project_icd10_amd.services.multi_diagnosis_service import MultiDiagnosisService
     md = MultiDiagnosisService(es, ms)
+    os.environ.setdefault("ICD_NER_ALLOW_SYNTHETIC", "1")
+    from rag_project_icd10_amd.services.medical_ner_service import MedicalNERService
+    ner = MedicalNERService()
+    if not ner.use_model:
+        ner = None
 
     def sync():
         if torch.cuda.is_available():
@@ -110,6 +115,14 @@ def main():
         st["confidence_statistics_device_ms"] = (time.perf_counter() - t) * 1e3
         st["match_diagnoses_batch_with_confidence_statistics_ms"] = best_of(
             lambda: md.match_diagnoses_batch(strings, top_k=k, vectors=qv, confidence_statistics=True))
+        # row N4: the NER token classifier (BERT-base shape) over the same strings: one padded batch vs one string per forward
+        if ner is not None:
+            st["ner_batch_1000_strings_ms"] = best_of(lambda: ner.extract_medical_entities_batch(strings), reps=2)
+            t = time.perf_counter()
+            for q in strings[:50]:
+                ner.extract_medical_entities(q)
+            sync()
+            st["ner_one_string_per_call_ms_per_string"] = (time.perf_counter() - t) * 1e3 / 50
         # tokenise + encode + everything above, in one call
         st["strings_to_matches_one_call_ms"] = best_of(lambda: md.match_diagnoses_batch(strings, top_k=k, confidence_statistics=True))
         del ids, qp, outs, stats, coh

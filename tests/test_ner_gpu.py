@@ -1,0 +1,54 @@
+"""SURVEY.md row N4 on the GPU: the token classifier's ROCm forward (padded batches) against the fixture made with
+transformers' own pipeline on the CPU, and the BERT-base-sized synthetic classifier batched vs one string per forward."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_tiny_classifier_on_gpu_equals_pipeline_fixture():
+    import torch
+    from test_ner_cpu import tiny_model
+    from rag_project_icd10_amd.services.medical_ner_service import _TokenClassifier
+    assert torch.cuda.is_available()
+    gold = json.load(open(os.path.join(GOLD, "ner_cases.json"), encoding="utf-8"))
+    model, tok, id2label = tiny_model(gold)
+    clf = _TokenClassifier(model, tok, id2label, "cuda", max_batch=16)
+    outs = gold["pipeline"]["outputs"]
+    got = clf([o["text"] for o in outs])
+    assert next(clf.model.parameters()).is_cuda
+    for o, g in zip(outs, got):
+        assert [(x["entity_group"], x["word"], x["start"], x["end"]) for x in g] == \
+               [(x["entity_group"], x["word"], x["start"], x["end"]) for x in o["groups"]], o["text"]
+        assert all(abs(float(a["score"]) - b["score"]) <= 5e-5 for a, b in zip(g, o["groups"]))
+
+
+def test_bert_base_classifier_batched_equals_single_on_gpu(monkeypatch):
+    import torch
+    from rag_project_icd10_amd.services.medical_ner_service import MedicalNERService
+    monkeypatch.setenv("MEDICAL_NER_MODEL", "/nonexistent/ner-model")
+    monkeypatch.setenv("ICD_NER_ALLOW_SYNTHETIC", "1")
+    svc = MedicalNERService()
+    assert svc.use_model and svc.synthetic and svc.ner_pipeline is not None and svc.ner_pipeline.device == "cuda"
+    strings = [l.strip() for l in open(os.path.join(GOLD, "diagnosis_strings.txt"), encoding="utf-8") if l.strip()][:96]
+    strings += ["", "x" * 700]
+    clf = svc.ner_pipeline
+    live = [s for s in strings if s.strip()]
+    enc = [clf._encode(s) for s in live]
+    batched = clf._forward(enc)
+    worst = 0.0
+    for i in (0, 1, 17, 50, len(live) - 1):
+        labels, scores = clf._forward([enc[i]])[0]
+        assert len(labels) == len(batched[i][0]) == len(enc[i][0])
+        worst = max(worst, float(np.abs(scores - batched[i][1]).max()))
+        assert np.mean(np.array(labels) == np.array(batched[i][0])) >= 0.9    # (random-init logits: near-ties may flip)
+    assert worst <= 5e-4, worst                      # fp32 BERT-base, padded vs unpadded attention
+    assert len(enc[-1][0]) == 512                    # truncated like the pipeline does
+    out = svc.extract_medical_entities_batch(strings)
+    assert len(out) == len(strings) and out[-2] == {} and all(isinstance(o, dict) for o in out)
+    assert svc.get_model_info()["device"] == "GPU" and svc.get_entity_summary(strings[0])["extraction_method"] == "model"
