@@ -191,6 +191,7 @@ int icd_score_stats(int32_t device, const double *scores, const int32_t *order, 
 int icd_cosine_rows(int32_t device, const float *x, const float *y, int64_t y_stride, int64_t nq, int32_t dim,
                     double *out, void *stream);
 
+/* (waits for the device: last_fallback is read from the device when asked for, not copied back by every search) */
 int icd_index_stats(icd_index *idx, icd_stats *out);
 
 /* Tuning knob / test hook (0 = automatic): aim for about `chunks` candidate lists per query in the coarse pass

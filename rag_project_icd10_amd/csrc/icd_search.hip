@@ -112,7 +112,6 @@ struct icd_index {
     bool *ev_valid = evring_valid[0];
     int64_t last_nq = 0;
     int last_chunks = 0, last_mode = 0;
-    int *h_nflag = nullptr;  // pinned
     unsigned long long *dbg = nullptr;  // diagnostic cycle counters [8192][4][4]
 };
 
@@ -128,7 +127,6 @@ void free_all(icd_index *x) {
     hipFree(x->o_scores); hipFree(x->o_ids); hipFree(x->o_adj); hipFree(x->o_adj_raw);
     hipFree(x->o_adj_ids); hipFree(x->o_adj_lv);
     hipFree(x->dbg);
-    if (x->h_nflag) hipHostFree(x->h_nflag);
     for (int r = 0; r < EV_RING; ++r)
         for (int i = 0; i <= NUM_EV; ++i)
             if (x->evring[r][i]) hipEventDestroy(x->evring[r][i]);
@@ -286,7 +284,6 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     for (int i = 0; i <= NUM_EV; ++i) x->ev_valid[i] = false;
     x->last_nq = nq;
     x->last_mode = use_fast ? ICD_MODE_AUTO : ICD_MODE_EXACT;
-    HIP_TRY(hipMemsetAsync(x->nflag, 0, sizeof(int), s));
     rec(x, 0, s);
 
     FinArgs f{};
@@ -380,13 +377,17 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     const bool stream_ok = x->dim % (32 * ST_PF) == 0 && stream_fits(kpx, 1, x->dim);
     // (k > 16 needs the 64-entry lists of the streaming kernel, ~0.9 ms per 16 queries: the coarse pass is faster there)
     const bool tiny = stream_ok && nq <= (use_fast ? (k <= 16 ? 16 : 0) : ST_MAX_ACTIVE);
+    // (the fallback counter starts every search at zero: the exact-only paths clear it here, the fast path in its
+    //  query-prep launch - one launch less per step)
     if (tiny) {
+        HIP_TRY(hipMemsetAsync(x->nflag, 0, sizeof(int), s));
         x->last_mode = ICD_MODE_EXACT;
         x->last_chunks = p_sparse;
         rec(x, 3, s);
         return run_exact(nullptr, nullptr, p_sparse, false, true);
     }
     if (!use_fast) {
+        HIP_TRY(hipMemsetAsync(x->nflag, 0, sizeof(int), s));
         int px = pick_chunks(mtx, row_tiles, pmax_x, 2 * x->num_cu);
         px = fit_p(px, x->partx_cap, kpx);
         if ((size_t)nq * px * kpx > x->partx_cap) return fail(ICD_ERR_INVALID, "workspace too small for nq=%d k=%d", nq, k);
@@ -403,7 +404,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     const int nq_pad = ((nq + 127) / 128) * 128;
     ConvertArgs cv{};
     cv.src = dq; cv.dst = x->q16; cv.rows = nq; cv.rows_pad = nq_pad; cv.dim = x->dim; cv.mode = 0;
-    cv.norm = x->qnorm; cv.scale_exp = x->qexp; cv.bad = x->qbad; cv.zero_u32 = x->shared_thr;
+    cv.norm = x->qnorm; cv.scale_exp = x->qexp; cv.bad = x->qbad; cv.zero_u32 = x->shared_thr; cv.zero_i32 = x->nflag;
     hipLaunchKernelGGL(convert_rows_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, s, cv);
     HIP_TRY(hipGetLastError());
     rec(x, 1, s);
@@ -658,8 +659,6 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     const size_t no = (size_t)max_nq * max_k;
     CR_TRY(wsalloc(&x->o_scores, no)); CR_TRY(wsalloc(&x->o_ids, no)); CR_TRY(wsalloc(&x->o_adj, no));
     CR_TRY(wsalloc(&x->o_adj_raw, no)); CR_TRY(wsalloc(&x->o_adj_ids, no)); CR_TRY(wsalloc(&x->o_adj_lv, no));
-    CR_TRY(hipHostMalloc(reinterpret_cast<void **>(&x->h_nflag), sizeof(int), hipHostMallocDefault));
-    *x->h_nflag = 0;
     for (int r = 0; r < EV_RING; ++r)
         for (int i = 0; i <= NUM_EV; ++i) CR_TRY(hipEventCreate(&x->evring[r][i]));
     CR_TRY(hipDeviceSynchronize());
@@ -703,7 +702,6 @@ static int search_common(icd_index *x, const float *queries, int64_t nq, int32_t
     }
     int rc = search_device(x, dq, (int)nq, k, mode, dev, s);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(x->h_nflag, x->nflag, sizeof(int), hipMemcpyDeviceToHost, s));
     rec(x, NUM_EV, s);
     if (!out_on_device) {
         const size_t no = (size_t)nq * k;
@@ -832,7 +830,15 @@ int icd_index_stats(icd_index *idx, icd_stats *out) {
     out->max_nq = idx->max_nq; out->max_k = idx->max_k; out->fast_path = idx->fast ? 1 : 0;
     out->rmax = idx->rmax;
     out->last_nq = idx->last_nq;
-    out->last_fallback = idx->h_nflag ? *idx->h_nflag : 0;
+    // the last search's fallback count is read from the device here, not copied back by every search: this call waits
+    // for the device (a diagnostic, not part of the search path)
+    int nf = 0;
+    if (idx->nflag && idx->last_nq > 0) {
+        HIP_TRY(hipSetDevice(idx->device));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(&nf, idx->nflag, sizeof(int), hipMemcpyDeviceToHost));
+    }
+    out->last_fallback = nf;
     out->last_chunks = idx->last_chunks; out->last_mode = idx->last_mode;
     return ICD_OK;
 }
