@@ -32,7 +32,7 @@ struct CoarseFlatArgs {
     int list_tiles;          // a list covers at most this many tiles
     int boot_tiles;          // threshold bootstrap over at most this many first tiles of a list (less for larger k)
     int P;                   // list slots per query (>= the largest number of lists of any query tile)
-    float *part_scores;      // [nq][P][KP]
+    float *part_scores;      // [nq][P][KP] (KP = the instantiation's candidates per list)
     int *part_rows;
     float *bounds;           // [nq][P]
     unsigned int *shared_thr; // [nq_pad] order_f32 keys, cleared before the launch: max over a query's lists of their thresholds
@@ -40,7 +40,7 @@ struct CoarseFlatArgs {
 };
 
 constexpr int CO_BOOT_MIN_TILES = 6;   // lists at least this long bootstrap their threshold ...
-constexpr int CO_QUOTA = (CO_CAP - CO_KP) / 2 - CO_CHECK_EVERY;   // 16: appends per lane between compactions
+constexpr int CO_KP_WIDE = 24;         // candidates per list of the instantiation for larger k (see icd_search.hip)
 constexpr int CO_BOOT_TILES = 8;       // ... over their first tiles
 
 // End of a list, all 32 queries of the wave at once (lane = half a query; the one-query-at-a-time compaction of
@@ -164,8 +164,11 @@ __host__ __device__ constexpr int cf_lds_bytes(int var) { return cf_ring_stages(
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); \
     __builtin_amdgcn_sched_barrier(0); } while (0)
 
-template <int D, int VAR = CF_PRODUCT_VAR>
+template <int D, int VAR = CF_PRODUCT_VAR, int KP = CO_KP>
 __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
+    // appends per lane between compactions: the buffer holds the KP kept entries + 2 x (quota + one check interval)
+    constexpr int CO_QUOTA = (CO_CAP - KP) / 2 - CO_CHECK_EVERY;   // 16 at KP = 16, 12 at KP = 24
+    static_assert(CO_QUOTA >= 8 && KP + 2 * (CO_QUOTA + CO_CHECK_EVERY) <= CO_CAP, "candidate buffer layout");
     constexpr bool EARLY_THR = (VAR & 1) != 0;
     constexpr bool DMA_SPREAD = (VAR & 2) != 0;
     constexpr bool Q_AGPR = (VAR & 8) != 0;
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     constexpr int KS = D / CO_BK;      // stages per tile
     constexpr int NF = D / 16;         // query fragments per lane
     static_assert(KS % S == 0, "ring slot must be a compile-time function of the stage");
-    using Ops = Sel2Ops<CO_KP>;
+    using Ops = Sel2Ops<KP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -473,15 +476,15 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             const int nlo = st.kept + (h ? other : mine), nhi = h ? mine : other;
             const int slot = slot0 + wave * 32 + c;
             const bool store = slot < a.nq;
-            const size_t o = ((size_t)min(slot, a.nq - 1) * a.P + ord) * CO_KP;
-            const float bound = flush_emit_parallel<CO_KP>(smem, wave_qbase + (uint32_t)c * Ops::QBYTES, h, c, nlo, nhi, st.thr,
+            const size_t o = ((size_t)min(slot, a.nq - 1) * a.P + ord) * KP;
+            const float bound = flush_emit_parallel<KP>(smem, wave_qbase + (uint32_t)c * Ops::QBYTES, h, c, nlo, nhi, st.thr,
                                                            store, a.part_scores + o, a.part_rows + o);
             if (store && h == 0) {
                 a.bounds[(size_t)slot * a.P + ord] = bound;
                 if (t1 == a.ctiles) {   // last list of the query tile: the unused ordinals are empty
                     for (int e = ord + 1; e < a.P; ++e) {
-                        const size_t oe = ((size_t)slot * a.P + e) * CO_KP;
-                        for (int d = 0; d < CO_KP; ++d) { a.part_scores[oe + d] = -INFINITY; a.part_rows[oe + d] = -1; }
+                        const size_t oe = ((size_t)slot * a.P + e) * KP;
+                        for (int d = 0; d < KP; ++d) { a.part_scores[oe + d] = -INFINITY; a.part_rows[oe + d] = -1; }
                         a.bounds[(size_t)slot * a.P + e] = -INFINITY;
                     }
                 }

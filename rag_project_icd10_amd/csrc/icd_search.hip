@@ -169,9 +169,9 @@ int launch_exact(icd_index *x, const ExactArgs &a, int mtiles, hipStream_t s) {
     return ICD_OK;
 }
 
-template <int D, int VAR = CF_PRODUCT_VAR>
+template <int D, int VAR = CF_PRODUCT_VAR, int KP = CO_KP>
 int launch_coarse_flat(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream_t s) {
-    auto kern = coarse_flat_kernel<D, VAR>;
+    auto kern = coarse_flat_kernel<D, VAR, KP>;
     constexpr int lds = cf_lds_bytes(VAR);
     static int configured[MAX_DEVICES] = {};   // (guarded by the caller's one-stream-per-handle contract; worst case a repeated call)
     HIP_TRY(ensure_dynamic_lds(kern, x->device, (size_t)(lds), configured));
@@ -416,6 +416,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     const FlatPlan plan = plan_flat_tiles(mtc, ctiles_min, x->n_pad / 128 - ctiles_min, x->num_cu);
     const int ctiles = plan.ctiles;
     int pc = 0;
+    const bool wide_lists = k > 64 && x->dim == 768;
     {
         // ---- product: flat partition of the (query tile x corpus tile) grid over the CUs (coarse_flat_kernel.hpp) ----
         CoarseFlatArgs a{};
@@ -425,9 +426,16 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         // largest score any list may have dropped, and with one list that is the query's own 16th best (8 % of
         // Gaussian queries then fail, profiles/r01_sizes_before_pmin2.log); with two or more it is about rank 32.
         a.list_tiles = std::max(1, (ctiles + 1) / 2);
-        // Larger k: every list keeps KP = 16 candidates and ends on its own 16th best, so the bound the certificate
-        // compares the k-th best against sits near rank 16 P / 2 of the whole corpus: ask for about k / 4 lists.
-        if (k > 8) a.list_tiles = std::max(1, std::min(a.list_tiles, ctiles / ((k + 3) / 4)));
+        // Larger k: every list keeps KP candidates and ends on its own KP-th best, so the bound the certificate
+        // compares the k-th best against sits near rank KP P / 2 of the whole corpus: ask for about k / 4 lists of 16.
+        // Above k = 64 (dim 768) the lists keep 24: a query fails the certificate when ONE list holds more than KP of
+        // the ~1.3 k rows around its top-k - with 16 that happens to 3-5 of 10 000 queries at k = 100 and costs an exact
+        // corpus sweep per batch (0.34 ms); with 24 per list and about k / 6 lists it did not happen. The wider lists make
+        // the coarse pass ~20 % slower (lower thresholds, more appends), so they only pay where that sweep is the larger
+        // cost: k = 100 1.69 -> 1.54 ms, k = 32 would go 0.87 -> 0.99 (profiles/r02_tile_planner_and_shapes.log).
+        const int kp_c = wide_lists ? CO_KP_WIDE : CO_KP;
+        if (wide_lists) a.list_tiles = std::max(1, std::min(a.list_tiles, ctiles / ((k + 5) / 6)));
+        else if (k > 8) a.list_tiles = std::max(1, std::min(a.list_tiles, ctiles / ((k + 3) / 4)));
         // The bootstrap level (6th best of the first boot_tiles * 128 rows of a list) must stay far below the k-th best
         // of the whole corpus or the list's bound lands inside the window: fewer tiles for larger k (measured at
         // k = 48 with 8 tiles: 1.6 % of the queries uncertified).
@@ -452,13 +460,15 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             return worst;
         };
         int P = lists_needed(U);
-        while (P > COARSE_MAX_P || (size_t)nq * P * CO_KP > x->partc_cap) {
-            if (U >= ctiles && a.list_tiles >= ctiles) break;
-            if (U < ctiles) U = std::min(ctiles, U + std::max(1, U / 4));
-            else a.list_tiles = std::min(ctiles, a.list_tiles * 2);
+        // too many lists for the workspace or for finalize's candidate window: longer lists first (the balance of the
+        // partition is untouched), more tiles per work-group only when a list already spans the corpus
+        while (P > COARSE_MAX_P || P * kp_c > FIN_MAX_CAND || (size_t)nq * P * kp_c > x->partc_cap) {
+            if (a.list_tiles < ctiles) a.list_tiles = std::min(ctiles, a.list_tiles + std::max(1, a.list_tiles / 8));
+            else if (U < ctiles) U = std::min(ctiles, U + std::max(1, U / 4));
+            else break;
             P = lists_needed(U);
         }
-        if (P > COARSE_MAX_P || (size_t)nq * P * CO_KP > x->partc_cap)
+        if (P > COARSE_MAX_P || P * kp_c > FIN_MAX_CAND || (size_t)nq * P * kp_c > x->partc_cap)
             return fail(ICD_ERR_INVALID, "coarse workspace too small for nq=%d (lists per query %d)", nq, P);
         a.units_per_wg = U; a.P = P;
         {
@@ -499,13 +509,14 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             else return fail(ICD_ERR_INVALID, "ICD_FLAT_VAR=%d is not built", v);
         }
 #endif
+        else if (wide_lists) rc = launch_coarse_flat<768, CF_PRODUCT_VAR, CO_KP_WIDE>(x, a, nwg, s);
         else rc = launch_coarse_flat<768>(x, a, nwg, s);
         if (rc) return rc;
     }
     rec(x, 2, s);
     {
         FinArgs g = f;
-        g.part_scores = x->partc_s; g.part_rows = x->partc_r; g.bounds = x->partc_b; g.P = pc; g.KP = CO_KP; g.nq = nq;
+        g.part_scores = x->partc_s; g.part_rows = x->partc_r; g.bounds = x->partc_b; g.P = pc; g.KP = wide_lists ? CO_KP_WIDE : CO_KP; g.nq = nq;
         g.perm_mul = x->perm_mul; g.perm_mod = x->perm_mod;
         g.perm_inv = (x->perm_mod > 0 && (double)x->perm_mod * (double)x->perm_mod < 9007199254740992.0) ? 1.0 / (double)x->perm_mod : 0.0;
         int rc = launch_finalize<true>(x, g, s);
@@ -631,8 +642,13 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     }
     if (x->fast) {
         CR_TRY(wsalloc(&x->q16, (size_t)x->max_nq_pad * dim));
-        const int lists_for_max_k = std::min(COARSE_MAX_P, std::max(6, (std::min(max_k, FAST_MAX_K) + 3) / 4 + 4));
-        x->partc_cap = std::max<size_t>((size_t)x->max_nq_pad * lists_for_max_k * CO_KP, (size_t)1 << 20);
+        // candidate lists of the coarse pass: about k / 4 lists of 16 up to k = 64, about k / 6 lists of 24 above (+ the
+        // lists that work-group boundaries add)
+        const int kcap = std::min(max_k, FAST_MAX_K);
+        const int lists_for_max_k = std::min(COARSE_MAX_P, std::max(6, (std::min(kcap, 64) + 3) / 4 + 4));
+        const int wide_for_max_k = kcap > 64 ? std::min(FIN_MAX_CAND / CO_KP_WIDE, (kcap + 5) / 6 + 4) : 0;
+        x->partc_cap = std::max<size_t>((size_t)x->max_nq_pad * std::max(lists_for_max_k * CO_KP, wide_for_max_k * CO_KP_WIDE),
+                                        (size_t)1 << 20);
         CR_TRY(wsalloc(&x->partc_s, x->partc_cap));
         CR_TRY(wsalloc(&x->partc_r, x->partc_cap));
         CR_TRY(wsalloc(&x->partc_b, x->partc_cap / CO_KP));
