@@ -180,9 +180,19 @@ class Ctx:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
-    def timed(self, fn, steps, warmup, before_timing=None):
-        """W untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; max over ranks"""
+    def timed(self, fn, steps, warmup, before_timing=None, settle_s=0.0):
+        """W untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; max over ranks.
+        settle_s: before the W warm-up steps the device is kept busy with the same work for that long (untimed setup,
+        like building the index): a fresh process needs ~20 steps until the chip holds its steady clock
+        (scripts/probe/clock_settle.py: 0.90, 0.77, then 0.745 ms per step in chunks of ten) and a K of a few dozen
+        steps would otherwise report the ramp, not the throughput."""
         out = None
+        if settle_s > 0:
+            t_end = time.perf_counter() + settle_s
+            while time.perf_counter() < t_end:
+                for _ in range(4):
+                    fn()
+                self.sync()
         for _ in range(warmup):
             out = fn()
         self.sync()
@@ -219,7 +229,7 @@ def run_replicated(ctx, args, index_factory=hip_index_factory):
         index.set_profiling(True)
         index.profile_summary()  # reset the event window
 
-    elapsed, out = ctx.timed(lambda: index.search_reweighted(dq, k, mode), args.steps, args.warmup, before)
+    elapsed, out = ctx.timed(lambda: index.search_reweighted(dq, k, mode), args.steps, args.warmup, before, settle_s=args.settle_ms / 1e3)
     prof = index.profile_summary()
     index.set_profiling(False)
     stats = index.stats()
@@ -247,7 +257,7 @@ def run_replicated(ctx, args, index_factory=hip_index_factory):
         traffic, traffic_src = pmc_traffic(kern, nq, n)
         line = {
             "metric": "queries_per_sec", "value": ctx.world * nq * args.steps / elapsed, "unit": "queries/s",
-            "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup, "settle_ms_before_warmup": args.settle_ms,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f16" if fast else "f32",
@@ -389,6 +399,8 @@ def main(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--settle-ms", type=float, default=60.0,
+                    help="untimed: keep the device busy with the step for this long before the warm-up steps (clock ramp of a fresh process)")
     ap.add_argument("--workload", choices=["replicated", "rowshard"], default="replicated")
     ap.add_argument("--nq", type=int, default=10000)
     ap.add_argument("--n", type=int, default=37000)

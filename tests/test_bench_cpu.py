@@ -88,7 +88,7 @@ def _worker_body(rank, world, port, q):
     from rag_project_icd10_amd.sharded import ROW_SHARD, ShardedSearch
     ctx = bench.Ctx()
     assert ctx.world == world and ctx.dist.get_world_size() == world
-    args = argparse.Namespace(steps=2, warmup=1, nq=40, n=900, k=5, mode="auto", rows_per_gpu=700, rowshard_queries=50,
+    args = argparse.Namespace(steps=2, warmup=1, settle_ms=0.0, nq=40, n=900, k=5, mode="auto", rows_per_gpu=700, rowshard_queries=50,
                               rowshard_slice=32, rowshard_steps=2, no_cpu_baseline=True)
 
     def index_factory(corpus, levels, device, max_nq, max_k, id_base=0):
