@@ -149,7 +149,11 @@ __device__ __forceinline__ float flush_emit_parallel(const char *smem, uint32_t 
 // VAR: bit flags of the stage variants (A/B builds instantiate several, `make ABLATE=1`; the product one is CF_PRODUCT_VAR)
 //   1    shared-threshold load issued two stages before the tile end (asm, counted wait) instead of a drained load after it
 //   2    LDS-DMA pieces one behind each of the four MFMAs that follow the barrier instead of a burst in front of them
+//   4    the MFMAs of a k-step issued in the reverse order of their fragment reads (one s_waitcnt per k-step instead of four)
 //   8    query fragments pinned to accumulator registers
+//   16   select by QUADS of score registers (four consecutive rows): four v_cmp into four SGPR pairs, OR-ed, ONE scalar
+//        branch per quad (one VALU -> SALU round trip instead of four); the appends of a quad with a passing lane run
+//        exec-masked from the four masks, no compare is repeated
 //   128  A fragments read two k-steps ahead of their MFMAs instead of one
 //   1024 diagnostic: s_memtime stamps around the mid-stage wait, the barrier and the select (CoarseFlatArgs::dbg)
 //   TIMING ONLY (the results are not the scores; they size the parts of the kernel, profiles/r02_coarse_loop_decomposition.log):
@@ -173,6 +177,8 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     constexpr bool DMA_SPREAD = (VAR & 2) != 0;
     constexpr bool Q_AGPR = (VAR & 8) != 0;
     constexpr bool PF2 = (VAR & 128) != 0;
+    constexpr bool REV_WAIT = (VAR & 4) != 0;
+    constexpr bool QUAD = (VAR & 16) != 0;
     constexpr bool NOBAR = (VAR & 256) != 0, NOVM = (VAR & 512) != 0, STAMPS = (VAR & 1024) != 0;
     constexpr bool NOPASS = (VAR & 4096) != 0, NOSEL = (VAR & 8192) != 0, NODMA = (VAR & 16384) != 0;
     constexpr int S = cf_ring_stages(VAR);            // ring slots
@@ -301,6 +307,51 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             }
         };
 
+        auto filter_quad = [&](const f32x16 (&pa)[4], auto Q, uint32_t rowbase, auto GUARD) {
+            constexpr int q = decltype(Q)::value;
+            constexpr int t = q >> 2, g = q & 3;
+            constexpr uint32_t qoff = (uint32_t)(t * 32 + 8 * g);   // registers 4 g .. 4 g + 3 of row tile t: rows qoff + 0..3 (+ 4 h)
+            float v0 = pa[t][4 * g + 0], v1 = pa[t][4 * g + 1], v2 = pa[t][4 * g + 2], v3 = pa[t][4 * g + 3];
+            const uint32_t rowq = rowbase + qoff;
+            if constexpr (decltype(GUARD)::value) {
+                if ((int)(rowq + 0u) >= a.n) v0 = -INFINITY;
+                if ((int)(rowq + 1u) >= a.n) v1 = -INFINITY;
+                if ((int)(rowq + 2u) >= a.n) v2 = -INFINITY;
+                if ((int)(rowq + 3u) >= a.n) v3 = -INFINITY;
+            }
+            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(v0 > st.thr), m1 = __builtin_amdgcn_ballot_w64(v1 > st.thr);
+            const unsigned long long m2 = __builtin_amdgcn_ballot_w64(v2 > st.thr), m3 = __builtin_amdgcn_ballot_w64(v3 > st.thr);
+            if (__builtin_expect(((m0 | m1) | (m2 | m3)) != 0ull, 0)) {
+                // EXEC is all ones here (256-thread blocks, wave-uniform control flow down to this point); the four appends
+                // run under the four masks and EXEC is restored
+                uint32_t r1, r2, r3;
+                asm volatile("v_or_b32_e32 %1, 1, %12\n\t"
+                             "v_or_b32_e32 %2, 2, %12\n\t"
+                             "v_or_b32_e32 %3, 3, %12\n\t"
+                             "s_mov_b64 exec, %4\n\t"
+                             "ds_write2st64_b32 %0, %8, %12 offset1:1\n\t"
+                             "v_add_u32_e32 %0, %0, %13\n\t"
+                             "s_mov_b64 exec, %5\n\t"
+                             "ds_write2st64_b32 %0, %9, %1 offset1:1\n\t"
+                             "v_add_u32_e32 %0, %0, %13\n\t"
+                             "s_mov_b64 exec, %6\n\t"
+                             "ds_write2st64_b32 %0, %10, %2 offset1:1\n\t"
+                             "v_add_u32_e32 %0, %0, %13\n\t"
+                             "s_mov_b64 exec, %7\n\t"
+                             "ds_write2st64_b32 %0, %11, %3 offset1:1\n\t"
+                             "v_add_u32_e32 %0, %0, %13\n\t"
+                             "s_mov_b64 exec, -1"
+                             : "+v"(st.aw), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                             : "s"(m0), "s"(m1), "s"(m2), "s"(m3), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(rowq), "v"(st.inc)
+                             : "memory");
+            }
+            if constexpr (q % 2 == 1) {   // every 8 registers: the overflow guard of filter_reg
+                if (__builtin_amdgcn_ballot_w64(Ops::used(st, h) > CO_QUOTA) != 0ull)
+                    Ops::check(st, lane, smem, wave_qbase, wave_scratch, false, CO_LIMIT, STAMPS ? st_comp : nullptr, CO_QUOTA);
+            }
+        };
+        static_assert(!QUAD || Ops::ROW_OFF == 256, "ds_write2st64_b32 offset1:1 = the row array of the query's buffer");
+
         // prologue: stages 0..S-2 in flight, stage 0 published, its first fragments read
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (query fragment loads: the vmcnt accounting starts from zero)
 #pragma unroll
@@ -323,8 +374,13 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                 constexpr int ks = decltype(KSI)::value;
                 constexpr int slot = ks % S, nslot = (ks + 1) % S;
                 auto mfma4 = [&](const half8 (&f)[4], int qi) {
+                    // (REV_WAIT: the four MFMAs of a k-step in the reverse of the order their fragments were read - the first one
+                    //  waits for the youngest read, the other three need no s_waitcnt at all)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[t], qf[qi], acc[t], 0, 0, 0);
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const int t = REV_WAIT ? 3 - tt : tt;
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[t], qf[qi], acc[t], 0, 0, 0);
+                    }
                 };
                 // stage g = (tile, ks) was published by the previous mid-stage barrier; afn holds its k-step 0 (PF2: bfn its k-step 1)
                 half8 f1[4], f2[4], f3[4];
@@ -456,6 +512,9 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             if constexpr (NOSEL) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(acc[t]));
+            } else if constexpr (QUAD) {
+                if (tile_row0 + CO_BN > a.n) static_for<0, 16>([&](auto Q) { filter_quad(acc, Q, rowbase, std::true_type{}); });
+                else static_for<0, 16>([&](auto Q) { filter_quad(acc, Q, rowbase, std::false_type{}); });
             } else if (tile_row0 + CO_BN > a.n) static_for<0, 64>([&](auto F) { filter_reg(acc, F, rowbase, std::true_type{}); });
             else static_for<0, 64>([&](auto F) { filter_reg(acc, F, rowbase, std::false_type{}); });
             if constexpr (STAMPS) {

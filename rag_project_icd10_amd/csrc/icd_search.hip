@@ -13,6 +13,9 @@
 
 #include "../../include/icd_search.h"
 #include "coarse_flat_kernel.hpp"
+#ifdef ICD_ABLATE
+#include "../../experiments/r02_rg_kernel/coarse_rg_kernel.hpp"   // (A/B builds only: the row-group experiment)
+#endif
 #include "exact_kernel.hpp"
 #include "finalize.hpp"
 #include "hier_kernel.hpp"
@@ -180,7 +183,19 @@ int launch_coarse_flat(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream
     return ICD_OK;
 }
 
-// streaming exact kernel + list reduction for a sparse query set (device-side gated when nq_ptr is given)
+#ifdef ICD_ABLATE
+template <int D, int KP = CO_KP, int VAR = 0>
+int launch_coarse_rg(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream_t s) {
+    auto kern = coarse_rg_kernel<D, KP, VAR>;
+    constexpr int lds = rg_lds_bytes();
+    static int configured[MAX_DEVICES] = {};   // (guarded by the caller's one-stream-per-handle contract; worst case a repeated call)
+    HIP_TRY(ensure_dynamic_lds(kern, x->device, (size_t)(lds), configured));
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, s, a);
+    HIP_TRY(hipGetLastError());
+    return ICD_OK;
+}
+#endif
+
 // streaming exact kernel + list reduction for a sparse query set (device-side gated when nq_ptr is given).
 // p_out = 0: choose the smallest number of output lists (direct tiny-batch path); returns it in *p_used.
 constexpr int LDS_LIMIT = 160 * 1024;   // LDS per CU (MI355X_MICROARCH.md)
@@ -498,11 +513,25 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         // (dim 1024: the query fragments alone are 256 registers: no pinning and no deeper fragment prefetch there)
         if (x->dim == 1024) rc = launch_coarse_flat<1024, (CF_PRODUCT_VAR & 3)>(x, a, nwg, s);
 #ifdef ICD_ABLATE
+        else if (const char *rv = getenv("ICD_RG_VAR")) {   // A/B builds: the row-group kernel and its timing variants
+            const int v = atoi(rv);
+            if (wide_lists) rc = launch_coarse_rg<768, CO_KP_WIDE>(x, a, nwg, s);
+            else if (v == 0) rc = launch_coarse_rg<768>(x, a, nwg, s);
+            else if (v == 1) rc = launch_coarse_rg<768, CO_KP, 1>(x, a, nwg, s);
+            else if (v == 4) rc = launch_coarse_rg<768, CO_KP, 4>(x, a, nwg, s);
+            else if (v == 8) rc = launch_coarse_rg<768, CO_KP, 8>(x, a, nwg, s);
+            else if (v == 16) rc = launch_coarse_rg<768, CO_KP, 16>(x, a, nwg, s);
+            else if (v == 36) rc = launch_coarse_rg<768, CO_KP, 36>(x, a, nwg, s);
+            else if (v == 64) rc = launch_coarse_rg<768, CO_KP, 64>(x, a, nwg, s);
+            else if (v == 68) rc = launch_coarse_rg<768, CO_KP, 68>(x, a, nwg, s);
+            else if (v == 100) rc = launch_coarse_rg<768, CO_KP, 100>(x, a, nwg, s);
+            else return fail(ICD_ERR_INVALID, "ICD_RG_VAR=%d is not built", v);
+        }
         else if (const char *fv = getenv("ICD_FLAT_VAR")) {   // A/B builds: stage / select variants of the flat kernel
             const int v = atoi(fv);
             if (false) {}
 #define ICD_FV_CASE(V) else if (v == V) rc = launch_coarse_flat<768, V>(x, a, nwg, s);
-            ICD_FV_CASE(0) ICD_FV_CASE(CF_PRODUCT_VAR) ICD_FV_CASE(CF_PRODUCT_VAR + 1024) ICD_FV_CASE(CF_PRODUCT_VAR + 4096)
+            ICD_FV_CASE(0) ICD_FV_CASE(CF_PRODUCT_VAR) ICD_FV_CASE(CF_PRODUCT_VAR + 4) ICD_FV_CASE(CF_PRODUCT_VAR + 16) ICD_FV_CASE(CF_PRODUCT_VAR + 1024) ICD_FV_CASE(CF_PRODUCT_VAR + 4096)
             ICD_FV_CASE(CF_PRODUCT_VAR + 8192) ICD_FV_CASE(CF_PRODUCT_VAR + 8192 + 256) ICD_FV_CASE(CF_PRODUCT_VAR + 8192 + 512)
             ICD_FV_CASE(CF_PRODUCT_VAR + 8192 + 16384 + 512) ICD_FV_CASE(CF_PRODUCT_VAR + 8192 + 16384 + 768)
 #undef ICD_FV_CASE

@@ -213,12 +213,15 @@ struct Sel2 {
     uint32_t inc;   // +4 (low lane, grows up) or -4 (high lane, grows down)
 };
 
-template <int KP>
+// QB: bytes from one query's buffer to the next (512 = packed; 516 puts the 32 buffers of a wave one bank apart, for
+// a select in which all lanes of a wave write at once: coarse_rg_kernel.hpp)
+template <int KP, int QB = 512>
 struct Sel2Ops {
     static constexpr int CAP = 64;
     // byte offsets inside a query buffer
     static constexpr uint32_t ROW_OFF = CAP * 4;
-    static constexpr uint32_t QBYTES = CAP * 8;
+    static constexpr uint32_t QBYTES = QB;
+    static_assert(QB >= CAP * 8 && QB % 4 == 0, "a query buffer holds CAP scores and CAP rows");
 
     __device__ static __forceinline__ void init(Sel2 &s, uint32_t qbase, int h, bool valid) {
         s.thr = valid ? -INFINITY : INFINITY;
