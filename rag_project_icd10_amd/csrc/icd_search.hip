@@ -531,7 +531,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             const int v = atoi(fv);
             if (false) {}
 #define ICD_FV_CASE(V) else if (v == V) rc = launch_coarse_flat<768, V>(x, a, nwg, s);
-            ICD_FV_CASE(0) ICD_FV_CASE(CF_PRODUCT_VAR) ICD_FV_CASE(CF_PRODUCT_VAR + 4) ICD_FV_CASE(CF_PRODUCT_VAR + 16) ICD_FV_CASE(CF_PRODUCT_VAR + 1024) ICD_FV_CASE(CF_PRODUCT_VAR + 4096)
+            ICD_FV_CASE(0) ICD_FV_CASE(CF_PRODUCT_VAR) ICD_FV_CASE(CF_PRODUCT_VAR + 4) ICD_FV_CASE(CF_PRODUCT_VAR + 16) ICD_FV_CASE(CF_PRODUCT_VAR + 16 + 4096) ICD_FV_CASE(CF_PRODUCT_VAR + 1024) ICD_FV_CASE(CF_PRODUCT_VAR + 4096)
             ICD_FV_CASE(CF_PRODUCT_VAR + 8192) ICD_FV_CASE(CF_PRODUCT_VAR + 8192 + 256) ICD_FV_CASE(CF_PRODUCT_VAR + 8192 + 512)
             ICD_FV_CASE(CF_PRODUCT_VAR + 8192 + 16384 + 512) ICD_FV_CASE(CF_PRODUCT_VAR + 8192 + 16384 + 768)
 #undef ICD_FV_CASE
