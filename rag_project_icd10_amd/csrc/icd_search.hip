@@ -15,6 +15,7 @@
 #include "coarse_flat_kernel.hpp"
 #ifdef ICD_ABLATE
 #include "../../experiments/r02_rg_kernel/coarse_rg_kernel.hpp"   // (A/B builds only: the row-group experiment)
+#include "../../experiments/r02_w8_kernel/coarse_w8_kernel.hpp"   // (A/B builds only: eight waves, two per SIMD)
 #endif
 #include "exact_kernel.hpp"
 #include "finalize.hpp"
@@ -191,6 +192,16 @@ int launch_coarse_rg(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream_t
     static int configured[MAX_DEVICES] = {};   // (guarded by the caller's one-stream-per-handle contract; worst case a repeated call)
     HIP_TRY(ensure_dynamic_lds(kern, x->device, (size_t)(lds), configured));
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, s, a);
+    HIP_TRY(hipGetLastError());
+    return ICD_OK;
+}
+template <int D, int KP = CO_KP, int VAR = 0>
+int launch_coarse_w8(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream_t s) {
+    auto kern = coarse_w8_kernel<D, KP, VAR>;
+    constexpr int lds = w8_lds_bytes();
+    static int configured[MAX_DEVICES] = {};
+    HIP_TRY(ensure_dynamic_lds(kern, x->device, (size_t)(lds), configured));
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), lds, s, a);
     HIP_TRY(hipGetLastError());
     return ICD_OK;
 }
@@ -513,6 +524,12 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         // (dim 1024: the query fragments alone are 256 registers: no pinning and no deeper fragment prefetch there)
         if (x->dim == 1024) rc = launch_coarse_flat<1024, (CF_PRODUCT_VAR & 3)>(x, a, nwg, s);
 #ifdef ICD_ABLATE
+        else if (const char *wv = getenv("ICD_W8_VAR")) {   // A/B builds: the eight-wave kernel
+            const int v = atoi(wv);
+            if (v == 0 && !wide_lists) rc = launch_coarse_w8<768>(x, a, nwg, s);
+            else if (v == 1) rc = launch_coarse_w8<768, CO_KP, 1>(x, a, nwg, s);
+            else return fail(ICD_ERR_INVALID, "ICD_W8_VAR=%d is not built", v);
+        }
         else if (const char *rv = getenv("ICD_RG_VAR")) {   // A/B builds: the row-group kernel and its timing variants
             const int v = atoi(rv);
             if (wide_lists) rc = launch_coarse_rg<768, CO_KP_WIDE>(x, a, nwg, s);
