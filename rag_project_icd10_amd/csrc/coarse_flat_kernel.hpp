@@ -146,6 +146,103 @@ __device__ __forceinline__ float flush_emit_parallel(const char *smem, uint32_t 
     return bound;
 }
 
+// Compaction of ALL 32 queries of a wave at once (lane = half a query, as flush_emit_parallel): every buffer that holds
+// more than KP entries keeps its KP best at the front (unsorted; ties at the KP-th score: as many of the tied as fit) and
+// the query's threshold becomes the bound on what was dropped. The one-query-at-a-time compaction of Sel2Ops::check costs
+// ~1 200 cycles and happens at a different register in every wave, so each tile end lasts as long as the slowest wave's
+// compactions (about one per tile and work-group: 8 % of the sweep); this one costs ~250 cycles per query and all four
+// waves run it at the same tile ends (CoarseFlatArgs-independent schedule, see the kernel).
+template <int KP, typename Ops>
+__device__ __forceinline__ void compact_all_parallel(char *smem, Sel2 &st, uint32_t qb, int h, int rot) {
+    constexpr int CAP = 64, HALF = 32;
+    const int mine = Ops::used(st, h);
+    const auto swm = __builtin_amdgcn_permlane32_swap((unsigned)mine, (unsigned)mine, false, false);
+    const int other = (int)(h ? swm[0] : swm[1]);
+    const int nlo = st.kept + (h ? other : mine), nhi = h ? mine : other;
+    const int total = nlo + nhi;
+    float v[HALF];
+    uint32_t rw[HALF];
+    const int lo_end = nlo, hi_begin = CAP - nhi;
+#pragma unroll
+    for (int j = 0; j < HALF; ++j) {
+        const int slot = HALF * h + ((j + rot) & (HALF - 1));
+        const bool valid = slot < lo_end || slot >= hi_begin;
+        const float sv = *reinterpret_cast<const float *>(smem + qb + slot * 4);
+        rw[j] = *reinterpret_cast<const uint32_t *>(smem + qb + CAP * 4 + slot * 4);
+        v[j] = valid ? sv : -INFINITY;
+    }
+    auto pair_sum = [&](int x) {
+        const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+        return x + (int)(h ? sw[0] : sw[1]);
+    };
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < HALF; ++j) mx = fmaxf(mx, v[j]);
+    {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(mx, __uint_as_float(h ? sw[0] : sw[1]));
+    }
+    // bisection on the order-preserving key; invariant count(v > lo) >= KP > count(v > hi)
+    uint32_t lo = order_f32(st.thr), hi = order_f32(mx);
+    int cnt_lo = 0;
+#pragma unroll
+    for (int j = 0; j < HALF; ++j) cnt_lo += (v[j] > st.thr) ? 1 : 0;
+    cnt_lo = pair_sum(cnt_lo);
+    bool active = total > KP && cnt_lo > KP && hi > lo + 1u;
+    while (__builtin_amdgcn_ballot_w64(active) != 0ull) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        const float midf = unorder_f32(mid);
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < HALF; ++j) c += (v[j] > midf) ? 1 : 0;
+        c = pair_sum(c);
+        if (active) {
+            if (c >= KP) { lo = mid; cnt_lo = c; } else hi = mid;
+            active = cnt_lo > KP && hi > lo + 1u;
+        }
+    }
+    float cut = unorder_f32(lo);   // keep v > cut
+    int quota_ties = 0;
+    float tie = 0.0f;
+    if (cnt_lo > KP) {   // (possible only after the loop ended on hi == lo + 1: scores tied at key hi)
+        tie = unorder_f32(hi);
+        int above = 0, tied = 0;
+#pragma unroll
+        for (int j = 0; j < HALF; ++j) { above += (v[j] > tie) ? 1 : 0; tied += (v[j] == tie) ? 1 : 0; }
+        const int above_all = pair_sum(above);
+        const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)tied, (unsigned)tied, false, false);
+        const int tied_low_lane = h ? (int)sw[0] : tied;           // the low lane's ties are served first
+        const int room = KP - above_all;
+        quota_ties = h ? max(0, min(tied, room - min(tied_low_lane, room))) : min(tied, room);
+        cut = tie;
+    }
+    int mine_n = 0;
+#pragma unroll
+    for (int j = 0; j < HALF; ++j) mine_n += (v[j] > cut) ? 1 : 0;
+    mine_n += quota_ties;
+    const auto swn = __builtin_amdgcn_permlane32_swap((unsigned)mine_n, (unsigned)mine_n, false, false);
+    const int other_n = (int)(h ? swn[0] : swn[1]);
+    if (total > KP) {   // (both lanes of a query agree; a buffer of at most KP entries stays as it is)
+        int dest = h ? other_n : 0;
+        int ties_left = quota_ties;
+#pragma unroll
+        for (int j = 0; j < HALF; ++j) {
+            bool take = v[j] > cut;
+            if (!take && ties_left > 0 && v[j] == tie && cnt_lo > KP) { take = true; --ties_left; }
+            if (take) {
+                *reinterpret_cast<float *>(smem + qb + dest * 4) = v[j];
+                *reinterpret_cast<uint32_t *>(smem + qb + CAP * 4 + dest * 4) = rw[j];
+                ++dest;
+            }
+        }
+        const int kept = mine_n + other_n;   // <= KP
+        st.thr = cut;   // every kept entry is above it (or tied with it), every dropped one at or below; >= the old threshold
+        st.kept = kept;
+        st.aw0 = h ? qb + (CAP - 1) * 4 : qb + (uint32_t)kept * 4;
+        st.aw = st.aw0;
+    }
+}
+
 // VAR: bit flags of the stage variants (A/B builds instantiate several, `make ABLATE=1`; the product one is CF_PRODUCT_VAR)
 //   1    shared-threshold load issued two stages before the tile end (asm, counted wait) instead of a drained load after it
 //   2    LDS-DMA pieces one behind each of the four MFMAs that follow the barrier instead of a burst in front of them
@@ -156,12 +253,13 @@ __device__ __forceinline__ float flush_emit_parallel(const char *smem, uint32_t 
 //        exec-masked from the four masks, no compare is repeated
 //   128  A fragments read two k-steps ahead of their MFMAs instead of one
 //   1024 diagnostic: s_memtime stamps around the mid-stage wait, the barrier and the select (CoarseFlatArgs::dbg)
+//   32 / 2048  every 16 / 24 tiles all four waves compact ALL their queries at once (compact_all_parallel) at the tile end
 //   TIMING ONLY (the results are not the scores; they size the parts of the kernel, profiles/r02_coarse_loop_decomposition.log):
 //   256 no s_barrier   512 no wait for the LDS-DMA pieces   4096 thresholds at +inf (nothing passes)
 //   8192 no select at all   16384 no LDS-DMA inside the tile loop
 // Variants that were measured and dropped (per-wave DMA slots, branch-free select, 3/6-stage rings, select deferred into
 // the next tile's MFMA gaps, 16x16x32 MFMA shape) live in experiments/r02_flat_variants/ with their logs.
-constexpr int CF_PRODUCT_VAR = 1 + 2 + 8 + 128;   // measured: profiles/r02_ab_flat_variants.log
+constexpr int CF_PRODUCT_VAR = 1 + 2 + 8 + 128 + 16 + 2048;   // measured: profiles/r02_ab_flat_variants.log, profiles/r02_coarse_variants_rg_w8_all.log (+ 16 + 2048: -2 %)
 __host__ __device__ constexpr int cf_ring_stages(int) { return CO_S; }
 __host__ __device__ constexpr int cf_lds_bytes(int var) { return cf_ring_stages(var) * CO_STAGE_BYTES + CO_BM * CO_CAP * 8 + 4 * 256; }
 #define ICD_CF_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); \
@@ -179,6 +277,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     constexpr bool PF2 = (VAR & 128) != 0;
     constexpr bool REV_WAIT = (VAR & 4) != 0;
     constexpr bool QUAD = (VAR & 16) != 0;
+    constexpr int EPOCH = ((VAR & 32) && (VAR & 2048)) ? 32 : ((VAR & 32) ? 16 : ((VAR & 2048) ? 24 : 0));   // tiles between the synchronised compactions of all queries
     constexpr bool NOBAR = (VAR & 256) != 0, NOVM = (VAR & 512) != 0, STAMPS = (VAR & 1024) != 0;
     constexpr bool NOPASS = (VAR & 4096) != 0, NOSEL = (VAR & 8192) != 0, NODMA = (VAR & 16384) != 0;
     constexpr int S = cf_ring_stages(VAR);            // ring slots
@@ -517,6 +616,10 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                 else static_for<0, 16>([&](auto Q) { filter_quad(acc, Q, rowbase, std::false_type{}); });
             } else if (tile_row0 + CO_BN > a.n) static_for<0, 64>([&](auto F) { filter_reg(acc, F, rowbase, std::true_type{}); });
             else static_for<0, 64>([&](auto F) { filter_reg(acc, F, rowbase, std::false_type{}); });
+            if constexpr (EPOCH > 0) {
+                if ((tile + 1) % EPOCH == 0 && tile + 1 < ntiles)
+                    compact_all_parallel<KP, Ops>(smem, st, wave_qbase + (uint32_t)c * Ops::QBYTES, h, c);
+            }
             if constexpr (STAMPS) {
                 unsigned long long ts1;
                 ICD_CF_STAMP(ts1);

@@ -196,6 +196,17 @@ int launch_coarse_rg(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream_t
     return ICD_OK;
 }
 template <int D, int KP = CO_KP, int VAR = 0>
+int launch_coarse_w8rg(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream_t s) {
+    auto kern = coarse_w8rg_kernel<D, KP, VAR>;
+    constexpr int lds = w8_lds_bytes();
+    static int configured[MAX_DEVICES] = {};
+    HIP_TRY(ensure_dynamic_lds(kern, x->device, (size_t)(lds), configured));
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), lds, s, a);
+    HIP_TRY(hipGetLastError());
+    return ICD_OK;
+}
+
+template <int D, int KP = CO_KP, int VAR = 0>
 int launch_coarse_w8(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream_t s) {
     auto kern = coarse_w8_kernel<D, KP, VAR>;
     constexpr int lds = w8_lds_bytes();
@@ -528,6 +539,10 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             const int v = atoi(wv);
             if (v == 0 && !wide_lists) rc = launch_coarse_w8<768>(x, a, nwg, s);
             else if (v == 1) rc = launch_coarse_w8<768, CO_KP, 1>(x, a, nwg, s);
+            else if (v == 10 && !wide_lists) rc = launch_coarse_w8rg<768>(x, a, nwg, s);
+            else if (v == 11) rc = launch_coarse_w8rg<768, CO_KP, 1>(x, a, nwg, s);
+            else if (v == 12) rc = launch_coarse_w8rg<768, CO_KP, 2>(x, a, nwg, s);
+            else if (v == 14) rc = launch_coarse_w8rg<768, CO_KP, 4>(x, a, nwg, s);
             else return fail(ICD_ERR_INVALID, "ICD_W8_VAR=%d is not built", v);
         }
         else if (const char *rv = getenv("ICD_RG_VAR")) {   // A/B builds: the row-group kernel and its timing variants
@@ -548,9 +563,9 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             const int v = atoi(fv);
             if (false) {}
 #define ICD_FV_CASE(V) else if (v == V) rc = launch_coarse_flat<768, V>(x, a, nwg, s);
-            ICD_FV_CASE(0) ICD_FV_CASE(CF_PRODUCT_VAR) ICD_FV_CASE(CF_PRODUCT_VAR + 4) ICD_FV_CASE(CF_PRODUCT_VAR + 16) ICD_FV_CASE(CF_PRODUCT_VAR + 16 + 4096) ICD_FV_CASE(CF_PRODUCT_VAR + 1024) ICD_FV_CASE(CF_PRODUCT_VAR + 4096)
-            ICD_FV_CASE(CF_PRODUCT_VAR + 8192) ICD_FV_CASE(CF_PRODUCT_VAR + 8192 + 256) ICD_FV_CASE(CF_PRODUCT_VAR + 8192 + 512)
-            ICD_FV_CASE(CF_PRODUCT_VAR + 8192 + 16384 + 512) ICD_FV_CASE(CF_PRODUCT_VAR + 8192 + 16384 + 768)
+            ICD_FV_CASE(0) ICD_FV_CASE(139) ICD_FV_CASE(143) ICD_FV_CASE(155) ICD_FV_CASE(171) ICD_FV_CASE(187) ICD_FV_CASE(2187) ICD_FV_CASE(2203)
+            ICD_FV_CASE(2235) ICD_FV_CASE(1163) ICD_FV_CASE(4235) ICD_FV_CASE(4251) ICD_FV_CASE(8331) ICD_FV_CASE(8587) ICD_FV_CASE(8843)
+            ICD_FV_CASE(25227) ICD_FV_CASE(25483)
 #undef ICD_FV_CASE
             else return fail(ICD_ERR_INVALID, "ICD_FLAT_VAR=%d is not built", v);
         }
