@@ -92,6 +92,25 @@ def test_heavy_duplicates_through_the_coarse_path(oracle):
     idx.close()
 
 
+@pytest.mark.parametrize("dups", [False, True])
+def test_lists_long_enough_for_the_synchronised_compaction(oracle, dups):
+    """Lists of 32 tiles (two lists per query over 8 192 rows): the coarse kernel's all-queries compaction at tile 24
+    runs, with unique scores and with a fifth of the rows duplicated (score ties at the KP-th place of a buffer take its
+    tie path: as many of the tied entries as fit, the tied score as the bound). 300 queries: more than one query tile."""
+    n = 8192
+    corpus = unit_rows(n, 768, 71)
+    if dups:
+        corpus[5::5] = corpus[np.arange(5, n, 5) // 2]
+    levels, queries = icd_levels(n, 72), unit_rows(300, 768, 73)
+    idx = IcdIndex(corpus, levels, max_nq=300, max_k=10)
+    idx.set_chunks(2)
+    st = _check(oracle, idx, corpus, levels, queries, 10, MODE_AUTO)
+    assert st["last_mode"] == MODE_AUTO and st["last_chunks"] >= 2
+    if not dups:
+        assert st["last_fallback"] == 0
+    idx.close()
+
+
 @pytest.mark.parametrize("n,nq,dim,k,mode", [
     (3000, 1, 1024, 10, MODE_AUTO), (3000, 3, 1024, 64, MODE_EXACT), (2500, 2, 96, 7, MODE_AUTO),
     (9000, 40, 768, 10, MODE_EXACT), (9000, 64, 768, 100, MODE_EXACT), (700, 16, 768, 128, MODE_EXACT),
