@@ -33,6 +33,11 @@ __device__ __forceinline__ void static_for(F &&f) {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
+// v_min_f32 / v_max_f32 as they are: fminf / fmaxf canonicalise both operands first (a v_max x, x in front of every
+// operand: 8 instead of 5 instructions per score in the threshold bootstrap); MFMA results need no quieting
+__device__ __forceinline__ float raw_min_f32(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float raw_max_f32(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 #ifndef ICD_CO_KP
 #define ICD_CO_KP 16
 #endif

@@ -597,11 +597,11 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float v = acc[t][r];
-                        const float lo1 = fminf(boot1, v);
-                        boot1 = fmaxf(boot1, v);
-                        const float lo2 = fminf(boot2, lo1);
-                        boot2 = fmaxf(boot2, lo1);
-                        boot3 = fmaxf(boot3, lo2);
+                        const float lo1 = raw_min_f32(boot1, v);
+                        boot1 = raw_max_f32(boot1, v);
+                        const float lo2 = raw_min_f32(boot2, lo1);
+                        boot2 = raw_max_f32(boot2, lo1);
+                        boot3 = raw_max_f32(boot3, lo2);
                     }
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(boot3), __float_as_uint(boot3), false, false);
                 const float thr0 = fminf(boot3, __uint_as_float(h ? sw[0] : sw[1]));
