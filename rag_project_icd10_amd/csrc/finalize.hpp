@@ -30,6 +30,9 @@ struct FinArgs {
     int sparse_max;
     int dense_grid, dense_bmq, dense_max_p, n_rows;   // dense_max_p > 0: exact_topk chose its chunk count on the device
     int lds_cand;       // candidate slots the launch's LDS was sized for (0: P * KP)
+    int lists_by_query; // with qlist: the lists (and bounds) of slot s belong to query qlist[s] and sit at that query's index
+    int wide_window;    // fast path: rescoring window as wide as the instantiation allows (second chance of a query whose
+                        // first window overflowed with near-ties), not the one sized for k
     int nq;             // slots (upper bound if nq_ptr)
     const int *nq_ptr;  // nullable
     const int *qlist;   // nullable: slot -> query index
@@ -237,7 +240,8 @@ __global__ __launch_bounds__(256, (EWM == 1 && !DEEP) ? 7 : 1) void finalize_ker
     }
 
     const int k = a.k;
-    const size_t pbase = (size_t)slot * ncand;
+    const size_t lslot = a.lists_by_query ? (size_t)qidx : (size_t)slot;
+    const size_t pbase = lslot * ncand;
 
     // 1-2. load the candidates, rank them, keep the best T sorted. Instantiated per candidates-per-lane (2 covers the
     // common P * KP <= 128; the loops of an 8-per-lane instance would run six dead elements through ~12 VALU per
@@ -245,13 +249,15 @@ __global__ __launch_bounds__(256, (EWM == 1 && !DEEP) ? 7 : 1) void finalize_ker
     // RESCORE keeps the best T coarse candidates as the rescoring window; everything past T counts as dropped (it raises
     // tau). 32 is plenty at k <= 12 (the window holds ~12 rows) and, with many lists, lets rank_top's prefilter cut the
     // ranking loop from ~300 survivors to ~50.
-    const int T = RESCORE ? ((EWM >= 4 && k > 64 && ncand >= 256) ? 256 : (EWM >= 2 && k > 32 && ncand >= 128) ? 128 : ((ncand > 128 && k <= 12) ? 32 : 64)) : k;
+    const int T = !RESCORE ? k
+                  : (a.wide_window && EWM >= 4) ? (ncand >= 256 ? 256 : (ncand >= 128 ? 128 : 64))
+                  : ((EWM >= 4 && k > 64 && ncand >= 256) ? 256 : (EWM >= 2 && k > 32 && ncand >= 128) ? 128 : ((ncand > 128 && k <= 12) ? 32 : 64));
     float tau = -INFINITY;  // largest coarse score that may have been dropped anywhere
     if (RESCORE) {
         // every list comes with the threshold it ended on: nothing it dropped scores above that. The lists
         // are ranked by a key with 6 low score bits dropped when scores tie (Sel2), hence the relative slack.
         if (lane < P) {
-            const float bd = a.bounds[(size_t)slot * P + lane];
+            const float bd = a.bounds[lslot * P + lane];
             if (bd > -INFINITY) tau = bd + fabsf(bd) * COARSE_KEY_SLACK;
         }
     }

@@ -100,7 +100,8 @@ struct icd_index {
     float *partc_s = nullptr; int *partc_r = nullptr; float *partc_b = nullptr; size_t partc_cap = 0;   // coarse lists + bounds
     float *partx_s = nullptr; int *partx_r = nullptr; size_t partx_cap = 0;
     float *lists_s = nullptr; int *lists_r = nullptr; size_t lists_cap = 0;   // streaming kernel: [slot][4 nwg][KP]
-    int *nflag = nullptr; int *flagged = nullptr;
+    int *nflag = nullptr; int *flagged = nullptr;   // fallback counters [4] and lists [2][max_nq_pad] (second: after the wide-window retry)
+    int fallback_word = 0;                           // which counter / list the last search's exact re-search read
     unsigned int *scratch_u32 = nullptr;  // [0]=rmax bits, [1]=any_bad
     // output staging (used when the caller's buffers are host memory)
     float *o_scores = nullptr; long long *o_ids = nullptr;
@@ -320,6 +321,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     }
     for (int i = 0; i <= NUM_EV; ++i) x->ev_valid[i] = false;
     x->last_nq = nq;
+    x->fallback_word = 0;
     x->last_mode = use_fast ? ICD_MODE_AUTO : ICD_MODE_EXACT;
     rec(x, 0, s);
 
@@ -582,8 +584,25 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         g.perm_inv = (x->perm_mod > 0 && (double)x->perm_mod * (double)x->perm_mod < 9007199254740992.0) ? 1.0 / (double)x->perm_mod : 0.0;
         int rc = launch_finalize<true>(x, g, s);
         if (rc) return rc;
+        // Second chance before the exact re-search. A query fails the first pass when more candidates lie within 2 eps of
+        // its k-th best than the window sized for k holds (32 or 64 for k <= 32): a family of near-identical rows, the
+        // shape ICD sibling codes have. Its lists may hold 128-512 candidates: the same kernel with the widest window
+        // (256) certifies it from them in microseconds where the exact sweep costs 2.5-5 us per query
+        // (profiles/r02_family_corpus_probe.log: 1 000 queries 2.7 / 5.2 ms -> see there). Only launched when the lists can
+        // fill a wider window (mid-size batches; 10 000 queries have 5 lists of 16); gated on the flagged count on the device.
+        x->fallback_word = 0;
+        if (k <= 32 && pc * g.KP >= 128) {
+            FinArgs g2 = g;
+            g2.qlist = x->flagged; g2.nq_ptr = x->nflag; g2.lists_by_query = 1; g2.wide_window = 1;
+            g2.nflag = x->nflag + 1; g2.flagged = x->flagged + x->max_nq_pad;
+            rc = launch_finalize_t<true, false, 4>(x, g2, s);
+            if (rc) return rc;
+            x->fallback_word = 1;
+        }
     }
     rec(x, 3, s);
+    const int *fl_list = x->flagged + (size_t)x->fallback_word * x->max_nq_pad;
+    const int *fl_count = x->nflag + x->fallback_word;
     // fallback over the flagged list, both device-side gated on its length: the streaming kernel for
     // a sparse list (<= ST_MAX_ACTIVE queries), the fp32-MFMA kernel for a dense one. Both leave
     // [slot][p_sparse][KP] lists for the same finalize launch.
@@ -594,9 +613,9 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         if ((size_t)nq * px * kpx > x->partx_cap) return fail(ICD_ERR_INVALID, "workspace too small for nq=%d k=%d", nq, k);
         const int tiles_per = (row_tiles + px - 1) / px;
         px = (row_tiles + tiles_per - 1) / tiles_per;
-        return run_exact(x->flagged, x->nflag, px, true, false);
+        return run_exact(fl_list, fl_count, px, true, false);
     }
-    return run_exact(x->flagged, x->nflag, p_sparse, true, stream_ok);
+    return run_exact(fl_list, fl_count, p_sparse, true, stream_ok);
 }
 
 }  // namespace
@@ -732,7 +751,7 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     CR_TRY(hipMemset(x->nflag, 0, 4 * sizeof(int)));
     CR_TRY(wsalloc(&x->dbg, (size_t)8192 * 16));
     CR_TRY(hipMemset(x->dbg, 0, (size_t)8192 * 16 * 8));
-    CR_TRY(wsalloc(&x->flagged, (size_t)x->max_nq_pad));
+    CR_TRY(wsalloc(&x->flagged, (size_t)2 * x->max_nq_pad));
     const size_t no = (size_t)max_nq * max_k;
     CR_TRY(wsalloc(&x->o_scores, no)); CR_TRY(wsalloc(&x->o_ids, no)); CR_TRY(wsalloc(&x->o_adj, no));
     CR_TRY(wsalloc(&x->o_adj_raw, no)); CR_TRY(wsalloc(&x->o_adj_ids, no)); CR_TRY(wsalloc(&x->o_adj_lv, no));
@@ -913,7 +932,7 @@ int icd_index_stats(icd_index *idx, icd_stats *out) {
     if (idx->nflag && idx->last_nq > 0) {
         HIP_TRY(hipSetDevice(idx->device));
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(&nf, idx->nflag, sizeof(int), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&nf, idx->nflag + idx->fallback_word, sizeof(int), hipMemcpyDeviceToHost));
     }
     out->last_fallback = nf;
     out->last_chunks = idx->last_chunks; out->last_mode = idx->last_mode;

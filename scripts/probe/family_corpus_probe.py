@@ -1,0 +1,35 @@
+"""Probe: search time and fallback counts on a corpus of FAMILIES of near-identical rows in code order (the shape the ICD
+corpus has: semantic_text repeats the ancestors' names), for the serving path's k = 2 top_k, at several family
+tightnesses. Gaussian unit rows never fail the certificate; this is where the fallback paths decide the latency."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
+from conftest import icd_levels
+from rag_project_icd10_amd._native import IcdIndex, MODE_AUTO
+
+def family(nfam, per, dim, spread, nq, seed):
+    rng = np.random.default_rng(seed)
+    cent = rng.standard_normal((nfam, dim)).astype(np.float32)
+    x = np.repeat(cent, per, axis=0) + spread * rng.standard_normal((nfam * per, dim)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    q = cent[rng.integers(0, nfam, nq)] + spread * rng.standard_normal((nq, dim)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return np.ascontiguousarray(x, dtype=np.float32), np.ascontiguousarray(q, dtype=np.float32)
+
+for spread in (0.35, 0.1, 0.03, 0.01):
+    corpus, queries = family(300, 124, 768, spread, 1000, 7)
+    n = corpus.shape[0]
+    idx = IcdIndex(corpus, icd_levels(n, 8), max_nq=1000, max_k=128)
+    for nq, k in ((1000, 10), (1000, 20), (1000, 40), (100, 20), (1, 20)):
+        dq = torch.from_numpy(queries[:nq]).cuda()
+        for _ in range(3): idx.search_reweighted(dq, k, MODE_AUTO)
+        torch.cuda.synchronize()
+        idx.set_profiling(True); idx.profile_summary()
+        t0 = time.perf_counter(); it = 10
+        for _ in range(it): idx.search_reweighted(dq, k, MODE_AUTO)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / it
+        p = idx.profile_summary(); idx.set_profiling(False); st = idx.stats()
+        print("spread %.2f n %d nq %4d k %3d: %.3f ms | prep %.3f coarse %.3f finalize %.3f exact %.3f exact_fin %.3f | lists %d fallback %d mode %d" % (
+            spread, n, nq, k, dt * 1e3, p["ms_prep"], p["ms_coarse"], p["ms_finalize"], p["ms_exact"], p["ms_exact_finalize"],
+            st["last_chunks"], st["last_fallback"], st["last_mode"]), flush=True)
+    idx.close()
