@@ -16,20 +16,28 @@ def family(nfam, per, dim, spread, nq, seed):
     q /= np.linalg.norm(q, axis=1, keepdims=True)
     return np.ascontiguousarray(x, dtype=np.float32), np.ascontiguousarray(q, dtype=np.float32)
 
-for spread in (0.35, 0.1, 0.03, 0.01):
-    corpus, queries = family(300, 124, 768, spread, 1000, 7)
-    n = corpus.shape[0]
-    idx = IcdIndex(corpus, icd_levels(n, 8), max_nq=1000, max_k=128)
-    for nq, k in ((1000, 10), (1000, 20), (1000, 40), (100, 20), (1, 20)):
-        dq = torch.from_numpy(queries[:nq]).cuda()
-        for _ in range(3): idx.search_reweighted(dq, k, MODE_AUTO)
-        torch.cuda.synchronize()
-        idx.set_profiling(True); idx.profile_summary()
-        t0 = time.perf_counter(); it = 10
-        for _ in range(it): idx.search_reweighted(dq, k, MODE_AUTO)
-        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / it
-        p = idx.profile_summary(); idx.set_profiling(False); st = idx.stats()
-        print("spread %.2f n %d nq %4d k %3d: %.3f ms | prep %.3f coarse %.3f finalize %.3f exact %.3f exact_fin %.3f | lists %d fallback %d mode %d" % (
-            spread, n, nq, k, dt * 1e3, p["ms_prep"], p["ms_coarse"], p["ms_finalize"], p["ms_exact"], p["ms_exact_finalize"],
-            st["last_chunks"], st["last_fallback"], st["last_mode"]), flush=True)
-    idx.close()
+def main(spreads=(0.35, 0.1, 0.03, 0.01), shapes=((1000, 10), (1000, 20), (1000, 40), (100, 20), (1, 20)), max_nq=1000):
+    for spread in spreads:
+        corpus, queries = family(300, 124, 768, spread, max_nq, 7)
+        n = corpus.shape[0]
+        idx = IcdIndex(corpus, icd_levels(n, 8), max_nq=max_nq, max_k=128)
+        for nq, k in shapes:
+            dq = torch.from_numpy(queries[:nq]).cuda()
+            for _ in range(3): idx.search_reweighted(dq, k, MODE_AUTO)
+            torch.cuda.synchronize()
+            idx.set_profiling(True); idx.profile_summary()
+            t0 = time.perf_counter(); it = 10
+            for _ in range(it): idx.search_reweighted(dq, k, MODE_AUTO)
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / it
+            p = idx.profile_summary(); idx.set_profiling(False); st = idx.stats()
+            print("spread %.2f n %d nq %4d k %3d: %.3f ms | prep %.3f coarse %.3f finalize %.3f exact %.3f exact_fin %.3f | lists %d fallback %d mode %d" % (
+                spread, n, nq, k, dt * 1e3, p["ms_prep"], p["ms_coarse"], p["ms_finalize"], p["ms_exact"], p["ms_exact_finalize"],
+                st["last_chunks"], st["last_fallback"], st["last_mode"]), flush=True)
+        idx.close()
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "large":
+        main(spreads=(0.35, 0.1), shapes=((4000, 10), (4000, 20), (10000, 10), (10000, 20)), max_nq=10000)
+    else:
+        main()
