@@ -240,7 +240,8 @@ def run_replicated(ctx, args, index_factory=hip_index_factory):
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle as orc
         t0 = time.perf_counter()
-        os_, oi = orc.flat_ip_topk(corpus, queries, k)
+        # (torchrun exports OMP_NUM_THREADS=1 to its ranks: give the checker its share of the host's cores explicitly)
+        os_, oi = orc.flat_ip_topk(corpus, queries, k, nthreads=max(1, (os.cpu_count() or 1) // max(1, ctx.world)))
         want = orc.reweight(os_, oi, levels)
         check_s = time.perf_counter() - t0
         recall = float(np.mean([len(set(a) & set(b)) / k for a, b in zip(ids, oi)]))
