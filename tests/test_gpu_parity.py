@@ -192,6 +192,31 @@ def test_tight_families_are_certified_by_the_wide_window(oracle, k):
     idx.close()
 
 
+def test_more_lists_certify_tight_families_in_a_large_batch(oracle):
+    """4 096 queries have 8 candidate lists of 16: fewer candidates than a 124-row family of near-identical rows has
+    members, so most queries take the exact re-search; with ~20 lists per query (icd_index_set_chunks, what
+    MilvusService.search_batch asks for after such a batch) none does. Bit-identical results either way."""
+    rng = np.random.default_rng(7)
+    cent = rng.standard_normal((300, 768)).astype(np.float32)
+    corpus = np.repeat(cent, 124, axis=0) + 0.1 * rng.standard_normal((300 * 124, 768)).astype(np.float32)
+    corpus = np.ascontiguousarray(corpus / np.linalg.norm(corpus, axis=1, keepdims=True), dtype=np.float32)
+    queries = cent[rng.integers(0, 300, 4096)] + 0.1 * rng.standard_normal((4096, 768)).astype(np.float32)
+    queries = np.ascontiguousarray(queries / np.linalg.norm(queries, axis=1, keepdims=True), dtype=np.float32)
+    levels = icd_levels(corpus.shape[0], 9)
+    idx = IcdIndex(corpus, levels, max_nq=4096, max_k=20)
+    s0, i0 = idx.search(queries, 20, MODE_AUTO)
+    assert idx.stats()["last_fallback"] > 0.5 * 4096
+    idx.set_chunks(20)
+    s1, i1 = idx.search(queries, 20, MODE_AUTO)
+    st = idx.stats()
+    assert st["last_fallback"] == 0 and st["last_chunks"] >= 12
+    assert np.array_equal(i0, i1) and _bits(s0) == _bits(s1)
+    sample = np.arange(0, 4096, 16)
+    os_, oi = oracle.flat_ip_topk(corpus, queries[sample], 20)
+    assert np.array_equal(i1[sample], oi) and _bits(s1[sample]) == _bits(os_)
+    idx.close()
+
+
 def test_corpus_in_code_order_stays_on_the_fast_path(oracle):
     """A query's whole family is contiguous in the corpus. The fp16 copy is stored in a permuted row order so the family
     spreads over the candidate lists; without it one list holds the family, ends on a bound inside it and the
