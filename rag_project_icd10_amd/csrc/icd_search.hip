@@ -16,6 +16,7 @@
 #ifdef ICD_ABLATE
 #include "../../experiments/r02_rg_kernel/coarse_rg_kernel.hpp"   // (A/B builds only: the row-group experiment)
 #include "../../experiments/r02_w8_kernel/coarse_w8_kernel.hpp"   // (A/B builds only: eight waves, two per SIMD)
+#include "../../experiments/r02_g16_kernel/coarse_g16_kernel.hpp" // (A/B builds only: the flat geometry on 16x16x32)
 #endif
 #include "exact_kernel.hpp"
 #include "finalize.hpp"
@@ -196,6 +197,17 @@ int launch_coarse_rg(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream_t
     HIP_TRY(hipGetLastError());
     return ICD_OK;
 }
+template <int D, int KP = CO_KP, int VAR = 0>
+int launch_coarse_g16(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream_t s) {
+    auto kern = coarse_g16_kernel<D, KP, VAR>;
+    constexpr int lds = w8_lds_bytes();
+    static int configured[MAX_DEVICES] = {};
+    HIP_TRY(ensure_dynamic_lds(kern, x->device, (size_t)(lds), configured));
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, s, a);
+    HIP_TRY(hipGetLastError());
+    return ICD_OK;
+}
+
 template <int D, int KP = CO_KP, int VAR = 0>
 int launch_coarse_w8rg(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream_t s) {
     auto kern = coarse_w8rg_kernel<D, KP, VAR>;
@@ -541,6 +553,8 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             const int v = atoi(wv);
             if (v == 0 && !wide_lists) rc = launch_coarse_w8<768>(x, a, nwg, s);
             else if (v == 1) rc = launch_coarse_w8<768, CO_KP, 1>(x, a, nwg, s);
+            else if (v == 20 && !wide_lists) rc = launch_coarse_g16<768>(x, a, nwg, s);
+            else if (v == 21) rc = launch_coarse_g16<768, CO_KP, 1>(x, a, nwg, s);
             else if (v == 10 && !wide_lists) rc = launch_coarse_w8rg<768>(x, a, nwg, s);
             else if (v == 11) rc = launch_coarse_w8rg<768, CO_KP, 1>(x, a, nwg, s);
             else if (v == 12) rc = launch_coarse_w8rg<768, CO_KP, 2>(x, a, nwg, s);
