@@ -209,6 +209,17 @@ int launch_coarse_g16(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream_
 }
 
 template <int D, int KP = CO_KP, int VAR = 0>
+int launch_coarse_g16r(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream_t s) {
+    auto kern = coarse_g16r_kernel<D, KP, VAR>;
+    constexpr int lds = g16_lds_bytes();
+    static int configured[MAX_DEVICES] = {};
+    HIP_TRY(ensure_dynamic_lds(kern, x->device, (size_t)(lds), configured));
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, s, a);
+    HIP_TRY(hipGetLastError());
+    return ICD_OK;
+}
+
+template <int D, int KP = CO_KP, int VAR = 0>
 int launch_coarse_w8rg(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream_t s) {
     auto kern = coarse_w8rg_kernel<D, KP, VAR>;
     constexpr int lds = w8_lds_bytes();
@@ -555,6 +566,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             else if (v == 1) rc = launch_coarse_w8<768, CO_KP, 1>(x, a, nwg, s);
             else if (v == 20 && !wide_lists) rc = launch_coarse_g16<768>(x, a, nwg, s);
             else if (v == 21) rc = launch_coarse_g16<768, CO_KP, 1>(x, a, nwg, s);
+            else if (v == 30 && !wide_lists) rc = launch_coarse_g16r<768>(x, a, nwg, s);
             else if (v == 10 && !wide_lists) rc = launch_coarse_w8rg<768>(x, a, nwg, s);
             else if (v == 11) rc = launch_coarse_w8rg<768, CO_KP, 1>(x, a, nwg, s);
             else if (v == 12) rc = launch_coarse_w8rg<768, CO_KP, 2>(x, a, nwg, s);
