@@ -23,7 +23,6 @@
 
 namespace icd {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int W8_WAVES = 8;
 constexpr int W8_QPW = 16;   // queries per wave

@@ -253,13 +253,18 @@ __device__ __forceinline__ void compact_all_parallel(char *smem, Sel2 &st, uint3
 //        exec-masked from the four masks, no compare is repeated
 //   128  A fragments read two k-steps ahead of their MFMAs instead of one
 //   1024 diagnostic: s_memtime stamps around the mid-stage wait, the barrier and the select (CoarseFlatArgs::dbg)
+//   32768  the sweep on v_mfma_f32_16x16x32_f16 (the chip holds a higher clock on this shape: loop -12 %): the wave's 32 queries
+//        are two B-operand groups of 16, every corpus fragment (16 rows x 32 halves) feeds two MFMAs; a query's scores then
+//        sit in FOUR lanes (l & 15 equal) - 32 v_permlane16_swap per tile exchange group 1 of the even 16-lane rows with
+//        group 0 of the odd ones, after which lane l holds 64 scores of query l & 31 again (rows 16 rg + 8 (l >> 5) + 0..7)
+//        and the two-lane select below runs unchanged
 //   32 / 2048  every 16 / 24 tiles all four waves compact ALL their queries at once (compact_all_parallel) at the tile end
 //   TIMING ONLY (the results are not the scores; they size the parts of the kernel, profiles/r02_coarse_loop_decomposition.log):
 //   256 no s_barrier   512 no wait for the LDS-DMA pieces   4096 thresholds at +inf (nothing passes)
 //   8192 no select at all   16384 no LDS-DMA inside the tile loop
 // Variants that were measured and dropped (per-wave DMA slots, branch-free select, 3/6-stage rings, select deferred into
 // the next tile's MFMA gaps, 16x16x32 MFMA shape) live in experiments/r02_flat_variants/ with their logs.
-constexpr int CF_PRODUCT_VAR = 1 + 2 + 8 + 128 + 16 + 2048;   // measured: profiles/r02_ab_flat_variants.log, profiles/r02_coarse_variants_rg_w8_all.log (+ 16 + 2048: -2 %)
+constexpr int CF_PRODUCT_VAR = 1 + 2 + 8 + 128 + 16 + 2048 + 32768;   // measured: profiles/r02_ab_flat_variants.log, profiles/r02_coarse_variants_rg_w8_all.log (+ 16 + 2048: -2 %; + 32768: -2 % at 37 000 rows, -4 % on 1.25 M-row shards)
 __host__ __device__ constexpr int cf_ring_stages(int) { return CO_S; }
 __host__ __device__ constexpr int cf_lds_bytes(int var) { return cf_ring_stages(var) * CO_STAGE_BYTES + CO_BM * CO_CAP * 8 + 4 * 256; }
 #define ICD_CF_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); \
@@ -277,6 +282,8 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     constexpr bool PF2 = (VAR & 128) != 0;
     constexpr bool REV_WAIT = (VAR & 4) != 0;
     constexpr bool QUAD = (VAR & 16) != 0;
+    constexpr bool X16 = (VAR & 32768) != 0;   // v_mfma_f32_16x16x32_f16: a wave's 32 queries as two groups of 16 (see the VAR list)
+    static_assert(!X16 || (QUAD && (VAR & 128) != 0 && (VAR & 8) != 0 && D % 32 == 0), "the 16x16x32 form is built on the quad select, PF2 and pinned queries");
     constexpr int EPOCH = ((VAR & 32) && (VAR & 2048)) ? 32 : ((VAR & 32) ? 16 : ((VAR & 2048) ? 24 : 0));   // tiles between the synchronised compactions of all queries
     constexpr bool NOBAR = (VAR & 256) != 0, NOVM = (VAR & 512) != 0, STAMPS = (VAR & 1024) != 0;
     constexpr bool NOPASS = (VAR & 4096) != 0, NOSEL = (VAR & 8192) != 0, NODMA = (VAR & 16384) != 0;
@@ -291,6 +298,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
+    const int qi = lane & 15, g16 = lane >> 4;   // (X16: query of the group / row of the 16-row group, and k-octet / row quartet)
     // Which range does this work-group take? Work-groups l, l + T, l + 2T, ... (T = pos_period) sweep the same corpus
     // tiles at the same time (for other query tiles). The dispatcher deals consecutive blockIdx round-robin over the
     // 8 XCDs, each with its own L2: remap so that an XCD gets a contiguous stretch of the CLASS-MAJOR order
@@ -312,15 +320,25 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
         src_off[i] = (uint32_t)row_local * (uint32_t)(D * 2) + (uint32_t)piece * 16u - (uint32_t)(i * 1024);   // (piece i is issued with instruction offset 1024 i, see issue_stage)
     }
     uint32_t rd_off[4];
-    {
+    if constexpr (X16) {   // A fragment of a 16-row group, k-step k2 of the stage: row qi, 16-B piece 4 k2 + g16 of its line
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) rd_off[k2] = (uint32_t)qi * 128u + (uint32_t)(((4 * k2 + g16) ^ ((qi >> 1) & 7)) * 16);
+        rd_off[2] = rd_off[3] = 0u;
+    } else {
         const int sw = (c >> 1) & 7;
 #pragma unroll
         for (int s = 0; s < 4; ++s) rd_off[s] = (uint32_t)c * 128u + (uint32_t)(((2 * s + h) ^ sw) * 16);
     }
     auto read_frags = [&](half8 (&f)[4], int ring_slot, int s) {
-        const char *sb = smem + ring_slot * CO_STAGE_BYTES + rd_off[s];
+        if constexpr (X16) {   // quad s of the stage: k-step s >> 1, row groups 4 (s & 1) .. + 3
+            const char *sb = smem + ring_slot * CO_STAGE_BYTES + (s & 1) * 8192 + rd_off[s >> 1];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) f[t] = *reinterpret_cast<const half8 *>(sb + t * 4096);
+            for (int t = 0; t < 4; ++t) f[t] = *reinterpret_cast<const half8 *>(sb + t * 2048);
+        } else {
+            const char *sb = smem + ring_slot * CO_STAGE_BYTES + rd_off[s];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) f[t] = *reinterpret_cast<const half8 *>(sb + t * 4096);
+        }
     };
     constexpr uint32_t RING_BYTES = (uint32_t)S * CO_STAGE_BYTES;
     const uint32_t wave_qbase = RING_BYTES + (uint32_t)(wave * 32) * Ops::QBYTES;
@@ -345,9 +363,18 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
         const int slot0 = mtile * CO_BM;
 
         if (mtile != cur_mtile) {   // query fragments -> registers (B operand: lane holds Q[query c][16 s + 8 h + j])
-            const _Float16 *qrow = a.q16 + (size_t)(slot0 + wave * 32 + c) * D + 8 * h;
+            if constexpr (X16) {   // group gr's fragments at qf[gr NF/2 ..): lane holds Q[query 16 gr + qi][32 s + 8 g16 + 0..7]
 #pragma unroll
-            for (int s = 0; s < NF; ++s) qf[s] = *reinterpret_cast<const half8 *>(qrow + 16 * s);
+                for (int gr = 0; gr < 2; ++gr) {
+                    const _Float16 *qrow = a.q16 + (size_t)(slot0 + wave * 32 + 16 * gr + qi) * D + 8 * g16;
+#pragma unroll
+                    for (int s = 0; s < NF / 2; ++s) qf[gr * (NF / 2) + s] = *reinterpret_cast<const half8 *>(qrow + 32 * s);
+                }
+            } else {
+                const _Float16 *qrow = a.q16 + (size_t)(slot0 + wave * 32 + c) * D + 8 * h;
+#pragma unroll
+                for (int s = 0; s < NF; ++s) qf[s] = *reinterpret_cast<const half8 *>(qrow + 16 * s);
+            }
             if constexpr (Q_AGPR) {
 #pragma unroll
                 for (int s = 0; s < NF; ++s) asm volatile("" : "+a"(qf[s]));
@@ -406,11 +433,13 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             }
         };
 
-        auto filter_quad = [&](const f32x16 (&pa)[4], auto Q, uint32_t rowbase, auto GUARD) {
+        auto filter_quad = [&](const f32x16 (&pa)[X16 ? 1 : 4], const f32x4 (&px)[X16 ? 16 : 1], auto Q, uint32_t rowbase, auto GUARD) {
             constexpr int q = decltype(Q)::value;
             constexpr int t = q >> 2, g = q & 3;
-            constexpr uint32_t qoff = (uint32_t)(t * 32 + 8 * g);   // registers 4 g .. 4 g + 3 of row tile t: rows qoff + 0..3 (+ 4 h)
-            float v0 = pa[t][4 * g + 0], v1 = pa[t][4 * g + 1], v2 = pa[t][4 * g + 2], v3 = pa[t][4 * g + 3];
+            // registers 4 g .. 4 g + 3 of row tile t: rows qoff + 0..3 (+ 4 h); X16: quad q = row group q >> 1, half q & 1 (+ 8 h)
+            constexpr uint32_t qoff = X16 ? (uint32_t)(16 * (q >> 1) + 4 * (q & 1)) : (uint32_t)(t * 32 + 8 * g);
+            float v0 = X16 ? px[X16 ? q : 0][0] : pa[X16 ? 0 : t][4 * g + 0], v1 = X16 ? px[X16 ? q : 0][1] : pa[X16 ? 0 : t][4 * g + 1];
+            float v2 = X16 ? px[X16 ? q : 0][2] : pa[X16 ? 0 : t][4 * g + 2], v3 = X16 ? px[X16 ? q : 0][3] : pa[X16 ? 0 : t][4 * g + 3];
             const uint32_t rowq = rowbase + qoff;
             if constexpr (decltype(GUARD)::value) {
                 if ((int)(rowq + 0u) >= a.n) v0 = -INFINITY;
@@ -464,23 +493,40 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
 
         for (int tile = 0; tile < ntiles; ++tile) {
             uint32_t seen_early = 0u;
-            f32x16 acc[4];
+            f32x16 acc[X16 ? 1 : 4];
+            f32x4 xs[X16 ? 16 : 1];   // X16: accumulator of row group rg and query group gr at xs[2 rg + gr]
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < (X16 ? 1 : 4); ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < (X16 ? 16 : 1); ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xs[t][r] = 0.0f;
             static_for<0, KS>([&](auto KSI) {
                 constexpr int ks = decltype(KSI)::value;
                 constexpr int slot = ks % S, nslot = (ks + 1) % S;
                 auto mfma4 = [&](const half8 (&f)[4], int qi) {
                     // (REV_WAIT: the four MFMAs of a k-step in the reverse of the order their fragments were read - the first one
                     //  waits for the youngest read, the other three need no s_waitcnt at all)
+                    if constexpr (X16) {   // qi = 4 ks + quad: k-step 2 ks + (quad >> 1), row groups 4 (quad & 1) + t, both query groups
+                        const int quad = qi & 3, kq = (qi >> 2) * 2 + (quad >> 1);
 #pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) {
-                        const int t = REV_WAIT ? 3 - tt : tt;
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[t], qf[qi], acc[t], 0, 0, 0);
+                        for (int t = 0; t < 4; ++t) {
+                            const int rg = 4 * (quad & 1) + t;
+#pragma unroll
+                            for (int gr = 0; gr < 2; ++gr)
+                                xs[2 * rg + gr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[t], qf[gr * (NF / 2) + kq], xs[2 * rg + gr], 0, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt) {
+                            const int t = REV_WAIT ? 3 - tt : tt;
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[t], qf[qi], acc[t], 0, 0, 0);
+                        }
                     }
                 };
+                constexpr int M4 = X16 ? 8 : 4;   // MFMAs per k-step group
                 // stage g = (tile, ks) was published by the previous mid-stage barrier; afn holds its k-step 0 (PF2: bfn its k-step 1)
                 half8 f1[4], f2[4], f3[4];
                 if constexpr (PF2) {
@@ -496,9 +542,9 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                 }
                 // pin: the reads go out before the MFMAs of the k-step in front of them
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, M4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, M4, 0);
                 // publish stage g+1: this wave's pieces of g+1 have landed when only the stages behind it are outstanding
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (STAMPS) {
@@ -539,21 +585,35 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                 if constexpr (!DMA_SPREAD) {          // the four pieces in a burst behind the barrier
                     __builtin_amdgcn_sched_group_barrier(0x020, 4, 1);
                     __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x008, M4, 1);
                     __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x008, M4, 1);
                 } else {                               // one piece behind each of the next four MFMAs
                     __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                        __builtin_amdgcn_sched_group_barrier(0x008, M4 / 4, 1);
                         __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
                     }
                     __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x008, M4, 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
+            if constexpr (X16) {
+                // Lane (qi, g16) holds, per row group rg, rows 4 g16 + 0..3 of query qi (xs[2 rg]) and of query 16 + qi
+                // (xs[2 rg + 1]). Swapping xs[2 rg]'s odd 16-lane rows with xs[2 rg + 1]'s even ones gives every lane 8
+                // consecutive rows of ONE query: lane l -> query l & 31, xs[2 rg] = rows 16 rg + 8 (l >> 5) + 0..3,
+                // xs[2 rg + 1] = rows + 4..7: the lane pair (l, l + 32) of the two-lane select.
+#pragma unroll
+                for (int rg = 0; rg < 8; ++rg)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(xs[2 * rg][i]), __float_as_uint(xs[2 * rg + 1][i]), false, false);
+                        xs[2 * rg][i] = __uint_as_float(sw[0]);
+                        xs[2 * rg + 1][i] = __uint_as_float(sw[1]);
+                    }
+            }
             unsigned long long ts0 = 0;
             if constexpr (STAMPS) ICD_CF_STAMP(ts0);
             // Threshold sharing between the lists of a query (they are swept by different work-groups at the same
@@ -580,7 +640,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             if constexpr (STAMPS) { ICD_CF_STAMP(ts_a); st_thr += ts_a - ts0; }
             // fused select of the finished tile (rows >= n exist only in the corpus's last tile)
             const int tile_row0 = (t0 + tile) * CO_BN;
-            const uint32_t rowbase = (uint32_t)(tile_row0 + 4 * h);
+            const uint32_t rowbase = (uint32_t)(tile_row0 + (X16 ? 8 : 4) * h);
             if (tile < boot_tiles && tile_row0 + CO_BN <= a.n) {
                 // Threshold bootstrap. A list that starts at -inf appends all 128 rows of its first tile and the
                 // next few hundred, and compacts 5-8 times per query before its threshold means anything (~60 us
@@ -596,7 +656,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float v = acc[t][r];
+                        const float v = X16 ? xs[X16 ? 4 * t + (r >> 2) : 0][r & 3] : acc[X16 ? 0 : t][r];
                         const float lo1 = raw_min_f32(boot1, v);
                         boot1 = raw_max_f32(boot1, v);
                         const float lo2 = raw_min_f32(boot2, lo1);
@@ -610,10 +670,16 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             if constexpr (STAMPS) { unsigned long long ts_b; ICD_CF_STAMP(ts_b); st_boot += ts_b - ts_a; }
             if constexpr (NOSEL) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(acc[t]));
+                for (int t = 0; t < (X16 ? 1 : 4); ++t) asm volatile("" ::"v"(acc[t]));
+                if constexpr (X16) {
+                    float keep = 0.0f;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) keep += xs[X16 ? t : 0][0] + xs[X16 ? t : 0][1] + xs[X16 ? t : 0][2] + xs[X16 ? t : 0][3];
+                    asm volatile("" ::"v"(keep));
+                }
             } else if constexpr (QUAD) {
-                if (tile_row0 + CO_BN > a.n) static_for<0, 16>([&](auto Q) { filter_quad(acc, Q, rowbase, std::true_type{}); });
-                else static_for<0, 16>([&](auto Q) { filter_quad(acc, Q, rowbase, std::false_type{}); });
+                if (tile_row0 + CO_BN > a.n) static_for<0, 16>([&](auto Q) { filter_quad(acc, xs, Q, rowbase, std::true_type{}); });
+                else static_for<0, 16>([&](auto Q) { filter_quad(acc, xs, Q, rowbase, std::false_type{}); });
             } else if (tile_row0 + CO_BN > a.n) static_for<0, 64>([&](auto F) { filter_reg(acc, F, rowbase, std::true_type{}); });
             else static_for<0, 64>([&](auto F) { filter_reg(acc, F, rowbase, std::false_type{}); });
             if constexpr (EPOCH > 0) {

@@ -14,6 +14,7 @@
 namespace icd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
 
 // ---- 64-bit sortable key: larger key = better hit (score desc, row asc) -----------------------------
