@@ -495,10 +495,12 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             uint32_t seen_early = 0u;
             f32x16 acc[X16 ? 1 : 4];
             f32x4 xs[X16 ? 16 : 1];   // X16: accumulator of row group rg and query group gr at xs[2 rg + gr]
+            if constexpr (!X16) {
 #pragma unroll
-            for (int t = 0; t < (X16 ? 1 : 4); ++t)
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+                    for (int r = 0; r < 16; ++r) acc[X16 ? 0 : t][r] = 0.0f;
+            }
 #pragma unroll
             for (int t = 0; t < (X16 ? 16 : 1); ++t)
 #pragma unroll
