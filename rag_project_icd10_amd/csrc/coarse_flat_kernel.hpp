@@ -685,7 +685,9 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             } else if (tile_row0 + CO_BN > a.n) static_for<0, 64>([&](auto F) { filter_reg(acc, F, rowbase, std::true_type{}); });
             else static_for<0, 64>([&](auto F) { filter_reg(acc, F, rowbase, std::false_type{}); });
             if constexpr (EPOCH > 0) {
-                if ((tile + 1) % EPOCH == 0 && tile + 1 < ntiles)
+                // (nothing to do where no lane has appended more than a few entries since the last compaction: the long lists
+                //  of a row-sharded corpus, 4 900 tiles, append a handful of rows per hundred tiles once they are warm)
+                if ((tile + 1) % EPOCH == 0 && tile + 1 < ntiles && __builtin_amdgcn_ballot_w64(Ops::used(st, h) > 3) != 0ull)
                     compact_all_parallel<KP, Ops>(smem, st, wave_qbase + (uint32_t)c * Ops::QBYTES, h, c);
             }
             if constexpr (STAMPS) {
