@@ -261,7 +261,7 @@ __device__ __forceinline__ void compact_all_parallel(char *smem, Sel2 &st, uint3
 //   32 / 2048  every 16 / 24 tiles all four waves compact ALL their queries at once (compact_all_parallel) at the tile end
 //   TIMING ONLY (the results are not the scores; they size the parts of the kernel, profiles/r02_coarse_loop_decomposition.log):
 //   256 no s_barrier   512 no wait for the LDS-DMA pieces   4096 thresholds at +inf (nothing passes)
-//   8192 no select at all   16384 no LDS-DMA inside the tile loop
+//   8192 no select at all   16384 no LDS-DMA inside the tile loop   65536 (with 32768) no lane swaps
 // Variants that were measured and dropped (per-wave DMA slots, branch-free select, 3/6-stage rings, select deferred into
 // the next tile's MFMA gaps, 16x16x32 MFMA shape) live in experiments/r02_flat_variants/ with their logs.
 constexpr int CF_PRODUCT_VAR = 1 + 2 + 8 + 128 + 16 + 2048 + 32768;   // measured: profiles/r02_ab_flat_variants.log, profiles/r02_coarse_variants_rg_w8_all.log (+ 16 + 2048: -2 %; + 32768: -2 % at 37 000 rows, -4 % on 1.25 M-row shards)
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
-            if constexpr (X16) {
+            if constexpr (X16 && (VAR & 65536) == 0) {   // (VAR & 65536: TIMING ONLY, without the lane swaps)
                 // Lane (qi, g16) holds, per row group rg, rows 4 g16 + 0..3 of query qi (xs[2 rg]) and of query 16 + qi
                 // (xs[2 rg + 1]). Swapping xs[2 rg]'s odd 16-lane rows with xs[2 rg + 1]'s even ones gives every lane 8
                 // consecutive rows of ONE query: lane l -> query l & 31, xs[2 rg] = rows 16 rg + 8 (l >> 5) + 0..3,
