@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
-    const int qi = lane & 15, g16 = lane >> 4;   // (X16: query of the group / row of the 16-row group, and k-octet / row quartet)
+    const int q16 = lane & 15, g16 = lane >> 4;   // (X16: query of the group / row of the 16-row group, and k-octet / row quartet)
     // Which range does this work-group take? Work-groups l, l + T, l + 2T, ... (T = pos_period) sweep the same corpus
     // tiles at the same time (for other query tiles). The dispatcher deals consecutive blockIdx round-robin over the
     // 8 XCDs, each with its own L2: remap so that an XCD gets a contiguous stretch of the CLASS-MAJOR order
@@ -320,9 +320,9 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
         src_off[i] = (uint32_t)row_local * (uint32_t)(D * 2) + (uint32_t)piece * 16u - (uint32_t)(i * 1024);   // (piece i is issued with instruction offset 1024 i, see issue_stage)
     }
     uint32_t rd_off[4];
-    if constexpr (X16) {   // A fragment of a 16-row group, k-step k2 of the stage: row qi, 16-B piece 4 k2 + g16 of its line
+    if constexpr (X16) {   // A fragment of a 16-row group, k-step k2 of the stage: row q16, 16-B piece 4 k2 + g16 of its line
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) rd_off[k2] = (uint32_t)qi * 128u + (uint32_t)(((4 * k2 + g16) ^ ((qi >> 1) & 7)) * 16);
+        for (int k2 = 0; k2 < 2; ++k2) rd_off[k2] = (uint32_t)q16 * 128u + (uint32_t)(((4 * k2 + g16) ^ ((q16 >> 1) & 7)) * 16);
         rd_off[2] = rd_off[3] = 0u;
     } else {
         const int sw = (c >> 1) & 7;
@@ -363,10 +363,10 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
         const int slot0 = mtile * CO_BM;
 
         if (mtile != cur_mtile) {   // query fragments -> registers (B operand: lane holds Q[query c][16 s + 8 h + j])
-            if constexpr (X16) {   // group gr's fragments at qf[gr NF/2 ..): lane holds Q[query 16 gr + qi][32 s + 8 g16 + 0..7]
+            if constexpr (X16) {   // group gr's fragments at qf[gr NF/2 ..): lane holds Q[query 16 gr + q16][32 s + 8 g16 + 0..7]
 #pragma unroll
                 for (int gr = 0; gr < 2; ++gr) {
-                    const _Float16 *qrow = a.q16 + (size_t)(slot0 + wave * 32 + 16 * gr + qi) * D + 8 * g16;
+                    const _Float16 *qrow = a.q16 + (size_t)(slot0 + wave * 32 + 16 * gr + q16) * D + 8 * g16;
 #pragma unroll
                     for (int s = 0; s < NF / 2; ++s) qf[gr * (NF / 2) + s] = *reinterpret_cast<const half8 *>(qrow + 32 * s);
                 }
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             });
             if constexpr (X16 && (VAR & 65536) == 0) {   // (VAR & 65536: TIMING ONLY, without the lane swaps)
-                // Lane (qi, g16) holds, per row group rg, rows 4 g16 + 0..3 of query qi (xs[2 rg]) and of query 16 + qi
+                // Lane (q16, g16) holds, per row group rg, rows 4 g16 + 0..3 of query q16 (xs[2 rg]) and of query 16 + q16
                 // (xs[2 rg + 1]). Swapping xs[2 rg]'s odd 16-lane rows with xs[2 rg + 1]'s even ones gives every lane 8
                 // consecutive rows of ONE query: lane l -> query l & 31, xs[2 rg] = rows 16 rg + 8 (l >> 5) + 0..3,
                 // xs[2 rg + 1] = rows + 4..7: the lane pair (l, l + 32) of the two-lane select.
