@@ -559,6 +559,10 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         int rc;
         // (dim 1024: the query fragments alone are 256 registers: no pinning, no deeper fragment prefetch and the 32x32x16
         //  shape there; the quad select and the synchronised compaction apply)
+#ifdef ICD_ABLATE
+        if (x->dim == 1024 && getenv("ICD_1024_FULL")) rc = launch_coarse_flat<1024, CF_PRODUCT_VAR>(x, a, nwg, s);   // A/B: the 768 form
+        else
+#endif
         if (x->dim == 1024) rc = launch_coarse_flat<1024, (CF_PRODUCT_VAR & (3 | 16 | 2048))>(x, a, nwg, s);
 #ifdef ICD_ABLATE
         else if (const char *wv = getenv("ICD_W8_VAR")) {   // A/B builds: the eight-wave kernel
