@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     constexpr bool REV_WAIT = (VAR & 4) != 0;
     constexpr bool QUAD = (VAR & 16) != 0;
     constexpr bool X16 = (VAR & 32768) != 0;   // v_mfma_f32_16x16x32_f16: a wave's 32 queries as two groups of 16 (see the VAR list)
-    static_assert(!X16 || (QUAD && (VAR & 128) != 0 && (VAR & 8) != 0 && D % 32 == 0), "the 16x16x32 form is built on the quad select, PF2 and pinned queries");
+    static_assert(!X16 || (QUAD && (VAR & 8) != 0 && D % 32 == 0), "the 16x16x32 form is built on the quad select and pinned queries");
     constexpr int EPOCH = ((VAR & 32) && (VAR & 2048)) ? 32 : ((VAR & 32) ? 16 : ((VAR & 2048) ? 24 : 0));   // tiles between the synchronised compactions of all queries
     constexpr bool NOBAR = (VAR & 256) != 0, NOVM = (VAR & 512) != 0, STAMPS = (VAR & 1024) != 0;
     constexpr bool NOPASS = (VAR & 4096) != 0, NOSEL = (VAR & 8192) != 0, NODMA = (VAR & 16384) != 0;
