@@ -5,6 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks ITSELF: the parent (which never
+touches the GPU) runs the second command line above as a child process, relays rank 0's JSON line and exits with the
+child's status (spawn_ranks). Under torchrun (WORLD_SIZE set) the process is a rank and runs the workload.
+
 Workload `replicated` (default; BASELINE.json configs[1] at N = 1, configs[3] at N > 1), per GPU:
     corpus  37 000 x 768 fp32, iid N(0,1) rows L2-normalised, default_rng(1234); levels default_rng(1235)
             from the real CSV histogram;
@@ -22,6 +26,12 @@ level i32) per hit -> merge kernel + level reweight on every rank (rag_project_i
 One STEP = one pass of the whole query batch; per-GPU work is fixed as N grows (weak scaling: the corpus grows).
 With N > 1 the default run also measures this workload and reports it under "rowshard" in the same JSON line, so the
 driver's scaling run (bench.py --gpus 1/2/4/8) yields both curves.
+
+At N = 1 the default line also carries, under "extra" (never the headline): the same step on the real CSV's size
+(40 474 rows) and on SURVEY 8d's clustered data (512 centroids, x = normalise(c_j + 0.5 eps)), each with ms_per_step,
+fallback_queries and ids_exact against the oracle from the same run; "exact_mode" = the fp32-MFMA kernel alone on the
+headline workload against its own 157.3 TFLOP/s peak; "windows" = the K-step window repeated (min / median / max) and
+the first window of the process, before the clock has settled.
 
 The JSON line also carries
     roofline      dominant kernel (coarse_flat_kernel): algorithmic FLOPs 2*nq*n*dim per launch / its mean
@@ -45,13 +55,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS_F16 = 2500.0  # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
-# the kernel's own MFMA stream with nothing else in the loop, 10 000 x 37 000 x 768 (profiles/r01_ablate8_bare_loop_breakdown.log:
-# 0.357 ms): what the instruction stream can reach at the clock the chip holds under this load
-BARE_STREAM_TFLOPS = 1594.0
+PEAK_TFLOPS_F32 = 157.3   # fp32-input MFMA = the fp32 vector peak (same guide, "Matrix cores")
 
 
 def unit_rows(n, dim, seed):
     x = np.random.default_rng(seed).standard_normal((n, dim), dtype=np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def clustered_rows(n, dim, seed, centroid_seed=77, ncent=512, spread=0.5):
+    """SURVEY 8d's clustered variant: 512 unit centroids c_j, x = normalise(c_j + 0.5 eps) with |eps| ~ 1 (eps =
+    N(0, I) / sqrt(dim)): rows of one cluster have cosine ~0.8, the shape text embeddings have; corpus and queries share
+    the centroids (centroid_seed) and differ in `seed`"""
+    cent = unit_rows(ncent, dim, centroid_seed)
+    rng = np.random.default_rng(seed)
+    x = cent[rng.integers(0, ncent, n)] + (spread / np.sqrt(dim)) * rng.standard_normal((n, dim), dtype=np.float32)
     x /= np.linalg.norm(x, axis=1, keepdims=True)
     return np.ascontiguousarray(x, dtype=np.float32)
 
@@ -116,14 +135,16 @@ def cpu_baseline(corpus, levels, queries, k, budget_s=12.0, with_encoder=True):
     return out
 
 
-def pmc_traffic(kernel, nq, n):
+def pmc_traffic(kernel, nq, n, suffix=""):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/rNN_pmc_traffic.json, made by scripts/gpu_pmc.sh: FETCH_SIZE and WRITE_SIZE collected in their own
+    (profiles/rNN_pmc_traffic<suffix>.json, made by scripts/gpu_pmc.sh: FETCH_SIZE and WRITE_SIZE collected in their own
     passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950). PMC counters cannot be read from inside
-    this process; the number is reported only for the workload it was collected on, with the file it came from."""
+    this process: this is a CITATION of a profile of the same workload on another run (traffic_source names the file),
+    reported only for the workload it was collected on."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-    if not files or (nq, n) != (10000, 37000):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic{suffix}.json")))
+    want = (16384, 1250000) if suffix else (10000, 37000)
+    if not files or (nq, n) != want:
         return None, None
     try:
         d = json.load(open(files[-1]))
@@ -180,14 +201,33 @@ class Ctx:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
-    def timed(self, fn, steps, warmup, before_timing=None, settle_s=0.0):
-        """W untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; max over ranks.
-        settle_s: before the W warm-up steps the device is kept busy with the same work for that long (untimed setup,
-        like building the index): a fresh process needs ~20 steps until the chip holds its steady clock
-        (scripts/probe/clock_settle.py: 0.90, 0.77, then 0.745 ms per step in chunks of ten) and a K of a few dozen
-        steps would otherwise report the ramp, not the throughput."""
+    def window(self, fn, steps):
+        """exactly `steps` steps between barrier + synchronize on both sides; max over ranks"""
         out = None
+        self.barrier()
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        self.sync()
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0), out
+
+    def timed(self, fn, steps, warmup, before_timing=None, after_timing=None, settle_s=0.0, repeats=0):
+        """W untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; max over ranks:
+        THE measurement (first return value). Around it, reported next to it and never instead of it:
+        settle_s > 0: a fresh process needs ~20 steps until the chip holds its steady clock (scripts/probe/clock_settle.py:
+          0.90, 0.77, then 0.745 ms per step in chunks of ten), so before the W warm-up steps of the measurement the device
+          is kept busy with the same step for that long (untimed setup, like building the index) - and the window a plain
+          "W warm-up steps, K timed steps" gives in a fresh process is measured FIRST and returned as info["first_window_s"];
+        repeats: the K-step window is repeated that many times after the measurement (info["repeat_s"])."""
+        out = None
+        info = {"first_window_s": None, "repeat_s": []}
         if settle_s > 0:
+            for _ in range(warmup):
+                fn()
+            self.sync()
+            info["first_window_s"], _ = self.window(fn, steps)
             t_end = time.perf_counter() + settle_s
             while time.perf_counter() < t_end:
                 for _ in range(4):
@@ -198,19 +238,67 @@ class Ctx:
         self.sync()
         if before_timing:
             before_timing()
-        self.barrier()
-        self.sync()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            out = fn()
-        self.sync()
-        self.barrier()
-        return self.max_over_ranks(time.perf_counter() - t0), out
+        elapsed, out = self.window(fn, steps)
+        if after_timing:
+            after_timing()
+        for _ in range(repeats):
+            info["repeat_s"].append(self.window(fn, steps)[0])
+        return elapsed, out, info
 
 
 def hip_index_factory(corpus, levels, device, max_nq, max_k, id_base=0):
     from rag_project_icd10_amd._native import IcdIndex
     return IcdIndex(corpus, levels, device=device, max_nq=max_nq, max_k=max_k, id_base=id_base)
+
+
+def oracle_check(corpus, levels, queries, k, out, world=1):
+    """parity of EVERY query of a batch against the CPU oracle (the checker, outside any timed region)"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    adj, raw, ids, lv = (x.cpu().numpy() for x in out)
+    t0 = time.perf_counter()
+    # (torchrun exports OMP_NUM_THREADS=1 to its ranks: give the checker its share of the host's cores explicitly)
+    os_, oi = orc.flat_ip_topk(corpus, queries, k, nthreads=max(1, (os.cpu_count() or 1) // max(1, world)))
+    want = orc.reweight(os_, oi, levels)
+    return {"recall_at_10": float(np.mean([len(set(a) & set(b)) / k for a, b in zip(ids, oi)])),
+            "ids_exact": bool(np.array_equal(ids, want[2])),
+            "adjusted_scores_exact": bool(adj.tobytes() == want[0].tobytes()),
+            "max_abs_dscore": float(np.max(np.abs(raw.astype(np.float64) - want[1].astype(np.float64)))),
+            "parity_checked_queries": int(len(queries)), "parity_check_s": round(time.perf_counter() - t0, 2)}
+
+
+def side_workload(ctx, args, index_factory, name, corpus, levels, queries, k, mode, steps):
+    """one of the line's `extra` objects: the same step on other data / another size / the exact kernel alone, timed
+    over `steps` steps after a short warm-up and checked against the oracle on every query, in this run"""
+    from rag_project_icd10_amd._native import MODE_AUTO
+    torch = ctx.torch
+    index = index_factory(corpus, levels, ctx.local_rank, len(queries), max(k, 10))
+    dq = torch.from_numpy(queries).to(ctx.dev)
+    fn = lambda: index.search_reweighted(dq, k, mode)
+    for _ in range(max(3, args.warmup)):
+        fn()
+    ctx.sync()
+    index.set_profiling(True)
+    index.profile_summary()
+    elapsed, out = ctx.window(fn, steps)
+    prof = index.profile_summary()
+    index.set_profiling(False)
+    stats = index.stats()
+    fast = mode == MODE_AUTO and stats["last_mode"] == MODE_AUTO
+    dom_ms = prof["ms_coarse"] if fast else prof["ms_exact"]
+    flops = 2.0 * len(queries) * corpus.shape[0] * corpus.shape[1]
+    achieved = flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    peak = PEAK_TFLOPS_F16 if fast else PEAK_TFLOPS_F32
+    obj = {"workload": name, "corpus_rows": int(corpus.shape[0]), "nq": int(len(queries)), "top_k": k, "steps": steps,
+           "ms_per_step": elapsed / steps * 1e3, "queries_per_sec": len(queries) * steps / elapsed,
+           "fallback_queries": int(stats["last_fallback"]), "coarse_chunks": int(stats["last_chunks"]),
+           "kernel_ms": {kname: round(v, 5) for kname, v in prof.items() if kname != "count"},
+           "roofline": {"bound": "mfma", "kernel": "coarse_flat_kernel" if fast else "exact_topk_kernel", "achieved": achieved,
+                        "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "launch_ms": dom_ms,
+                        "launches_averaged": prof["count"]}}
+    obj.update(oracle_check(corpus, levels, queries, k, out, ctx.world))
+    index.close()
+    return obj
 
 
 def run_replicated(ctx, args, index_factory=hip_index_factory):
@@ -224,38 +312,30 @@ def run_replicated(ctx, args, index_factory=hip_index_factory):
     index = index_factory(corpus, levels, ctx.local_rank, nq, max(k, 10))
     dq = torch.from_numpy(queries).to(ctx.dev)
     ctx.sync()
+    prof = {}
 
     def before():
         index.set_profiling(True)
         index.profile_summary()  # reset the event window
 
-    elapsed, out = ctx.timed(lambda: index.search_reweighted(dq, k, mode), args.steps, args.warmup, before, settle_s=args.settle_ms / 1e3)
-    prof = index.profile_summary()
-    index.set_profiling(False)
+    def after():   # the kernel times of the measured window only (the repeats that follow are not averaged in)
+        prof.update(index.profile_summary())
+        index.set_profiling(False)
+
+    elapsed, out, info = ctx.timed(lambda: index.search_reweighted(dq, k, mode), args.steps, args.warmup, before, after,
+                                   settle_s=args.settle_ms / 1e3, repeats=args.repeats)
     stats = index.stats()
     line = None
     if ctx.rank == 0:
-        adj, raw, ids, lv = (x.cpu().numpy() for x in out)
-        # parity / recall of EVERY query of rank 0's batch against the CPU oracle (outside the timed region)
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle as orc
-        t0 = time.perf_counter()
-        # (torchrun exports OMP_NUM_THREADS=1 to its ranks: give the checker its share of the host's cores explicitly)
-        os_, oi = orc.flat_ip_topk(corpus, queries, k, nthreads=max(1, (os.cpu_count() or 1) // max(1, ctx.world)))
-        want = orc.reweight(os_, oi, levels)
-        check_s = time.perf_counter() - t0
-        recall = float(np.mean([len(set(a) & set(b)) / k for a, b in zip(ids, oi)]))
-        ids_exact = bool(np.array_equal(ids, want[2]))
-        adj_exact = bool(adj.tobytes() == want[0].tobytes())
-        max_dscore = float(np.max(np.abs(raw.astype(np.float64) - want[1].astype(np.float64))))
-
+        parity = oracle_check(corpus, levels, queries, k, out, ctx.world)
         fast = mode == MODE_AUTO and stats["last_mode"] == MODE_AUTO
         dom_ms = prof["ms_coarse"] if fast else prof["ms_exact"]
         flops = 2.0 * nq * n * dim
         achieved = flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-        peak = PEAK_TFLOPS_F16 if fast else 157.3
+        peak = PEAK_TFLOPS_F16 if fast else PEAK_TFLOPS_F32
         kern = "coarse_flat_kernel" if fast else "exact_topk_kernel"
         traffic, traffic_src = pmc_traffic(kern, nq, n)
+        per_step = sorted(x / args.steps * 1e3 for x in [elapsed] + info["repeat_s"])
         line = {
             "metric": "queries_per_sec", "value": ctx.world * nq * args.steps / elapsed, "unit": "queries/s",
             "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup, "settle_ms_before_warmup": args.settle_ms,
@@ -269,21 +349,35 @@ def run_replicated(ctx, args, index_factory=hip_index_factory):
                        "parallelism": f"query-sharded x{ctx.world}, corpus replicated" if ctx.world > 1 else "single GPU",
                        "collective_ranks": ctx.dist.get_world_size() if ctx.world > 1 else 1,
                        "result_arithmetic": "fp32 canonical chain (bit-identical to the CPU oracle)"},
-            "recall_at_10": recall, "ids_exact": ids_exact, "adjusted_scores_exact": adj_exact, "max_abs_dscore": max_dscore,
-            "parity_checked_queries": int(nq), "parity_check_s": round(check_s, 2),
+            **parity,
             "fallback_queries": int(stats["last_fallback"]), "coarse_chunks": int(stats["last_chunks"]),
             "kernel_ms": {kname: round(v, 5) for kname, v in prof.items() if kname != "count"},
             "roofline": {"bound": "mfma", "kernel": kern,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "traffic_unit": "bytes per launch (rocprofv3 PMC passes of this kernel, 2 x FETCH_SIZE + WRITE_SIZE)",
-                         "flops_per_launch": flops, "launch_ms": dom_ms, "launches_averaged": prof["count"],
-                         "bare_mfma_stream_tflops": BARE_STREAM_TFLOPS if fast else None,
-                         "frac_of_bare_mfma_stream": achieved / BARE_STREAM_TFLOPS if fast else None},
+                         "traffic_unit": "bytes per launch (rocprofv3 PMC passes of this kernel, 2 x FETCH_SIZE + WRITE_SIZE); a citation "
+                                         "of the committed profile of this workload, not measured in this run",
+                         "flops_per_launch": flops, "launch_ms": dom_ms, "launches_averaged": prof["count"]},
+            "extra": {"windows": {"what": f"the {args.steps}-step window repeated {1 + len(info['repeat_s'])} times back to back (the first is `value`), ms per step",
+                                  "min": per_step[0], "median": per_step[len(per_step) // 2], "max": per_step[-1],
+                                  "first_window_of_the_process": (info["first_window_s"] / args.steps * 1e3) if info["first_window_s"] else None}},
         }
-        if ctx.world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(corpus, levels, queries, k)
     index.close()
+    del index, dq
+    if ctx.world == 1 and not args.no_extras:
+        # (every rank would run these; they are N = 1 lines: other data and sizes next to the Gaussian headline)
+        steps_x = max(5, min(args.steps, 20))
+        ex = line["extra"]
+        n_real = 40474
+        ex["real_size"] = side_workload(ctx, args, index_factory, f"the real CSV's size: {nq} Gaussian queries x {n_real}x768 Gaussian rows",
+                                        unit_rows(n_real, dim, 1234), icd_levels(n_real, 1235), queries, k, mode, steps_x)
+        ex["clustered"] = side_workload(ctx, args, index_factory, f"SURVEY 8d clustered: 512 centroids, x = normalise(c_j + 0.5 eps), {nq} queries x {n}x768",
+                                        clustered_rows(n, dim, 2234), levels, clustered_rows(nq, dim, 5321), k, mode, steps_x)
+        if mode == MODE_AUTO:
+            ex["exact_mode"] = side_workload(ctx, args, index_factory, f"--mode exact: the fp32-MFMA kernel alone, {nq} x {n}x768",
+                                             corpus, levels, queries, k, MODE_EXACT, max(3, steps_x // 4))
+    if line is not None and ctx.world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(corpus, levels, queries, k)
     return line
 
 
@@ -323,6 +417,8 @@ def run_rowshard(ctx, args, index_factory=hip_index_factory, sharded_factory=Non
     index = index_factory(corpus, levels, ctx.local_rank, sl, max(k, 10), ctx.rank * n)
     ctx.sync()
     t_build = time.perf_counter() - t0
+    shard_host = corpus.cpu().numpy()   # the oracle's copy of this rank's shard (the checker below; outside the timed region)
+    levels_host = levels.cpu().numpy()
     del corpus
     gq = torch.Generator(device=ctx.dev)
     gq.manual_seed(4321)
@@ -340,16 +436,22 @@ def run_rowshard(ctx, args, index_factory=hip_index_factory, sharded_factory=Non
             index.set_profiling(True)
             index.profile_summary()
 
-    elapsed, outs = ctx.timed(one_pass, steps, warmup, before)
+    elapsed, outs, _ = ctx.timed(one_pass, steps, warmup, before)
     prof = index.profile_summary() if hasattr(index, "profile_summary") else {"ms_coarse": 0.0, "count": 0}
     if hasattr(index, "set_profiling"):
         index.set_profiling(False)
-    # correctness on a query sample: every rank's EXACT-kernel hits of its shard, gathered, merged by plain torch
-    # (score desc, id asc) must equal the ids / raw scores the row-sharded path returned
-    from rag_project_icd10_amd._native import MODE_EXACT
-    m = min(64, sl, nq)
+    # correctness on a query sample, against the CPU ORACLE: every rank runs oracle/icd_oracle.c over its own shard (host
+    # copy), the per-shard exact hits are gathered and merged by plain torch (score desc, id asc), and the ids / raw scores
+    # the row-sharded HIP path returned must equal that merge bit for bit
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    m = min(64 if ctx.world <= 2 else 32, sl, nq)
     sample = queries[:m].contiguous()
-    es, ei = index.search(sample, k, MODE_EXACT)
+    t0 = time.perf_counter()
+    os_, oi_ = orc.flat_ip_topk(shard_host, sample.cpu().numpy(), k, id_base=ctx.rank * n,
+                                nthreads=max(1, (os.cpu_count() or 1) // max(1, ctx.world)))
+    check_s = time.perf_counter() - t0
+    es, ei = torch.from_numpy(os_).to(ctx.dev), torch.from_numpy(oi_).to(ctx.dev)
     if ctx.world > 1:
         gs = [torch.empty_like(es) for _ in range(ctx.world)]
         gi = [torch.empty_like(ei) for _ in range(ctx.world)]
@@ -366,6 +468,15 @@ def run_rowshard(ctx, args, index_factory=hip_index_factory, sharded_factory=Non
     ids_ok = bool(torch.equal(torch.gather(ids0[:m], 1, got), torch.gather(wi, 1, want)))
     raw_ok = bool(torch.equal(torch.gather(raw0[:m], 1, got).view(torch.int32), torch.gather(ws, 1, want).view(torch.int32)))
     sorted_ok = bool((adj0[:, 1:] <= adj0[:, :-1]).all())
+    # rank 0 also checks the reweighted ORDER of the sample: adjusted score = raw x weight of the level the hit carries
+    # (levels of its own shard from the host copy; hits of other shards carry their level in the payload)
+    adj_ok = True
+    if ctx.rank == 0:
+        a0, r0, i0, l0 = (x[:m].cpu().numpy() for x in (adj0, raw0, ids0, lv0))
+        w = np.where(l0 == 1, 1.2, np.where(l0 == 3, 0.8, 1.0))
+        adj_ok = bool(np.array_equal(a0, r0.astype(np.float64) * w))
+        mine = (i0 >= 0) & (i0 < n)
+        adj_ok = adj_ok and bool(np.array_equal(l0[mine], levels_host[i0[mine]]))
     stats = index.stats() if hasattr(index, "stats") else {}
     line = None
     if ctx.rank == 0:
@@ -374,6 +485,7 @@ def run_rowshard(ctx, args, index_factory=hip_index_factory, sharded_factory=Non
         dom_ms = float(prof.get("ms_coarse", 0.0))
         # (slices differ in size only in the last one: price the mean launch against the mean slice)
         achieved = (flops_gpu / launches) / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic("coarse_flat_kernel", sl, n, "_rowshard")
         line = {
             "metric": "queries_per_sec", "value": nq * steps / elapsed, "unit": "queries/s",
             "n_gpus": ctx.world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
@@ -384,24 +496,80 @@ def run_rowshard(ctx, args, index_factory=hip_index_factory, sharded_factory=Non
                        "parallelism": f"row-sharded x{ctx.world}", "collective": "all_gather_into_tensor (RCCL)" if ctx.world > 1 else "none (one shard)",
                        "collective_ranks": dist.get_world_size() if ctx.world > 1 else 1},
             "whole_job_tflops": ctx.world * flops_gpu * steps / elapsed / 1e12,
-            "ids_exact_on_sample": ids_ok, "raw_scores_exact_on_sample": raw_ok, "adjusted_sorted": sorted_ok, "sample_queries": int(m),
+            "ids_exact_on_sample": ids_ok, "raw_scores_exact_on_sample": raw_ok, "adjusted_sorted": sorted_ok,
+            "adjusted_scores_exact_on_sample": adj_ok, "sample_queries": int(m),
+            "sample_checked_against": "oracle/icd_oracle.c over every rank's shard (host copy), merged by plain torch", "parity_check_s": round(check_s, 2),
             "fallback_queries_last_slice": int(stats.get("last_fallback", 0)),
             "index_build_s": round(t_build, 3),
             "roofline": {"bound": "mfma", "kernel": "coarse_flat_kernel", "achieved": achieved, "peak": PEAK_TFLOPS_F16,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS_F16, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS_F16, "traffic": traffic, "traffic_source": traffic_src,
                          "flops_per_launch": flops_gpu / launches, "launch_ms": dom_ms, "launches_averaged": int(prof.get("count", 0))},
         }
     index.close()
     return line
 
 
+def test_engine():
+    """CPU tests of the N-rank control flow (ICD_BENCH_DEVICE=cpu) name a Python file that provides `index_factory` and
+    `sharded_factory` (tests/bench_cpu_engine.py); the product path has no such hook: without it the HIP index is the
+    only engine and a box without a GPU fails loudly"""
+    path = os.environ.get("ICD_BENCH_TEST_ENGINE")
+    if not path or os.environ.get("ICD_BENCH_DEVICE") != "cpu":
+        return {}
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("icd_bench_test_engine", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return {"index_factory": mod.index_factory, "sharded_factory": mod.sharded_factory}
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as ONE child (python -m torch.distributed.run, one
+    rank per GPU) BEFORE anything in this process has touched the GPU, relay rank 0's JSON line, exit with the child's
+    status. The parent never initialises HIP (a process that has must not exec or fork GPU work)."""
+    import subprocess
+    import torch   # (importing torch and counting devices does not initialise the runtime)
+    one_device = os.environ.get("ICD_BENCH_ONE_DEVICE") == "1" or os.environ.get("ICD_BENCH_DEVICE") == "cpu"
+    have = torch.cuda.device_count()
+    if not one_device and have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), "--", os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (dmabuf IPC: RCCL between processes needs it on this driver)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for raw in p.stdout:
+        t = raw.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        elif t:
+            print(t, file=sys.stderr)   # anything else a rank printed
+    rc = p.wait()
+    if rc != 0 or line is None:
+        print(f"bench.py: the {args.gpus}-rank child exited with status {rc}" + ("" if line else " and printed no result line"), file=sys.stderr)
+        return rc if rc != 0 else 3
+    print(line, flush=True)
+    return 0
+
+
 def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--settle-ms", type=float, default=60.0,
                     help="untimed: keep the device busy with the step for this long before the warm-up steps (clock ramp of a fresh process)")
+    ap.add_argument("--repeats", type=int, default=5, help="replicated workload: repeat the K-step window this many times after the measurement (reported under extra.windows)")
     ap.add_argument("--workload", choices=["replicated", "rowshard"], default="replicated")
     ap.add_argument("--nq", type=int, default=10000)
     ap.add_argument("--n", type=int, default=37000)
@@ -413,15 +581,27 @@ def main(argv=None):
     ap.add_argument("--rowshard-steps", type=int, default=3, help="passes of the row-sharded workload (each ~0.2 s per GPU)")
     ap.add_argument("--no-rowshard", action="store_true", help="N > 1: skip the row-sharded leg of the default run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the real-size / clustered / exact-mode side workloads")
     args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    in_group = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus > 1 and not in_group:
+        sys.exit(spawn_ranks(args, argv))
+    if in_group and int(os.environ["WORLD_SIZE"]) != args.gpus and os.environ.get("RANK") == "0":
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks: reporting the latter", file=sys.stderr)
 
     ctx = Ctx()
+    if os.environ.get("ICD_BENCH_TEST_FAIL_RANK") == str(ctx.rank):   # test hook: a rank that dies must fail the whole run
+        raise RuntimeError(f"rank {ctx.rank}: forced failure (ICD_BENCH_TEST_FAIL_RANK)")
+    eng = test_engine()
     if args.workload == "rowshard":
-        line = run_rowshard(ctx, args)
+        line = run_rowshard(ctx, args, **eng)
     else:
-        line = run_replicated(ctx, args)
+        line = run_replicated(ctx, args, **({"index_factory": eng["index_factory"]} if eng else {}))
         if ctx.world > 1 and not args.no_rowshard:
-            rs = run_rowshard(ctx, args)
+            rs = run_rowshard(ctx, args, **eng)
             if line is not None:
                 line["rowshard"] = rs
     if ctx.rank == 0:

@@ -9,13 +9,20 @@ A store is a directory:
                     (services/milvus_service.py:174-186): code, preferred_zh, has_complication, main_code,
                     secondary_code, level, parent_code, category_path, semantic_text
 Rows are appended by `append()` (the reference's client.insert) and are durable once it returns. The manifest is
-the commit record: it is rewritten (atomically) AFTER the three data files were extended, and carries their committed
-lengths. A process that dies in between leaves surplus bytes behind the committed lengths; `_load()` and `append()`
-truncate them (`_repair()`), so later rows never shift against their metadata. Files SHORTER than the manifest says
-are corruption and raise.
+the commit record: it is rewritten (atomically) AFTER the three data files were extended AND fsynced, and carries their
+committed lengths. A process that dies in between leaves surplus bytes behind the committed lengths; `_load()` and
+`append()` truncate them (`_repair()`), so later rows never shift against their metadata. Files SHORTER than the
+manifest says are corruption and raise.
+
+Several processes may hold handles of one store (`build_database` next to the API): every load, repair and append runs
+under an exclusive flock on `<store>/.lock`, and `append()` first compares the manifest on disk with what this handle
+last saw - a handle that another process has appended behind RELOADS before it appends (it never truncates rows that
+were committed by someone else).
 """
 from __future__ import annotations
 
+import contextlib
+import fcntl
 import json
 import os
 import shutil
@@ -51,15 +58,39 @@ class CorpusStore:
     def exists(self) -> bool:
         return os.path.exists(self._file("manifest.json"))
 
+    @contextlib.contextmanager
+    def _locked(self):
+        """exclusive inter-process lock of the store directory (flock: released by the kernel if the holder dies)"""
+        os.makedirs(self._dir(), exist_ok=True)
+        fd = os.open(self._file(".lock"), os.O_CREAT | os.O_RDWR, 0o644)
+        try:
+            fcntl.flock(fd, fcntl.LOCK_EX)
+            yield
+        finally:
+            fcntl.flock(fd, fcntl.LOCK_UN)
+            os.close(fd)
+
+    def _fsync_dir(self):
+        fd = os.open(self._dir(), os.O_RDONLY)
+        try:
+            os.fsync(fd)
+        finally:
+            os.close(fd)
+
     # ---- open / create ----------------------------------------------------------------------------
     @classmethod
     def open(cls, path: str, collection: str, dim: int) -> "CorpusStore":
         st = cls(path, collection, dim)
         if st.exists():
-            st._load()
+            with st._locked():
+                st._load()
         return st
 
     def create(self):
+        with self._locked():
+            self._create()
+
+    def _create(self):
         os.makedirs(self._dir(), exist_ok=True)
         self.count = 0
         self._meta_bytes = 0
@@ -87,6 +118,16 @@ class CorpusStore:
             f.flush()
             os.fsync(f.fileno())
         os.replace(tmp, self._file("manifest.json"))
+        self._fsync_dir()   # the rename itself
+
+    def _disk_commit(self):
+        """(count, meta_bytes) of the manifest on disk, or None"""
+        try:
+            with open(self._file("manifest.json"), encoding="utf-8") as f:
+                man = json.load(f)
+            return int(man["count"]), (int(man["meta_bytes"]) if "meta_bytes" in man else None)
+        except FileNotFoundError:
+            return None
 
     def _repair(self):
         """Cut the data files back to the committed lengths (bytes past them belong to an append that never committed);
@@ -140,21 +181,31 @@ class CorpusStore:
     # ---- rows ---------------------------------------------------------------------------------------
     def append(self, rows: List[Dict[str, Any]], vectors: np.ndarray):
         vectors = np.ascontiguousarray(vectors, dtype=np.float32).reshape(len(rows), self.dim)
-        if not self.exists():
-            self.create()
-        self._repair()   # (an earlier append may have died before its manifest)
         meta = "".join(json.dumps({k: r.get(k) for k in PAYLOAD_FIELDS}, ensure_ascii=False) + "\n" for r in rows).encode("utf-8")
-        with open(self._file("corpus.f32"), "ab") as f:
-            vectors.tofile(f)
-        with open(self._file("levels.i32"), "ab") as f:
-            np.asarray([int(r.get("level", 1)) for r in rows], dtype=np.int32).tofile(f)
-        with open(self._file("meta.jsonl"), "ab") as f:
-            f.write(meta)
-        self._meta_bytes += len(meta)
-        self.records.extend(rows)
-        self._vectors.append(vectors)
-        self.count += len(rows)
-        self._write_manifest()
+        with self._locked():
+            disk = self._disk_commit()
+            if disk is None:
+                self._create()
+            elif disk != (self.count, self._meta_bytes):
+                self._load()     # another handle committed rows since this one looked: take them in, never cut them off
+            else:
+                self._repair()   # (an earlier append may have died before its manifest: surplus bytes of nobody's)
+
+            def extend(name, write):
+                with open(self._file(name), "ab") as f:
+                    write(f)
+                    f.flush()
+                    os.fsync(f.fileno())   # durable BEFORE the manifest that commits it
+
+            extend("corpus.f32", vectors.tofile)
+            extend("levels.i32", np.asarray([int(r.get("level", 1)) for r in rows], dtype=np.int32).tofile)
+            extend("meta.jsonl", lambda f: f.write(meta))
+            self._fsync_dir()
+            self._meta_bytes += len(meta)
+            self.records.extend(rows)
+            self._vectors.append(vectors)
+            self.count += len(rows)
+            self._write_manifest()
 
     def matrix(self) -> np.ndarray:
         if self._vectors:

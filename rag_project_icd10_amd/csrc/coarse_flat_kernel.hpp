@@ -263,7 +263,8 @@ __device__ __forceinline__ void compact_all_parallel(char *smem, Sel2 &st, uint3
 //   256 no s_barrier   512 no wait for the LDS-DMA pieces   4096 thresholds at +inf (nothing passes)
 //   8192 no select at all   16384 no LDS-DMA inside the tile loop   65536 (with 32768) no lane swaps
 // Variants that were measured and dropped (per-wave DMA slots, branch-free select, 3/6-stage rings, select deferred into
-// the next tile's MFMA gaps, 16x16x32 MFMA shape) live in experiments/r02_flat_variants/ with their logs.
+// the next tile's MFMA gaps, the first two selects built for the 16x16x32 shape before the lane swap let it keep this
+// one - bit 32768 IS that shape and is part of the product) live in experiments/r02_flat_variants/ with their logs.
 constexpr int CF_PRODUCT_VAR = 1 + 2 + 8 + 128 + 16 + 2048 + 32768;   // measured: profiles/r02_ab_flat_variants.log, profiles/r02_coarse_variants_rg_w8_all.log (+ 16 + 2048: -2 %; + 32768: -2 % at 37 000 rows, -4 % on 1.25 M-row shards)
 __host__ __device__ constexpr int cf_ring_stages(int) { return CO_S; }
 __host__ __device__ constexpr int cf_lds_bytes(int var) { return cf_ring_stages(var) * CO_STAGE_BYTES + CO_BM * CO_CAP * 8 + 4 * 256; }

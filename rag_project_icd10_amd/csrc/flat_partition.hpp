@@ -4,7 +4,7 @@
 // Units are numbered u = mtile * ctiles + tile; work-group w takes [w U, (w+1) U). Its run inside one query tile is cut
 // into lists of at most `list_tiles` tiles; ordinals count the lists of a query tile in row order.
 #pragma once
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define ICD_HD __host__ __device__
 #else
 #define ICD_HD

@@ -3,7 +3,10 @@
 `EMBEDDING_MODEL_NAME`, `MILVUS_DB_PATH`, ... up from the project's `.env` (env.example). python-dotenv is not
 installed in this deployment; this is the subset of its behaviour the reference relies on:
 
-  * the file is `.env` in the current directory or the nearest parent directory that has one;
+  * the file is the nearest `.env` walking UP from the directory of the calling module (python-dotenv's
+    `find_dotenv(usecwd=False)`: `python /path/tools/build_database.py` finds the project's `.env` from any cwd) - here
+    from this package's directory, so the project that contains the package; only when there is none, the nearest one
+    walking up from the current directory (this deployment's addition);
   * `KEY=VALUE` lines, optional `export ` prefix, blank lines and `#` comments ignored, an unquoted value ends at an
     inline ` #`, matching single or double quotes are stripped (double-quoted values honour \\n and \\" escapes);
   * variables already present in the process environment are NOT overridden (load_dotenv's default).
@@ -14,8 +17,8 @@ import os
 from typing import Dict, Optional
 
 
-def find_dotenv(start: Optional[str] = None, filename: str = ".env") -> str:
-    d = os.path.abspath(start or os.getcwd())
+def _walk_up(d: str, filename: str) -> str:
+    d = os.path.abspath(d)
     while True:
         p = os.path.join(d, filename)
         if os.path.isfile(p):
@@ -24,6 +27,12 @@ def find_dotenv(start: Optional[str] = None, filename: str = ".env") -> str:
         if parent == d:
             return ""
         d = parent
+
+
+def find_dotenv(start: Optional[str] = None, filename: str = ".env") -> str:
+    if start:
+        return _walk_up(start, filename)
+    return _walk_up(os.path.dirname(os.path.abspath(__file__)), filename) or _walk_up(os.getcwd(), filename)
 
 
 def parse_dotenv(text: str) -> Dict[str, str]:

@@ -14,8 +14,10 @@ later one is a B- token, group score = mean of the token scores, group word = th
 Pinned against the pipeline itself on a seeded model (tests/golden/make_ner_golden.py, tests/test_ner_cpu.py).
 Differences by design: `extract_medical_entities_batch` runs ONE padded forward on the GPU for many strings (the
 reference's /query issues 1 + 3 D single-string forwards per request); weights are resolved locally only - if the
-checkpoint is not available the service falls back to the rules exactly like the reference does on a failed load,
-unless synthetic weights are explicitly allowed (ICD_NER_ALLOW_SYNTHETIC=1: a seeded random-init BERT-base token
+checkpoint is not available the service switches to the rules. DELIBERATE DEVIATION: the reference's failed load sets
+`use_model = False` WITHOUT building the rule patterns (:93-101), so its rules path then raises AttributeError on every
+call and /query degrades each diagnosis to "no entities"; here a failed load also calls `_init_fallback_patterns()`, so
+the rules really run (an offline deployment gets entities instead of none) - unless synthetic weights are explicitly allowed (ICD_NER_ALLOW_SYNTHETIC=1: a seeded random-init BERT-base token
 classifier of the same shape, for throughput measurements; its entities mean nothing).
 """
 from __future__ import annotations

@@ -55,8 +55,20 @@ class MultiDiagnosisService:
         except Exception as exc:
             logger.error("batch search failed: %s", exc)
             hit_lists = [[] for _ in diagnoses]
-        entities = self.ner_service.extract_medical_entities_batch(diagnoses, filter_drugs=True) if self.ner_service \
-            else [{} for _ in diagnoses]
+        entities = [{} for _ in diagnoses]
+        if self.ner_service:
+            # (the reference extracts inside _match_single_diagnosis_enhanced's try, services/multi_diagnosis_service.py:147-158:
+            #  a failing NER costs that diagnosis its entities, never the request - one batch here, so a failure of the batch
+            #  retries string by string and only the strings that still fail go without entities)
+            try:
+                entities = self.ner_service.extract_medical_entities_batch(diagnoses, filter_drugs=True)
+            except Exception as exc:
+                logger.error("batch NER failed (%s): one string at a time", exc)
+                for i, d in enumerate(diagnoses):
+                    try:
+                        entities[i] = self.ner_service.extract_medical_entities(d, filter_drugs=True)
+                    except Exception as exc1:
+                        logger.error("NER failed for %r: %s", d, exc1)
         matches = [self._match_from_hits(d, hits, top_k, ents) for d, hits, ents in zip(diagnoses, hit_lists, entities)]
         return {"original_text": text, "extracted_diagnoses": diagnoses, "matches": matches,
                 "total_matches": sum(len(m.candidates) for m in matches), "processing_mode": mode,

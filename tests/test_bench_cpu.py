@@ -13,64 +13,6 @@ import torch.multiprocessing as mp
 from conftest import ROOT
 
 
-class _OracleIndex:
-    """stand-in for _native.IcdIndex with the same methods, computed by oracle/ on CPU tensors (test infrastructure)"""
-
-    def __init__(self, corpus, levels, device=0, max_nq=0, max_k=10, id_base=0):
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle as orc
-        self.orc = orc
-        self.corpus = np.ascontiguousarray(corpus.numpy() if hasattr(corpus, "numpy") else corpus, np.float32)
-        self.levels = np.ascontiguousarray(levels.numpy() if hasattr(levels, "numpy") else levels, np.int32)
-        self.id_base = int(id_base)
-        self.prof = False
-
-    def search(self, q, k, mode=0):
-        s, i = self.orc.flat_ip_topk(self.corpus, q.numpy(), k, id_base=self.id_base)
-        return torch.from_numpy(s), torch.from_numpy(i)
-
-    def lookup_levels(self, ids):
-        i = ids.numpy() - self.id_base
-        return torch.from_numpy(np.where(ids.numpy() >= 0, self.levels[np.clip(i, 0, len(self.levels) - 1)], 0).astype(np.int32))
-
-    def search_reweighted(self, q, k, mode=0):
-        s, i = self.orc.flat_ip_topk(self.corpus, q.numpy(), k, id_base=self.id_base)
-        return tuple(torch.from_numpy(x) for x in self.orc.reweight(s, i, self.levels, id_base=self.id_base))
-
-    def set_profiling(self, on):
-        self.prof = on
-
-    def profile_summary(self):
-        return {"ms_prep": 0.0, "ms_coarse": 1.0, "ms_finalize": 0.0, "ms_exact": 0.0, "ms_exact_finalize": 0.0, "ms_total": 1.0, "count": 1}
-
-    def stats(self):
-        return {"last_mode": 0, "last_fallback": 0, "last_chunks": 1}
-
-    def close(self):
-        pass
-
-
-def _merge_cpu(s, i, l, k):
-    """merge_fn of ShardedSearch on CPU tensors: global top-k (score desc, id asc) + level reweight + stable re-sort"""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle as orc
-    ms, mi = orc.merge(s.numpy(), i.numpy(), k)
-    lv_of = {int(a): int(b) for a, b in zip(i.numpy().ravel(), l.numpy().ravel()) if a >= 0}
-    nq = ms.shape[0]
-    adj = np.empty((nq, k), np.float64); raw = np.empty((nq, k), np.float32)
-    ids = np.empty((nq, k), np.int64); lv = np.empty((nq, k), np.int32)
-    for q in range(nq):
-        hl = np.asarray([lv_of.get(int(x), 0) for x in mi[q]], np.int32)
-        a, r, d, l2 = (np.empty(k, np.float64), np.empty(k, np.float32), np.empty(k, np.int64), np.empty(k, np.int32))
-        import ctypes
-        vp = ctypes.c_void_p
-        msq, miq = np.ascontiguousarray(ms[q]), np.ascontiguousarray(mi[q])
-        orc.lib().icd_oracle_reweight_one(vp(msq.ctypes.data), vp(miq.ctypes.data), vp(hl.ctypes.data), ctypes.c_int(k),
-                                          vp(a.ctypes.data), vp(r.ctypes.data), vp(d.ctypes.data), vp(l2.ctypes.data))
-        adj[q], raw[q], ids[q], lv[q] = a, r, d, l2
-    return tuple(torch.from_numpy(x) for x in (adj, raw, ids, lv))
-
-
 def _worker(rank, world, port, q):
     try:
         _worker_body(rank, world, port, q)
@@ -82,26 +24,17 @@ def _worker(rank, world, port, q):
 
 def _worker_body(rank, world, port, q):
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
                        "MASTER_PORT": str(port), "ICD_BENCH_BACKEND": "gloo", "ICD_BENCH_DEVICE": "cpu"})
     import bench
-    from rag_project_icd10_amd.sharded import ROW_SHARD, ShardedSearch
+    import bench_cpu_engine as eng
     ctx = bench.Ctx()
     assert ctx.world == world and ctx.dist.get_world_size() == world
-    args = argparse.Namespace(steps=2, warmup=1, settle_ms=0.0, nq=40, n=900, k=5, mode="auto", rows_per_gpu=700, rowshard_queries=50,
-                              rowshard_slice=32, rowshard_steps=2, no_cpu_baseline=True)
-
-    def index_factory(corpus, levels, device, max_nq, max_k, id_base=0):
-        return _OracleIndex(corpus, levels, device, max_nq, max_k, id_base)
-
-    def sharded_factory(index):
-        def search_fn(qs, k):
-            s, i = index.search(qs, k)
-            return s, i, index.lookup_levels(i)
-        return ShardedSearch(ROW_SHARD, search_fn=search_fn, merge_fn=_merge_cpu)
-
-    rs = bench.run_rowshard(ctx, args, index_factory=index_factory, sharded_factory=sharded_factory)
-    rp = bench.run_replicated(ctx, args, index_factory=index_factory)
+    args = argparse.Namespace(steps=2, warmup=1, settle_ms=0.0, repeats=1, nq=40, n=900, k=5, mode="auto", rows_per_gpu=700, rowshard_queries=50,
+                              rowshard_slice=32, rowshard_steps=2, no_cpu_baseline=True, no_extras=True)
+    rs = bench.run_rowshard(ctx, args, index_factory=eng.index_factory, sharded_factory=eng.sharded_factory)
+    rp = bench.run_replicated(ctx, args, index_factory=eng.index_factory)
     q.put((rank, json.dumps(rs) if rs else None, json.dumps(rp) if rp else None))
     ctx.dist.barrier()
     ctx.dist.destroy_process_group()
@@ -133,3 +66,52 @@ def test_bench_two_ranks_on_cpu():
         for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                     "vs_baseline", "dtype", "data", "config", "roofline"):
             assert key in line, key
+
+
+# ---- `python bench.py --gpus N` as the driver runs it: the parent starts the ranks itself -------------------------------
+SMALL = ["--steps", "2", "--warmup", "1", "--settle-ms", "0", "--repeats", "1", "--nq", "40", "--n", "900", "--k", "5",
+         "--rows-per-gpu", "700", "--rowshard-queries", "50", "--rowshard-slice", "32", "--rowshard-steps", "2", "--no-cpu-baseline"]
+
+
+def _run_bench(extra_args, extra_env=None, timeout=420):
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update({"ICD_BENCH_BACKEND": "gloo", "ICD_BENCH_DEVICE": "cpu",
+                "ICD_BENCH_TEST_ENGINE": os.path.join(ROOT, "tests", "bench_cpu_engine.py")})
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra_args + SMALL, env=env, capture_output=True,
+                          text=True, timeout=timeout, cwd=ROOT)
+
+
+def test_bench_gpus_2_starts_two_ranks_itself():
+    p = _run_bench(["--gpus", "2"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout     # ONE JSON line on stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["collective_ranks"] == 2 and "configs[3]" in line["config"]["workload"]
+    assert line["ids_exact"] and line["adjusted_scores_exact"]
+    rs = line["rowshard"]
+    assert rs["n_gpus"] == 2 and rs["config"]["collective_ranks"] == 2 and rs["config"]["corpus_rows_total"] == 1400
+    assert rs["ids_exact_on_sample"] and rs["raw_scores_exact_on_sample"] and rs["adjusted_scores_exact_on_sample"]
+    assert "oracle" in rs["sample_checked_against"]
+
+
+def test_bench_gpus_1_is_a_single_process_line_with_the_extras():
+    p = _run_bench(["--gpus", "1"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    assert line["n_gpus"] == 1 and line["config"]["collective_ranks"] == 1 and "rowshard" not in line
+    assert "configs[1]" in line["config"]["workload"]
+    ex = line["extra"]
+    assert ex["windows"]["min"] <= ex["windows"]["median"] <= ex["windows"]["max"]
+    for key, rows in (("real_size", 40474), ("clustered", 900), ("exact_mode", 900)):
+        assert ex[key]["corpus_rows"] == rows and ex[key]["ids_exact"] and ex[key]["ms_per_step"] > 0 and "fallback_queries" in ex[key]
+
+
+def test_bench_child_failure_fails_the_parent():
+    p = _run_bench(["--gpus", "2", "--no-rowshard"], {"ICD_BENCH_TEST_FAIL_RANK": "1"})
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.strip().startswith("{")]   # no result line from a failed run

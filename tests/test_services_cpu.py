@@ -224,6 +224,22 @@ def test_corpus_store_survives_a_torn_append(tmp_path):
         CorpusStore.open(str(tmp_path), "icd10", 4)
 
 
+def test_corpus_store_stale_handle_never_truncates_committed_rows(tmp_path):
+    """two handles of one store (build_database next to the API): an append through the handle that has not seen the
+    other's rows takes them in first - it must not cut them off as "surplus bytes" """
+    rows = [{"code": f"C{i}", "preferred_zh": "丙", "level": 1 + i % 3} for i in range(6)]
+    a = CorpusStore.open(str(tmp_path), "icd10", 4)
+    a.append(rows[:2], np.arange(8, dtype=np.float32).reshape(2, 4))
+    b = CorpusStore.open(str(tmp_path), "icd10", 4)          # second handle, sees 2 rows
+    a.append(rows[2:4], np.arange(8, 16, dtype=np.float32).reshape(2, 4))   # committed behind b's back
+    b.append(rows[4:], np.arange(16, 24, dtype=np.float32).reshape(2, 4))   # stale handle: reloads, then appends
+    assert b.count == 6 and [r["code"] for r in b.records] == [f"C{i}" for i in range(6)]
+    c = CorpusStore.open(str(tmp_path), "icd10", 4)
+    assert c.count == 6 and np.array_equal(c.matrix(), np.arange(24, dtype=np.float32).reshape(6, 4))
+    assert np.array_equal(b.matrix(), c.matrix()) and c.levels().tolist() == [1, 2, 3, 1, 2, 3]
+    assert os.path.exists(os.path.join(str(tmp_path), "icd10", ".lock"))
+
+
 def test_large_batches_ask_for_more_candidate_lists_after_a_mass_fallback():
     """MilvusService.search_batch: the fallback count of the previous LARGE batch decides whether large batches get ~20
     candidate lists per query (icd_index_set_chunks) - small batches never do, a rebuilt index starts over."""
