@@ -315,7 +315,9 @@ def run_replicated(ctx, args, index_factory=hip_index_factory):
     prof = {}
 
     def before():
-        index.set_profiling(True)
+        # hipEvents around the kernels of every 5th step of the timed region (an event between two kernels keeps the
+        # second from starting under the first one's tail: ~4 % on this step if every step carried them)
+        index.set_profiling(True, every=args.profile_every)
         index.profile_summary()  # reset the event window
 
     def after():   # the kernel times of the measured window only (the repeats that follow are not averaged in)
@@ -357,7 +359,8 @@ def run_replicated(ctx, args, index_factory=hip_index_factory):
                          "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_unit": "bytes per launch (rocprofv3 PMC passes of this kernel, 2 x FETCH_SIZE + WRITE_SIZE); a citation "
                                          "of the committed profile of this workload, not measured in this run",
-                         "flops_per_launch": flops, "launch_ms": dom_ms, "launches_averaged": prof["count"]},
+                         "flops_per_launch": flops, "launch_ms": dom_ms, "launches_averaged": prof["count"],
+                         "launches_sampled": f"every {args.profile_every}th step of the timed region carries hipEvents"},
             "extra": {"windows": {"what": f"the {args.steps}-step window repeated {1 + len(info['repeat_s'])} times back to back (the first is `value`), ms per step",
                                   "min": per_step[0], "median": per_step[len(per_step) // 2], "max": per_step[-1],
                                   "first_window_of_the_process": (info["first_window_s"] / args.steps * 1e3) if info["first_window_s"] else None}},
@@ -569,6 +572,7 @@ def main(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--settle-ms", type=float, default=60.0,
                     help="untimed: keep the device busy with the step for this long before the warm-up steps (clock ramp of a fresh process)")
+    ap.add_argument("--profile-every", type=int, default=5, help="hipEvents around the kernels of every N-th step of the timed region")
     ap.add_argument("--repeats", type=int, default=5, help="replicated workload: repeat the K-step window this many times after the measurement (reported under extra.windows)")
     ap.add_argument("--workload", choices=["replicated", "rowshard"], default="replicated")
     ap.add_argument("--nq", type=int, default=10000)

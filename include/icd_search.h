@@ -20,6 +20,9 @@
  *   icd_merge_topk              <- no counterpart (the reference is single-process); merges the
  *                                  per-shard partial top-k lists of a row-sharded corpus after the
  *                                  RCCL all-gather.
+ *   icd_group_*                 <- no counterpart: one process per GPU, an RCCL communicator owned by the group; the
+ *                                  row-sharded search (local top-k -> ncclAllGather -> merge + reweight) and the
+ *                                  query-sharded one (SURVEY.md section 8b "suggested C ABI", 8e) in one call, on one stream.
  *
  * Conventions
  *   - All matrices are dense row-major (exactly numpy's C order): corpus [n][dim], queries [nq][dim],
@@ -45,7 +48,7 @@
 extern "C" {
 #endif
 
-#define ICD_ABI_VERSION 1
+#define ICD_ABI_VERSION 2   /* 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
 #define ICD_MAX_K 128
 
 typedef struct icd_index icd_index;
@@ -82,6 +85,10 @@ typedef struct icd_stats {
     int64_t last_fallback;      /* queries that took the exact fallback in AUTO mode */
     int32_t last_chunks;        /* candidate lists per query (P) of the last call's scoring pass */
     int32_t last_mode;
+    int64_t last_second_pass;   /* queries the first coarse pass could not certify and the second one took (AUTO mode) */
+    int32_t last_second_pass_lists; /* candidate lists per query of that second pass (0: it was not part of the call) */
+    int32_t wide_mode;          /* 1: large batches are planned with the second pass's list count from the start (the
+                                   previous large batch needed the second pass for most of its queries) */
 } icd_stats;
 
 /* per-kernel device time of the most recent search, measured with hipEvents on the search stream.
@@ -142,6 +149,31 @@ int icd_merge_topk(int32_t device, const float *scores, const int64_t *ids, cons
                    int32_t G, int64_t nq, int32_t k,
                    double *out_adj, float *out_raw, int64_t *out_ids, int32_t *out_levels, void *stream);
 
+/*
+ * Multi-GPU search, one process per GPU. Every rank creates its icd_index first (ROW_SHARD: over its rows, with id_base =
+ * index of its first row in the whole corpus; QUERY_SHARD: over the whole corpus), then the group:
+ *     rank 0:   icd_group_unique_id(id)   -> hand the ICD_GROUP_ID_BYTES bytes to every rank (file, socket, MPI, ...)
+ *     all:      icd_group_create(index, id, rank, world, mode, max_nq, max_k, &group)     (collective: ncclCommInitRank)
+ *     all:      icd_group_search(group, queries, nq, k, gather, out_adj, out_raw, out_ids, out_levels, stream)
+ * `queries` is the FULL batch [nq][dim] on every rank (device pointer); outputs are device pointers [nq][k] in the order
+ * icd_index_search_reweighted gives. ROW_SHARD: identical results on every rank (local raw top-k with global ids and
+ * levels -> one grouped ncclAllGather of 16 bytes per hit -> icd_merge_topk). QUERY_SHARD: rank r searches rows
+ * [lo_r, hi_r) of the batch (contiguous split, the first nq % world ranks one row more); gather = 1: one grouped
+ * ncclAllGather gives every rank all nq rows; gather = 0: no collective at all, rows 0 .. hi_r - lo_r of the outputs hold
+ * this rank's slice. Everything is enqueued on `stream`; nothing synchronises. world = 1 needs no id and no RCCL (given
+ * an id all the same, a one-rank communicator is created and the collective path runs end to end: tests).
+ * librccl.so.1 is opened (dlopen) by the first call that needs it.
+ */
+#define ICD_GROUP_ID_BYTES 128
+typedef struct icd_group icd_group;
+typedef enum icd_group_mode { ICD_GROUP_ROW_SHARD = 0, ICD_GROUP_QUERY_SHARD = 1 } icd_group_mode;
+int icd_group_unique_id(uint8_t *out_id /* [ICD_GROUP_ID_BYTES] */);
+int icd_group_create(icd_index *local, const uint8_t *id, int32_t rank, int32_t world, int32_t mode, int32_t max_nq,
+                     int32_t max_k, icd_group **out);
+int icd_group_search(icd_group *group, const float *queries, int64_t nq, int32_t k, int32_t gather, double *out_adj,
+                     float *out_raw, int64_t *out_ids, int32_t *out_levels, void *stream);
+int icd_group_destroy(icd_group *group);   /* (the index stays with the caller) */
+
 /* Level of each hit id (device pointers, [count]); ids < 0 give level 0. Used by the row-sharded
  * path to attach levels to the raw hits before the all-gather. */
 int icd_index_lookup_levels(icd_index *idx, const int64_t *ids, int64_t count, int32_t *out_levels,
@@ -191,12 +223,18 @@ int icd_score_stats(int32_t device, const double *scores, const int32_t *order, 
 int icd_cosine_rows(int32_t device, const float *x, const float *y, int64_t y_stride, int64_t nq, int32_t dim,
                     double *out, void *stream);
 
-/* (waits for the device: last_fallback is read from the device when asked for, not copied back by every search) */
+/* (last_fallback: every search copies its counters to pinned host memory behind itself, on its stream; this call waits
+ *  for the last search of this handle - an event on that stream - and for nothing else on the device) */
 int icd_index_stats(icd_index *idx, icd_stats *out);
 
 /* Tuning knob / test hook (0 = automatic): aim for about `chunks` candidate lists per query in the coarse pass
  * (the automatic choice gives every CU the same number of 128 x 128 tiles). */
 int icd_index_set_chunks(icd_index *idx, int32_t chunks);
+
+/* Test / A-B switch (default 1): 0 turns the second coarse pass (and the adaptive list count that follows from its counters)
+ * off - queries the first pass cannot certify then go straight to the exact re-search, as before round 3; 2 keeps the
+ * second pass but never switches to the wide partition (every large batch runs narrow plan + second pass). */
+int icd_index_set_second_pass(icd_index *idx, int32_t enabled);
 
 /* Test switch, process-wide, read by icd_index_create: 0 keeps the fp16 corpus copy in row order instead of the
  * golden-ratio permutation (results are identical; only the share of certified queries changes). Default 1. */
@@ -206,6 +244,8 @@ int icd_debug_set_permute(int32_t enabled);
  * [work-group][wave][8] = {LDS-DMA wait, barrier, stage body, fused select, tiles, ...}. */
 int icd_index_debug_counters(icd_index *idx, unsigned long long *out, int32_t count);
 
+/* enabled: 0 off; 1 events around every kernel of every search; N > 1 of every N-th search (an event between two kernels
+ * keeps the second from starting under the first one's tail: a timed region samples instead of paying that on every step) */
 int icd_index_set_profiling(icd_index *idx, int32_t enabled);
 /* Synchronises the events of the most recent search and fills `out`. */
 int icd_index_last_profile(icd_index *idx, icd_profile *out);

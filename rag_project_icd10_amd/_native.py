@@ -20,6 +20,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libicdsearch.so")
 MODE_AUTO = 0   # fp16-MFMA coarse pass + certified exact rescoring (+ exact fallback); same results as EXACT
 MODE_EXACT = 1  # fp32-MFMA kernel only
 MAX_K = 128
+ABI_VERSION = 2   # include/icd_search.h ICD_ABI_VERSION: a stale libicdsearch.so is refused with a clear message
 
 EXPORTED_SYMBOLS = (
     "icd_abi_version", "icd_last_error", "icd_device_count", "icd_index_create", "icd_index_destroy",
@@ -29,7 +30,12 @@ EXPORTED_SYMBOLS = (
     "icd_hier_rescore",
     "icd_score_stats",
     "icd_cosine_rows",
+    "icd_index_set_second_pass",
+    "icd_group_unique_id", "icd_group_create", "icd_group_search", "icd_group_destroy",
 )
+GROUP_ROW_SHARD = 0
+GROUP_QUERY_SHARD = 1
+GROUP_ID_BYTES = 128
 
 
 class IcdError(RuntimeError):
@@ -45,7 +51,8 @@ class _Stats(C.Structure):
                 ("bytes_corpus_f32", C.c_int64), ("bytes_corpus_f16", C.c_int64), ("bytes_workspace", C.c_int64),
                 ("max_nq", C.c_int32), ("max_k", C.c_int32), ("fast_path", C.c_int32), ("rmax", C.c_float),
                 ("last_nq", C.c_int64), ("last_fallback", C.c_int64), ("last_chunks", C.c_int32),
-                ("last_mode", C.c_int32)]
+                ("last_mode", C.c_int32), ("last_second_pass", C.c_int64), ("last_second_pass_lists", C.c_int32),
+                ("wide_mode", C.c_int32)]
 
 
 class _Profile(C.Structure):
@@ -79,6 +86,11 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.icd_index_lookup_levels.argtypes = [vp, vp, i64, vp, vp]
     lib.icd_index_stats.argtypes = [vp, C.POINTER(_Stats)]
     lib.icd_index_set_chunks.argtypes = [vp, i32]
+    lib.icd_index_set_second_pass.argtypes = [vp, i32]
+    lib.icd_group_unique_id.argtypes = [vp]
+    lib.icd_group_create.argtypes = [vp, vp, i32, i32, i32, i32, i32, C.POINTER(vp)]
+    lib.icd_group_search.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, vp, vp]
+    lib.icd_group_destroy.argtypes = [vp]
     lib.icd_debug_set_permute.argtypes = [i32]
     lib.icd_hier_rescore.argtypes = [i32, vp, vp, i64, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.icd_score_stats.argtypes = [i32, vp, vp, i64, i32, i32, vp, vp]
@@ -87,6 +99,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.icd_index_set_profiling.argtypes = [vp, i32]
     lib.icd_index_last_profile.argtypes = [vp, C.POINTER(_Profile)]
     lib.icd_index_profile_summary.argtypes = [vp, C.POINTER(_Profile), C.POINTER(C.c_int32)]
+    have = lib.icd_abi_version()
+    if have != ABI_VERSION:
+        raise ImportError(f"{p} has ABI version {have}, this package needs {ABI_VERSION}: rebuild it (make -C rag_project_icd10_amd/csrc)")
     for name in EXPORTED_SYMBOLS:
         getattr(lib, name)  # AttributeError if the build is stale
     if path is None:
@@ -294,13 +309,87 @@ class IcdIndex:
     def set_chunks(self, chunks: int):
         _check(self._lib, self._lib.icd_index_set_chunks(self._h, int(chunks)))
 
-    def set_profiling(self, enabled: bool):
-        _check(self._lib, self._lib.icd_index_set_profiling(self._h, 1 if enabled else 0))
+    def set_second_pass(self, enabled, adaptive: bool = True):
+        """test / A-B switch: the second coarse pass over uncertified queries (default on), and the adaptive list count of
+        large batches that follows from its counters"""
+        _check(self._lib, self._lib.icd_index_set_second_pass(self._h, 0 if not enabled else (1 if adaptive else 2)))
+
+    def set_profiling(self, enabled, every: int = 1):
+        """hipEvents around the kernels of every `every`-th search (read back by profile_summary / last_profile)"""
+        _check(self._lib, self._lib.icd_index_set_profiling(self._h, max(1, int(every)) if enabled else 0))
 
     def last_profile(self) -> dict:
         p = _Profile()
         _check(self._lib, self._lib.icd_index_last_profile(self._h, C.byref(p)))
         return {f: float(getattr(p, f)) for f, _ in _Profile._fields_}
+
+
+def group_unique_id() -> bytes:
+    """rank 0: the RCCL unique id every rank passes to IcdGroup (icd_group_unique_id); hand the bytes over any side channel"""
+    lib = load_library()
+    buf = (C.c_uint8 * GROUP_ID_BYTES)()
+    _check(lib, lib.icd_group_unique_id(C.cast(buf, C.c_void_p)))
+    return bytes(buf)
+
+
+class IcdGroup:
+    """Multi-GPU search behind the C ABI (icd_group_*): one process per GPU, this rank's IcdIndex (a row shard created with
+    id_base = its first global row, or a replica), an RCCL communicator owned by the group. `unique_id`: group_unique_id()
+    of rank 0 (None for a single rank). search() takes the FULL query batch as a CUDA tensor on every rank."""
+
+    def __init__(self, index: "IcdIndex", mode: int, rank: int = 0, world: int = 1, unique_id: Optional[bytes] = None,
+                 max_nq: Optional[int] = None, max_k: Optional[int] = None):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.index, self.mode, self.rank, self.world = index, int(mode), int(rank), int(world)
+        self.max_nq = int(max_nq or index.max_nq)
+        self.max_k = int(max_k or min(index.max_k, 1024 // max(1, world) if mode == GROUP_ROW_SHARD else index.max_k))
+        idbuf = None
+        if world > 1 and unique_id is None:
+            raise ValueError(f"a group of {world} ranks needs rank 0's {GROUP_ID_BYTES}-byte unique id")
+        if unique_id is not None:   # (world = 1 with an id: a one-rank communicator, the collective path end to end)
+            if len(unique_id) != GROUP_ID_BYTES:
+                raise ValueError(f"unique id must be {GROUP_ID_BYTES} bytes")
+            idbuf = (C.c_uint8 * GROUP_ID_BYTES).from_buffer_copy(unique_id)
+        _check(self._lib, self._lib.icd_group_create(index._h, C.cast(idbuf, C.c_void_p) if idbuf is not None else None, self.rank,
+                                                      self.world, self.mode, self.max_nq, self.max_k, C.byref(self._h)))
+
+    def search(self, queries, k: int = 10, gather: bool = True):
+        """-> (adj f64, raw f32, ids i64, levels i32), each [nq, k] CUDA tensors (query-sharded with gather=False: only the
+        first hi - lo rows, this rank's slice, are written and returned)"""
+        import torch
+        q, on_dev = self.index._prep_queries(queries)
+        if not on_dev:
+            q = torch.from_numpy(q).to(torch.device("cuda", self.index.device))
+        nq = int(q.shape[0])
+        dev = q.device
+        outs_n = nq
+        if self.mode == GROUP_QUERY_SHARD and not gather:
+            base, rem = divmod(nq, self.world)
+            outs_n = base + (1 if self.rank < rem else 0)
+        adj = torch.empty((max(nq, 1), k), dtype=torch.float64, device=dev)
+        raw = torch.empty((max(nq, 1), k), dtype=torch.float32, device=dev)
+        ids = torch.empty((max(nq, 1), k), dtype=torch.int64, device=dev)
+        lv = torch.empty((max(nq, 1), k), dtype=torch.int32, device=dev)
+        for s0 in range(0, max(nq, 1), self.max_nq if self.mode == GROUP_ROW_SHARD else max(nq, 1)):
+            qs = q[s0:s0 + self.max_nq] if self.mode == GROUP_ROW_SHARD else q
+            m = int(qs.shape[0])
+            if m:
+                _check(self._lib, self._lib.icd_group_search(self._h, qs.data_ptr(), m, k, 1 if gather else 0, adj[s0:].data_ptr(),
+                                                              raw[s0:].data_ptr(), ids[s0:].data_ptr(), lv[s0:].data_ptr(),
+                                                              _current_stream_ptr(self.index.device)))
+        return adj[:outs_n], raw[:outs_n], ids[:outs_n], lv[:outs_n]
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.icd_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _profile_summary(self) -> dict:

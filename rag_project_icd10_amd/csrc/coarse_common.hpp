@@ -75,7 +75,8 @@ struct ConvertArgs {
     unsigned int *amax_bits; // nullable: atomicMax of max |x| bits over all rows (mode 2)
     unsigned int *any_bad;   // nullable: set to 1 if any row is bad
     unsigned int *zero_u32;  // nullable [rows_pad]: cleared (the coarse pass's shared per-query thresholds)
-    int *zero_i32;           // nullable: two words cleared by the launch (the fallback counters of the search it starts)
+    unsigned int *zero_u32b; // nullable [rows_pad]: cleared (the same of the second coarse pass)
+    int *zero_i32;           // nullable: four words cleared by the launch (the fallback counters of the search it starts)
     long long perm_mul;      // with perm_mod > 0: dst row p holds src row (p * perm_mul) mod perm_mod (an affine permutation)
     int perm_mod;
 };
@@ -91,9 +92,10 @@ __host__ __device__ inline int scale_exp_for(float m) {
 __global__ __launch_bounds__(256) void convert_rows_kernel(ConvertArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
-    if (a.zero_i32 && blockIdx.x == 0 && threadIdx.x == 0) { a.zero_i32[0] = 0; a.zero_i32[1] = 0; }
+    if (a.zero_i32 && blockIdx.x == 0 && threadIdx.x < 4) a.zero_i32[threadIdx.x] = 0;
     if (row >= a.rows_pad) return;
     if (a.zero_u32 && lane == 0) a.zero_u32[row] = 0u;
+    if (a.zero_u32b && lane == 0) a.zero_u32b[row] = 0u;
     _Float16 *d = a.dst + (size_t)row * a.dim;
     if (row >= a.rows) {
         if (a.mode != 2)

@@ -36,6 +36,11 @@ struct CoarseFlatArgs {
     int *part_rows;
     float *bounds;           // [nq][P]
     unsigned int *shared_thr; // [nq_pad] order_f32 keys, cleared before the launch: max over a query's lists of their thresholds
+    // second pass over the queries the first pass could not certify (icd_search.hip, "pass 2"): the query slots are the
+    // entries of a device-side list whose length is only known on the device
+    const int *nq_ptr;       // nullable: number of active query slots = min(*nq_ptr, nq); total_units follows from it
+    const int *qlist;        // nullable: query slot s reads row qlist[s] of q16 (lists, bounds, shared_thr are indexed by slot)
+    int nwg_virtual;         // logical work-groups; a PERSIST launch covers them with fewer blocks (block b takes b, b + grid, ...)
     unsigned long long *dbg;  // diagnostic builds only (VAR & 1024): [block][wave][8] cycle sums
 };
 
@@ -272,7 +277,10 @@ __host__ __device__ constexpr int cf_lds_bytes(int var) { return cf_ring_stages(
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); \
     __builtin_amdgcn_sched_barrier(0); } while (0)
 
-template <int D, int VAR = CF_PRODUCT_VAR, int KP = CO_KP>
+// PERSIST: the grid is smaller than the logical work-group count (one block per CU) and every block loops over its share -
+// the form of the second pass, whose work is sized on the device (most launches find nothing to do and must cost nothing:
+// 256 blocks that read one counter and leave). The first pass launches one block per logical work-group.
+template <int D, int VAR = CF_PRODUCT_VAR, int KP = CO_KP, bool PERSIST = false>
 __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     // appends per lane between compactions: the buffer holds the KP kept entries + 2 x (quota + one check interval)
     constexpr int CO_QUOTA = (CO_CAP - KP) / 2 - CO_CHECK_EVERY;   // 16 at KP = 16, 12 at KP = 24
@@ -306,10 +314,10 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     // (class 0's members, class 1's, ...) - then the ~G/T work-groups that stream the same tiles share one L2 and
     // the corpus is fetched from the Infinity Cache once per class instead of once per work-group (measured:
     // FETCH_SIZE 4.3 GB -> see profiles/). Pure placement: any bijection is correct.
-    const int wg = flat_workgroup_of_block((int)blockIdx.x, (int)gridDim.x, a.pos_period);
-    const int u_begin = wg * a.units_per_wg;
-    const int u_end = min(a.total_units, u_begin + a.units_per_wg);
-    if (u_begin >= u_end) return;
+    const int nq_act = PERSIST && a.nq_ptr ? min(__builtin_amdgcn_readfirstlane(*a.nq_ptr), a.nq) : a.nq;
+    const int total_units = PERSIST ? ((nq_act + CO_BM - 1) / CO_BM) * a.ctiles : a.total_units;
+    const int nwg_logical = PERSIST ? a.nwg_virtual : (int)gridDim.x;
+    if (PERSIST && nq_act <= 0) return;
 
     // LDS-DMA: per-lane source offsets (bytes from the tile's first row, k = 0); piece i of this wave =
     // rows 8 (4 wave + i) .. +7, one full 128-B line each, 16-B pieces XOR-swizzled on the source side
@@ -350,6 +358,11 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
 
     half8 qf[NF];
     int cur_mtile = -1;
+    for (int vblock = (int)blockIdx.x; vblock < (PERSIST ? nwg_logical : (int)blockIdx.x + 1); vblock += PERSIST ? (int)gridDim.x : 1) {
+    const int wg = flat_workgroup_of_block(vblock, nwg_logical, a.pos_period);
+    const int u_begin = wg * a.units_per_wg;
+    const int u_end = min(total_units, u_begin + a.units_per_wg);
+    if (u_begin >= u_end) continue;
     int u = u_begin;
     while (u < u_end) {
         // ---- the list [t0, t1) of query tile mtile, and its ordinal ---------------------------------------
@@ -367,12 +380,16 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             if constexpr (X16) {   // group gr's fragments at qf[gr NF/2 ..): lane holds Q[query 16 gr + q16][32 s + 8 g16 + 0..7]
 #pragma unroll
                 for (int gr = 0; gr < 2; ++gr) {
-                    const _Float16 *qrow = a.q16 + (size_t)(slot0 + wave * 32 + 16 * gr + q16) * D + 8 * g16;
+                    int qr = slot0 + wave * 32 + 16 * gr + q16;
+                    if (PERSIST && a.qlist) qr = a.qlist[min(qr, nq_act - 1)];   // (slots past the list sit at +inf: any row will do)
+                    const _Float16 *qrow = a.q16 + (size_t)qr * D + 8 * g16;
 #pragma unroll
                     for (int s = 0; s < NF / 2; ++s) qf[gr * (NF / 2) + s] = *reinterpret_cast<const half8 *>(qrow + 32 * s);
                 }
             } else {
-                const _Float16 *qrow = a.q16 + (size_t)(slot0 + wave * 32 + c) * D + 8 * h;
+                int qr = slot0 + wave * 32 + c;
+                if (PERSIST && a.qlist) qr = a.qlist[min(qr, nq_act - 1)];
+                const _Float16 *qrow = a.q16 + (size_t)qr * D + 8 * h;
 #pragma unroll
                 for (int s = 0; s < NF; ++s) qf[s] = *reinterpret_cast<const half8 *>(qrow + 16 * s);
             }
@@ -400,12 +417,12 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
         };
 
         Sel2 st;
-        Ops::init(st, wave_qbase + (uint32_t)c * Ops::QBYTES, h, (slot0 + wave * 32 + c) < a.nq && !NOPASS);
+        Ops::init(st, wave_qbase + (uint32_t)c * Ops::QBYTES, h, (slot0 + wave * 32 + c) < nq_act && !NOPASS);
         float boot1 = -INFINITY, boot2 = -INFINITY, boot3 = -INFINITY;   // bootstrap: the lane's three best scores so far
         // (a third of the list at most: 6 rows above the level per boot_tiles tiles -> >= 18 in the whole list)
         const int boot_tiles = ntiles >= CO_BOOT_MIN_TILES ? min(a.boot_tiles, ntiles / 3) : 0;
         unsigned int *my_shared = a.shared_thr + (slot0 + wave * 32 + c);
-        const bool publish = (slot0 + wave * 32 + c) < a.nq;   // (padding queries sit at +inf and never publish)
+        const bool publish = (slot0 + wave * 32 + c) < nq_act;   // (padding queries sit at +inf and never publish)
         uint32_t published = 0u;
         auto filter_reg = [&](const f32x16 (&pa)[4], auto F, uint32_t rowbase, auto GUARD) {
             constexpr int f = decltype(F)::value;
@@ -708,8 +725,8 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             const int other = (int)(h ? swm[0] : swm[1]);
             const int nlo = st.kept + (h ? other : mine), nhi = h ? mine : other;
             const int slot = slot0 + wave * 32 + c;
-            const bool store = slot < a.nq;
-            const size_t o = ((size_t)min(slot, a.nq - 1) * a.P + ord) * KP;
+            const bool store = slot < nq_act;
+            const size_t o = ((size_t)min(slot, nq_act - 1) * a.P + ord) * KP;
             const float bound = flush_emit_parallel<KP>(smem, wave_qbase + (uint32_t)c * Ops::QBYTES, h, c, nlo, nhi, st.thr,
                                                            store, a.part_scores + o, a.part_rows + o);
             if (store && h == 0) {
@@ -726,6 +743,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
         __syncthreads();   // every wave is done with the ring and its buffers before the next list's prologue
         u += ntiles;
     }
+    }   // (logical work-groups of this block)
     if constexpr (STAMPS) {
         if (lane == 0 && a.dbg) {
             unsigned long long *d = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 8;

@@ -41,6 +41,21 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+}  // namespace
+
+// (icd_group.cpp reports its errors through the same thread-local text)
+extern "C" __attribute__((visibility("hidden"))) int icd_internal_fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+namespace {
+
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
@@ -52,6 +67,11 @@ int fail(int code, const char *fmt, ...) {
 constexpr float EPS_REL = 1.2e-3f;
 constexpr int FAST_MAX_K = 100;      // the rescoring window holds up to 256 candidates (four per lane): k + the rows inside 2 eps of the k-th
 constexpr int COARSE_MAX_P = 32;     // P * KP <= FIN_MAX_CAND
+constexpr int PASS2_CHUNKS = 20;     // second coarse pass (and wide_mode): about this many candidate lists per query
+constexpr int PASS2_MAX_P = 24;      // ... at most this many (workspace); 24 x 16 candidates < FIN_MAX_CAND
+constexpr int PASS2_BELOW = 320;     // the second pass runs when the first gave a query fewer candidates than this
+constexpr int WIDE_MIN_NQ = 2048;    // "large batch": below it a query has 16+ lists anyway
+constexpr int WIDE_REPROBE = 64;
 constexpr int NUM_EV = 6;
 constexpr int EV_RING = 128;         // profiled searches kept for icd_index_profile_summary
 
@@ -99,10 +119,13 @@ struct icd_index {
     unsigned int *shared_thr = nullptr;   // [max_nq_pad] coarse pass: per-query threshold shared by its lists
     long long perm_mul = 0; int perm_mod = 0;   // row order of the fp16 corpus: position p holds row (p * perm_mul) mod perm_mod
     float *partc_s = nullptr; int *partc_r = nullptr; float *partc_b = nullptr; size_t partc_cap = 0;   // coarse lists + bounds
+    float *part2_s = nullptr; int *part2_r = nullptr; float *part2_b = nullptr; size_t part2_cap = 0;   // lists of the second coarse pass
     float *partx_s = nullptr; int *partx_r = nullptr; size_t partx_cap = 0;
     float *lists_s = nullptr; int *lists_r = nullptr; size_t lists_cap = 0;   // streaming kernel: [slot][4 nwg][KP]
-    int *nflag = nullptr; int *flagged = nullptr;   // fallback counters [4] and lists [2][max_nq_pad] (second: after the wide-window retry)
+    int *nflag = nullptr; int *flagged = nullptr;   // fallback counters [4] and lists [3][max_nq_pad]: after the first finalize, after its wide-window retry, after the second coarse pass
     int fallback_word = 0;                           // which counter / list the last search's exact re-search read
+    int *h_nflag = nullptr;                          // pinned host copy of nflag[4], refreshed by every search (async, on its stream)
+    hipEvent_t ev_nflag = nullptr;                   // recorded behind that copy: icd_index_stats waits for it and nothing else
     unsigned int *scratch_u32 = nullptr;  // [0]=rmax bits, [1]=any_bad
     // output staging (used when the caller's buffers are host memory)
     float *o_scores = nullptr; long long *o_ids = nullptr;
@@ -110,7 +133,17 @@ struct icd_index {
     size_t bytes_ws = 0;
     // knobs / counters
     int chunks_override = 0;
+    // adaptive list count of LARGE batches (>= WIDE_MIN_NQ queries): when the second coarse pass had to rescue most of the
+    // previous large batch (a corpus of tight families), the first pass is planned with its list count right away
+    bool wide_mode = false;        // plan the first pass with PASS2_CHUNKS lists per query
+    int wide_runs = 0;             // large searches since wide_mode was entered (every WIDE_REPROBE-th runs narrow again)
+    bool last_narrow_large = false; // the last search was a large batch with the narrow plan and the second pass behind it
+    bool pass2_enabled = true;     // test hook (icd_index_set_second_pass)
+    bool adapt_enabled = true;     // ... 2 = second pass without the adaptive list count
     bool profiling = false;
+    int prof_every = 1;            // events on every prof_every-th search (a recorded event keeps the next kernel from
+    long prof_tick = 0;            // overlapping the previous one's tail: sampling keeps that cost out of a timed region)
+    bool prof_now = false;
     hipEvent_t evring[EV_RING][NUM_EV + 1] = {};
     bool evring_valid[EV_RING][NUM_EV + 1] = {};
     long prof_count = 0;           // profiled searches since the last summary
@@ -118,6 +151,7 @@ struct icd_index {
     bool *ev_valid = evring_valid[0];
     int64_t last_nq = 0;
     int last_chunks = 0, last_mode = 0;
+    int last_p2 = 0, last_p2_word = 0;   // lists per query of the last search's second pass (0: none) and the counter that fed it
     unsigned long long *dbg = nullptr;  // diagnostic cycle counters [8192][4][4]
 };
 
@@ -129,10 +163,13 @@ void free_all(icd_index *x) {
     if (!x) return;
     hipFree(x->corpus); hipFree(x->c16); hipFree(x->levels); hipFree(x->qdev); hipFree(x->q16);
     hipFree(x->qnorm); hipFree(x->qexp); hipFree(x->qbad); hipFree(x->shared_thr); hipFree(x->partc_s); hipFree(x->partc_r); hipFree(x->partc_b); hipFree(x->partx_s);
+    hipFree(x->part2_s); hipFree(x->part2_r); hipFree(x->part2_b);
     hipFree(x->partx_r); hipFree(x->lists_s); hipFree(x->lists_r); hipFree(x->nflag); hipFree(x->flagged); hipFree(x->scratch_u32);
     hipFree(x->o_scores); hipFree(x->o_ids); hipFree(x->o_adj); hipFree(x->o_adj_raw);
     hipFree(x->o_adj_ids); hipFree(x->o_adj_lv);
     hipFree(x->dbg);
+    if (x->h_nflag) hipHostFree(x->h_nflag);
+    if (x->ev_nflag) hipEventDestroy(x->ev_nflag);
     for (int r = 0; r < EV_RING; ++r)
         for (int i = 0; i <= NUM_EV; ++i)
             if (x->evring[r][i]) hipEventDestroy(x->evring[r][i]);
@@ -175,9 +212,9 @@ int launch_exact(icd_index *x, const ExactArgs &a, int mtiles, hipStream_t s) {
     return ICD_OK;
 }
 
-template <int D, int VAR = CF_PRODUCT_VAR, int KP = CO_KP>
+template <int D, int VAR = CF_PRODUCT_VAR, int KP = CO_KP, bool PERSIST = false>
 int launch_coarse_flat(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream_t s) {
-    auto kern = coarse_flat_kernel<D, VAR, KP>;
+    auto kern = coarse_flat_kernel<D, VAR, KP, PERSIST>;
     constexpr int lds = cf_lds_bytes(VAR);
     static int configured[MAX_DEVICES] = {};   // (guarded by the caller's one-stream-per-handle contract; worst case a repeated call)
     HIP_TRY(ensure_dynamic_lds(kern, x->device, (size_t)(lds), configured));
@@ -321,7 +358,7 @@ int launch_finalize(icd_index *x, const FinArgs &a, hipStream_t s) {
 }
 
 void rec(icd_index *x, int i, hipStream_t s) {
-    if (x->profiling) {
+    if (x->prof_now) {
         hipEventRecord(x->ev[i], s);
         x->ev_valid[i] = true;
     }
@@ -336,15 +373,17 @@ struct Outs {
 int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const Outs &o, hipStream_t s) {
     const int row_tiles = (int)((x->n + 127) / 128);
     const bool use_fast = (mode == ICD_MODE_AUTO) && x->fast && k <= FAST_MAX_K && (x->dim == 768 || x->dim == 1024);
-    if (x->profiling) {
+    x->prof_now = x->profiling && (x->prof_tick++ % x->prof_every == 0);
+    if (x->prof_now) {
         const int slot = (int)(x->prof_count % EV_RING);
         x->ev = x->evring[slot];
         x->ev_valid = x->evring_valid[slot];
         ++x->prof_count;
+        for (int i = 0; i <= NUM_EV; ++i) x->ev_valid[i] = false;
     }
-    for (int i = 0; i <= NUM_EV; ++i) x->ev_valid[i] = false;
     x->last_nq = nq;
     x->fallback_word = 0;
+    x->last_p2 = 0;
     x->last_mode = use_fast ? ICD_MODE_AUTO : ICD_MODE_EXACT;
     rec(x, 0, s);
 
@@ -467,6 +506,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     ConvertArgs cv{};
     cv.src = dq; cv.dst = x->q16; cv.rows = nq; cv.rows_pad = nq_pad; cv.dim = x->dim; cv.mode = 0;
     cv.norm = x->qnorm; cv.scale_exp = x->qexp; cv.bad = x->qbad; cv.zero_u32 = x->shared_thr; cv.zero_i32 = x->nflag;
+    cv.zero_u32b = x->shared_thr + x->max_nq_pad;
     hipLaunchKernelGGL(convert_rows_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, s, cv);
     HIP_TRY(hipGetLastError());
     rec(x, 1, s);
@@ -479,6 +519,27 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     const int ctiles = plan.ctiles;
     int pc = 0;
     const bool wide_lists = k > 64 && x->dim == 768;
+    // ---- adaptive list count of large batches -------------------------------------------------------------------------
+    // The counters of the previous search sit in pinned host memory once its copy event has completed (hipEventQuery: no
+    // wait). If that search was a large batch on the narrow plan and its second coarse pass had to take in a quarter of
+    // the queries and certified most of them, the corpus is one of tight families (ICD sibling codes): large batches then
+    // start with the second pass's list count (1.5 instead of 2.2 ms per 10 000 queries there; 7 % slower on Gaussian data,
+    // which is why it is not the default). Every WIDE_REPROBE-th large search runs narrow again and decides anew.
+    const bool large = nq >= WIDE_MIN_NQ;
+    if (x->last_narrow_large && hipEventQuery(x->ev_nflag) == hipSuccess) {
+        const int f0 = x->h_nflag[0], f2 = x->h_nflag[2];
+        const long long n_prev = x->last_nq;
+        if (n_prev > 0) {
+            if (!x->wide_mode && (long long)f0 * 4 > n_prev && (long long)f2 * 2 < f0) { x->wide_mode = true; x->wide_runs = 0; }
+            else if (x->wide_mode && (long long)f0 * 20 <= n_prev) x->wide_mode = false;   // (a narrow re-probe that certified 95 %)
+        }
+        x->last_narrow_large = false;
+    }
+    bool wide_now = false;
+    if (large && x->wide_mode && x->chunks_override == 0 && k <= 32) wide_now = (++x->wide_runs % WIDE_REPROBE) != 0;
+    const int kp_c = wide_lists ? CO_KP_WIDE : CO_KP;
+    CoarseFlatArgs a2{};      // the second pass's arguments (filled next to the first pass's)
+    int nwg2 = 0, p2 = 0;
     {
         // ---- product: flat partition of the (query tile x corpus tile) grid over the CUs (coarse_flat_kernel.hpp) ----
         CoarseFlatArgs a{};
@@ -495,7 +556,6 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         // corpus sweep per batch (0.34 ms); with 24 per list and about k / 6 lists it did not happen. The wider lists make
         // the coarse pass ~20 % slower (lower thresholds, more appends), so they only pay where that sweep is the larger
         // cost: k = 100 1.69 -> 1.54 ms, k = 32 would go 0.87 -> 0.99 (profiles/r02_tile_planner_and_shapes.log).
-        const int kp_c = wide_lists ? CO_KP_WIDE : CO_KP;
         if (wide_lists) a.list_tiles = std::max(1, std::min(a.list_tiles, ctiles / ((k + 5) / 6)));
         else if (k > 8) a.list_tiles = std::max(1, std::min(a.list_tiles, ctiles / ((k + 3) / 4)));
         // The bootstrap level (6th best of the first boot_tiles * 128 rows of a list) must stay far below the k-th best
@@ -508,19 +568,21 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         if (const char *e = getenv("ICD_FLAT_LIST")) a.list_tiles = std::max(1, atoi(e));   // A/B: tiles per list
         if (const char *e = getenv("ICD_FLAT_BOOT")) a.boot_tiles = std::max(0, atoi(e));   // A/B: bootstrap tiles
 #endif
-        if (x->chunks_override > 0) {   // test hook: about `chunks` lists per query
-            U = std::max(1, (ctiles + x->chunks_override - 1) / x->chunks_override);
+        if (x->chunks_override > 0 || wide_now) {   // test hook / wide mode: about `chunks` lists per query
+            const int chunks = x->chunks_override > 0 ? x->chunks_override : PASS2_CHUNKS;
+            U = std::max(1, (ctiles + chunks - 1) / chunks);
             a.list_tiles = ctiles;
         }
-        auto lists_needed = [&](int u) {   // the largest number of lists of any query tile (same rule as the kernel)
+        auto lists_needed_lt = [&](int u, int list_tiles) {   // the largest number of lists of any query tile (same rule as the kernel)
             int worst = 0;
             for (int m = 0; m < mtc; ++m) {
                 const long long m1 = (long long)(m + 1) * ctiles;
                 const int wl = (int)((m1 - 1) / u);   // last work-group touching the query tile
-                worst = std::max(worst, flat_first_ordinal(m, wl + 1, ctiles, u, a.list_tiles));
+                worst = std::max(worst, flat_first_ordinal(m, wl + 1, ctiles, u, list_tiles));
             }
             return worst;
         };
+        auto lists_needed = [&](int u) { return lists_needed_lt(u, a.list_tiles); };
         int P = lists_needed(U);
         // too many lists for the workspace or for finalize's candidate window: longer lists first (the balance of the
         // partition is untouched), more tiles per work-group only when a list already spans the corpus
@@ -556,6 +618,37 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         pc = P;
         x->last_chunks = P;
         const int nwg = (a.total_units + U - 1) / U;
+        a.nwg_virtual = nwg;
+        // ---- the second pass's plan: the same sweep cut into about PASS2_CHUNKS lists per query, every work-group's run
+        // one list (the shape icd_index_set_chunks asks for). Everything the host must know is independent of how many
+        // queries will be flagged: U2, the list slots per query (worst case over all query tiles of the full batch), the
+        // logical work-group count of a full batch. The kernel sizes the sweep from the flagged count on the device.
+        if (x->pass2_enabled && P * kp_c < PASS2_BELOW && x->part2_s) {
+            int U2 = std::max(1, (ctiles + PASS2_CHUNKS - 1) / PASS2_CHUNKS);
+            p2 = lists_needed_lt(U2, ctiles);
+            while ((p2 > PASS2_MAX_P || (size_t)nq * p2 * CO_KP > x->part2_cap) && U2 < ctiles) {
+                U2 = std::min(ctiles, U2 + std::max(1, U2 / 8));
+                p2 = lists_needed_lt(U2, ctiles);
+            }
+            if (p2 <= PASS2_MAX_P && (size_t)nq * p2 * CO_KP <= x->part2_cap && p2 * CO_KP > P * kp_c) {
+                a2 = a;
+                a2.nq_ptr = nullptr; a2.qlist = nullptr;   // (set at the launch: which flag word / list feeds it)
+                a2.units_per_wg = U2; a2.list_tiles = ctiles; a2.P = p2;
+                a2.boot_tiles = a.boot_tiles;
+                a2.pos_period = flat_class_period(U2, ctiles);
+                nwg2 = (int)(((long long)mtc * ctiles + U2 - 1) / U2);
+                {
+                    const int members = nwg2 / std::max(1, a2.pos_period);
+                    const int split = (members + 11) / 12;
+                    if (a2.pos_period > 0 && a2.pos_period < (1 << 20)) a2.pos_period *= std::max(1, split);
+                }
+                a2.nwg_virtual = nwg2;
+                a2.part_scores = x->part2_s; a2.part_rows = x->part2_r; a2.bounds = x->part2_b;
+                a2.shared_thr = x->shared_thr + x->max_nq_pad;
+            } else {
+                p2 = 0;
+            }
+        }
         int rc;
         // (dim 1024: the query fragments alone are 256 registers: no pinning, no deeper fragment prefetch and the 32x32x16
         //  shape there; the quad select and the synchronised compaction apply)
@@ -630,6 +723,31 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             if (rc) return rc;
             x->fallback_word = 1;
         }
+        // Second coarse pass, over the queries that are still flagged only. A large batch gives a query 5-8 lists of 16
+        // candidates: a family of near-identical rows larger than that (ICD sibling codes repeat their ancestors' names:
+        // 124-row families of mutual cosine 0.99 sit inside 2 eps of each other) cannot be certified from them, whatever
+        // the window. The same kernel sweeps the corpus again for the flagged queries with about PASS2_CHUNKS lists each
+        // (the partition sized on the device from the flagged count, one block per CU looping over the logical
+        // work-groups), finalize certifies from those lists with the widest window, and only what still fails goes to the
+        // exact re-search. A batch with nothing flagged pays two launches that read one counter and leave.
+        if (p2 > 0) {
+            const int w_in = x->fallback_word;
+            a2.nq_ptr = x->nflag + w_in;
+            a2.qlist = x->flagged + (size_t)w_in * x->max_nq_pad;
+            const int grid2 = std::max(8, std::min(nwg2, x->num_cu) & ~7);
+            if (x->dim == 1024) rc = launch_coarse_flat<1024, (CF_PRODUCT_VAR & (3 | 16 | 2048)), CO_KP, true>(x, a2, grid2, s);
+            else rc = launch_coarse_flat<768, CF_PRODUCT_VAR, CO_KP, true>(x, a2, grid2, s);
+            if (rc) return rc;
+            FinArgs g3 = g;
+            g3.part_scores = x->part2_s; g3.part_rows = x->part2_r; g3.bounds = x->part2_b; g3.P = p2; g3.KP = CO_KP;
+            g3.qlist = a2.qlist; g3.nq_ptr = a2.nq_ptr; g3.lists_by_query = 0; g3.wide_window = 1;
+            g3.nflag = x->nflag + 2; g3.flagged = x->flagged + (size_t)2 * x->max_nq_pad;
+            rc = launch_finalize_t<true, false, 4>(x, g3, s);
+            if (rc) return rc;
+            x->fallback_word = 2;
+            x->last_p2 = p2; x->last_p2_word = w_in;
+        }
+        x->last_narrow_large = x->adapt_enabled && large && p2 > 0 && !wide_now && x->chunks_override == 0;
     }
     rec(x, 3, s);
     const int *fl_list = x->flagged + (size_t)x->fallback_word * x->max_nq_pad;
@@ -763,11 +881,15 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
         CR_TRY(wsalloc(&x->partc_s, x->partc_cap));
         CR_TRY(wsalloc(&x->partc_r, x->partc_cap));
         CR_TRY(wsalloc(&x->partc_b, x->partc_cap / CO_KP));
+        x->part2_cap = (size_t)x->max_nq_pad * PASS2_MAX_P * CO_KP;
+        CR_TRY(wsalloc(&x->part2_s, x->part2_cap));
+        CR_TRY(wsalloc(&x->part2_r, x->part2_cap));
+        CR_TRY(wsalloc(&x->part2_b, x->part2_cap / CO_KP));
     }
     CR_TRY(wsalloc(&x->qnorm, (size_t)x->max_nq_pad));
     CR_TRY(wsalloc(&x->qexp, (size_t)x->max_nq_pad));
     CR_TRY(wsalloc(&x->qbad, (size_t)x->max_nq_pad));
-    CR_TRY(wsalloc(&x->shared_thr, (size_t)x->max_nq_pad));
+    CR_TRY(wsalloc(&x->shared_thr, (size_t)2 * x->max_nq_pad));   // [0]: first coarse pass, [1]: second
     CR_TRY(wsalloc(&x->qdev, (size_t)max_nq * dim));
     x->partx_cap = std::max<size_t>((size_t)x->max_nq_pad * 2 * exact_kp_for(max_k), (size_t)1 << 21);
     if (exact_kp_for(max_k) > 16)   // multi-level reduction of the streaming kernel's lists: ST_MAX_ACTIVE slots x 512 lists
@@ -780,9 +902,12 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     CR_TRY(wsalloc(&x->lists_r, x->lists_cap));
     CR_TRY(wsalloc(&x->nflag, 4));
     CR_TRY(hipMemset(x->nflag, 0, 4 * sizeof(int)));
+    CR_TRY(hipHostMalloc(reinterpret_cast<void **>(&x->h_nflag), 4 * sizeof(int), hipHostMallocDefault));
+    memset(x->h_nflag, 0, 4 * sizeof(int));
+    CR_TRY(hipEventCreateWithFlags(&x->ev_nflag, hipEventDisableTiming));
     CR_TRY(wsalloc(&x->dbg, (size_t)8192 * 16));
     CR_TRY(hipMemset(x->dbg, 0, (size_t)8192 * 16 * 8));
-    CR_TRY(wsalloc(&x->flagged, (size_t)2 * x->max_nq_pad));
+    CR_TRY(wsalloc(&x->flagged, (size_t)3 * x->max_nq_pad));
     const size_t no = (size_t)max_nq * max_k;
     CR_TRY(wsalloc(&x->o_scores, no)); CR_TRY(wsalloc(&x->o_ids, no)); CR_TRY(wsalloc(&x->o_adj, no));
     CR_TRY(wsalloc(&x->o_adj_raw, no)); CR_TRY(wsalloc(&x->o_adj_ids, no)); CR_TRY(wsalloc(&x->o_adj_lv, no));
@@ -830,6 +955,10 @@ static int search_common(icd_index *x, const float *queries, int64_t nq, int32_t
     int rc = search_device(x, dq, (int)nq, k, mode, dev, s);
     if (rc) return rc;
     rec(x, NUM_EV, s);
+    // the fallback counters travel to pinned host memory behind the search, on its stream: icd_index_stats reads them
+    // after waiting for THIS event only (no device-wide synchronisation: other streams - an encoder - keep running)
+    HIP_TRY(hipMemcpyAsync(x->h_nflag, x->nflag, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(x->ev_nflag, s));
     if (!out_on_device) {
         const size_t no = (size_t)nq * k;
         if (user.scores) HIP_TRY(hipMemcpyAsync(user.scores, dev.scores, no * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -957,21 +1086,32 @@ int icd_index_stats(icd_index *idx, icd_stats *out) {
     out->max_nq = idx->max_nq; out->max_k = idx->max_k; out->fast_path = idx->fast ? 1 : 0;
     out->rmax = idx->rmax;
     out->last_nq = idx->last_nq;
-    // the last search's fallback count is read from the device here, not copied back by every search: this call waits
-    // for the device (a diagnostic, not part of the search path)
+    // the last search's fallback count: every search copies its counters to pinned host memory behind itself; this call
+    // waits for that copy's event - the last search of THIS handle - and for nothing else on the device
     int nf = 0;
-    if (idx->nflag && idx->last_nq > 0) {
+    if (idx->h_nflag && idx->last_nq > 0) {
         HIP_TRY(hipSetDevice(idx->device));
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(&nf, idx->nflag + idx->fallback_word, sizeof(int), hipMemcpyDeviceToHost));
+        HIP_TRY(hipEventSynchronize(idx->ev_nflag));
+        nf = idx->h_nflag[idx->fallback_word];
     }
     out->last_fallback = nf;
+    out->last_second_pass = (idx->last_p2 > 0 && idx->h_nflag && idx->last_nq > 0) ? idx->h_nflag[idx->last_p2_word] : 0;
+    out->last_second_pass_lists = idx->last_p2;
+    out->wide_mode = idx->wide_mode ? 1 : 0;
     out->last_chunks = idx->last_chunks; out->last_mode = idx->last_mode;
     return ICD_OK;
 }
 
 int icd_debug_set_permute(int32_t enabled) {
     g_permute = enabled != 0;
+    return ICD_OK;
+}
+
+int icd_index_set_second_pass(icd_index *idx, int32_t enabled) {
+    if (!valid(idx)) return fail(ICD_ERR_STATE, "invalid handle");
+    idx->pass2_enabled = enabled != 0;
+    idx->adapt_enabled = enabled == 1;
+    if (!idx->pass2_enabled || !idx->adapt_enabled) { idx->wide_mode = false; idx->last_narrow_large = false; }
     return ICD_OK;
 }
 
@@ -992,7 +1132,10 @@ int icd_index_debug_counters(icd_index *idx, unsigned long long *out, int32_t co
 
 int icd_index_set_profiling(icd_index *idx, int32_t enabled) {
     if (!valid(idx)) return fail(ICD_ERR_STATE, "invalid handle");
+    if (enabled < 0) return fail(ICD_ERR_INVALID, "enabled=%d", enabled);
     idx->profiling = enabled != 0;
+    idx->prof_every = enabled > 1 ? enabled : 1;
+    idx->prof_tick = 0;
     return ICD_OK;
 }
 

@@ -224,37 +224,15 @@ class MilvusService:
         index = self._ready_index()
         if index is None:
             raise RuntimeError(f"collection {self.collection_name} is empty or missing")
-        self._adapt_candidate_lists(index, len(query_vectors))
+        # (large batches on a corpus of tight families of near-identical rows - ICD sibling codes - are handled inside the
+        #  library: a second coarse pass over the queries the first could not certify, and from the next large batch on the
+        #  wider partition right away; include/icd_search.h icd_stats.last_second_pass / wide_mode)
         adj, raw, ids, levels = index.search_reweighted(query_vectors, int(top_k))
         if not as_dicts:
             return adj, raw, ids, levels
         if hasattr(adj, "cpu"):
             adj, raw, ids = adj.cpu().numpy(), raw.cpu().numpy(), ids.cpu().numpy()
         return [self._hits_to_dicts(adj[q], raw[q], ids[q]) for q in range(len(ids))]
-
-    # Large batches on a corpus of tight families. The coarse pass gives a query about 256 x 128 / nq candidate lists of 16:
-    # 30 at 1 000 queries, 5-8 at 10 000. A query whose family of near-identical rows (ICD sibling codes) is larger than
-    # that budget cannot be certified from the lists and takes the exact re-search: 8.9 ms per 10 000 queries at top_k 10
-    # and 18 ms at 20 on 124-row families of mutual cosine 0.99, against 1.5 ms with ~20 lists per query
-    # (profiles/r02_family_corpus_probe.log). More lists cost Gaussian-like data 7 %, so they are not the default: the
-    # service looks at the fallback count of its previous LARGE batch (one 4-byte read, when the next one arrives) and
-    # asks for them from then on, for large batches only - the corpus, and with it the shape of its families, stays.
-    _LARGE_BATCH = 2048          # above this a query has fewer than 16 lists of 16
-    _WIDE_LISTS = 20
-    _FALLBACK_SHARE = 0.02
-
-    def _adapt_candidate_lists(self, index, nq: int):
-        if getattr(self, "_lists_index", None) is not index:      # a rebuilt index starts over
-            self._lists_index, self._wide_lists, self._check_last = index, False, False
-        if not self._wide_lists and self._check_last:
-            st = index.stats()                                    # (waits for the previous search; it is long done)
-            if st["last_nq"] >= self._LARGE_BATCH and st["last_fallback"] > self._FALLBACK_SHARE * st["last_nq"]:
-                self._wide_lists = True
-                logger.info("%d of the last %d queries took the exact re-search: large batches get %d candidate lists per "
-                            "query from now on", st["last_fallback"], st["last_nq"], self._WIDE_LISTS)
-        large = nq >= self._LARGE_BATCH
-        index.set_chunks(self._WIDE_LISTS if (large and self._wide_lists) else 0)
-        self._check_last = large
 
     # ---- admin (same keys as the reference) -------------------------------------------------------------------------
     def get_collection_stats(self) -> Dict[str, Any]:

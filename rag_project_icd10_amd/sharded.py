@@ -12,9 +12,14 @@ is new functionality required by the scaling configs:
     At Q = 100 000, k = 10 that is 16 MB per rank - microseconds over xGMI next to ~100 ms of MFMA
     work, so no ring/all-reduce is involved.
 
-The local search and the merge are injected callables: by default the HIP index / HIP merge kernel;
-the CPU (gloo, world_size 2) tests inject the oracle so the sharding + collective logic is covered
-without a GPU.
+Two engines behind one class:
+  * the C ABI (`from_index`, the default on GPUs): `icd_group_*` of libicdsearch.so - local search, ONE grouped
+    ncclAllGather (RCCL opened by the library itself), merge + reweight, all enqueued on one stream inside one call; PyTorch
+    only hands over the 128-byte RCCL unique id of rank 0 (through the process group that already exists) and the tensors'
+    pointers;
+  * injected callables + `torch.distributed` collectives (the constructor): the CPU (gloo, world_size 2) tests inject the
+    oracle so the sharding + collective logic is covered without a GPU, and a gloo group over GPU tensors (several ranks
+    on ONE device, which RCCL refuses) still works.
 """
 from __future__ import annotations
 
@@ -66,26 +71,46 @@ class ShardedSearch:
         self.search_fn = search_fn
         self.merge_fn = merge_fn
         self.local_reweighted_fn = local_reweighted_fn
+        self.native_group = None   # _native.IcdGroup when the C ABI runs the whole sharded search
 
     # ---- construction over the HIP index ---------------------------------------------------------------
     @classmethod
-    def from_index(cls, index, mode: str, group=None) -> "ShardedSearch":
+    def from_index(cls, index, mode: str, group=None, native: Optional[bool] = None) -> "ShardedSearch":
         """index: rag_project_icd10_amd._native.IcdIndex over this rank's shard (row mode, created with
-        id_base = first global row) or over the full corpus (query mode)."""
+        id_base = first global row) or over the full corpus (query mode).
+        native (default: yes unless the process group's backend is not nccl): run the sharded search through the C ABI's
+        icd_group_* (RCCL inside the library); otherwise torch.distributed collectives between the library's kernels."""
         from . import _native
 
         def search_fn(q, k):
             raw, ids = index.search(q, k)
             return raw, ids, index.lookup_levels(ids)
 
-        return cls(mode, search_fn=search_fn, merge_fn=_native.merge_topk,
+        self = cls(mode, search_fn=search_fn, merge_fn=_native.merge_topk,
                    local_reweighted_fn=index.search_reweighted, group=group)
+        if native is None:
+            native = self.world == 1 or dist.get_backend(group) == "nccl"
+        if native:
+            uid = None
+            if self.world > 1:   # rank 0's RCCL unique id travels through the existing process group (128 bytes)
+                t = torch.zeros(_native.GROUP_ID_BYTES, dtype=torch.uint8)
+                if self.rank == 0:
+                    t = torch.frombuffer(bytearray(_native.group_unique_id()), dtype=torch.uint8).clone()
+                if dist.get_backend(group) == "nccl":
+                    t = t.to(torch.device("cuda", index.device))
+                dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                uid = bytes(t.cpu().numpy().tobytes())
+            self.native_group = _native.IcdGroup(index, _native.GROUP_ROW_SHARD if mode == ROW_SHARD else _native.GROUP_QUERY_SHARD,
+                                                 rank=self.rank, world=self.world, unique_id=uid)
+        return self
 
     # ---- search ---------------------------------------------------------------------------------------------
     def search_reweighted(self, queries: torch.Tensor, k: int, gather: bool = True):
         """Row mode: `queries` is the full batch on every rank -> identical (adj, raw, ids, levels) on
         every rank. Query mode: `queries` is the full batch on every rank; rank r searches its slice
         and, with gather=True, all ranks receive the full result (else only the local slice)."""
+        if self.native_group is not None:
+            return self.native_group.search(queries, k, gather=gather)
         if self.mode == ROW_SHARD:
             raw, ids, levels = self.search_fn(queries, k)
             payload = pack_hits(raw, ids, levels)

@@ -34,7 +34,7 @@ class OracleIndex:
         s, i = self.orc.flat_ip_topk(self.corpus, q.numpy(), k, id_base=self.id_base)
         return tuple(torch.from_numpy(x) for x in self.orc.reweight(s, i, self.levels, id_base=self.id_base))
 
-    def set_profiling(self, on):
+    def set_profiling(self, on, every=1):
         self.prof = on
 
     def profile_summary(self):

@@ -24,6 +24,9 @@ Only DATA is written (inputs + the reference's outputs):
   milvus_search_vectors.npz   corpus [384,768] f32, queries [10,768] f32, tiny corpus [3,768]
   milvus_search_cases.json    records handed to insert_records, the rows the reference handed the engine
                               (vectors dropped), search outputs per (query, top_k), the error cases
+  milvus_batch_vectors.npz    batch_queries [160,768] f32: a batch large enough to take the MFMA coarse path of the
+                              HIP index (more than 16 queries), among them the designed tie / duplicate / zero queries
+  milvus_batch_cases.json     the reference's `search(q, 10)` and `search(q, 20)` looped over those 160 queries
 """
 import json
 import os
@@ -238,6 +241,24 @@ def main():
     list_embedding = svc.insert_records(records[:1], [[0.0] * DIM])   # .tolist() on a list -> caught -> False (:231,266-268)
     weights = {str(lv): svc._calculate_level_weight(lv) for lv in (-1, 0, 1, 2, 3, 4, 7, 100)}
 
+    # a BATCH of queries, the reference's search looped (it has no batch call): the case that puts the reference's own
+    # output against the fp16-MFMA coarse kernel + certified rescoring (batches of <= 16 take the streaming kernel)
+    rngb = np.random.default_rng(20251004)
+    batch = rngb.standard_normal((160, DIM)).astype(np.float32)
+    batch /= np.linalg.norm(batch, axis=1, keepdims=True)
+    batch[5] = corpus[100]                                # duplicate rows 100 / 200: raw tie, different levels
+    batch[6] = queries[6]                                 # the one-hot query: equal adjusted scores from different levels
+    batch[7] = 0.0                                        # all scores zero: every hit ties
+    batch[8] = corpus[101] * np.float32(0.5)              # duplicate rows 101 / 201, same weight: tie on both scores
+    batch[9] = batch[10]                                  # two identical queries in one batch
+    for qi in range(len(batch)):
+        assert chain_f32(corpus, batch[qi]).tobytes() == orc.scores(batch[qi], corpus).tobytes(), qi
+    batch_out = {str(k): [svc.search(batch[i], k) for i in range(len(batch))] for k in (10, 20)}
+    np.savez_compressed(os.path.join(HERE, "milvus_batch_vectors.npz"), batch_queries=batch)
+    json.dump({"generated_by": "tests/golden/make_milvus_golden.py: /root/reference/services/milvus_service.py search() looped over "
+                               "the 160 batch queries (corpus / records of milvus_search_cases.json)",
+               "out": batch_out}, open(os.path.join(HERE, "milvus_batch_cases.json"), "w"), ensure_ascii=False, indent=0)
+
     np.savez_compressed(os.path.join(HERE, "milvus_search_vectors.npz"), corpus=corpus, levels=levels.astype(np.int32),
                         queries=queries, tiny=tiny)
     json.dump({
@@ -250,7 +271,7 @@ def main():
         "insert_length_mismatch": mismatch, "insert_list_embedding": list_embedding,
         "level_weights": weights,
     }, open(os.path.join(HERE, "milvus_search_cases.json"), "w"), ensure_ascii=False, indent=0)
-    print("wrote milvus_search_vectors.npz / milvus_search_cases.json:", len(cases), "search cases")
+    print("wrote milvus_search_vectors.npz / milvus_search_cases.json:", len(cases), "search cases; milvus_batch_*:", len(batch), "queries x k = 10, 20")
 
 
 if __name__ == "__main__":

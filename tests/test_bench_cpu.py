@@ -31,7 +31,7 @@ def _worker_body(rank, world, port, q):
     import bench_cpu_engine as eng
     ctx = bench.Ctx()
     assert ctx.world == world and ctx.dist.get_world_size() == world
-    args = argparse.Namespace(steps=2, warmup=1, settle_ms=0.0, repeats=1, nq=40, n=900, k=5, mode="auto", rows_per_gpu=700, rowshard_queries=50,
+    args = argparse.Namespace(steps=2, warmup=1, settle_ms=0.0, repeats=1, profile_every=1, nq=40, n=900, k=5, mode="auto", rows_per_gpu=700, rowshard_queries=50,
                               rowshard_slice=32, rowshard_steps=2, no_cpu_baseline=True, no_extras=True)
     rs = bench.run_rowshard(ctx, args, index_factory=eng.index_factory, sharded_factory=eng.sharded_factory)
     rp = bench.run_replicated(ctx, args, index_factory=eng.index_factory)

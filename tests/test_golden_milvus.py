@@ -23,6 +23,12 @@ def gold():
     return cases, {k: vec[k] for k in vec.files}
 
 
+@pytest.fixture(scope="module")
+def gold_batch():
+    out = json.load(open(os.path.join(GOLDEN, "milvus_batch_cases.json"), encoding="utf-8"))["out"]
+    return out, np.load(os.path.join(GOLDEN, "milvus_batch_vectors.npz"))["batch_queries"]
+
+
 class _DimProbe:
     def __init__(self, dim):
         self.dim = dim
@@ -94,6 +100,19 @@ def test_oracle_and_dict_builder_equal_the_reference_output(tmp_path, gold, orac
     assert svc_t._hits_to_dicts(adj[0], oraw[0], oid[0]) == tiny["out"]
 
 
+def test_oracle_equals_the_reference_on_the_batch_fixture(tmp_path, gold, gold_batch, oracle):
+    """the 160-query batch (the reference's search looped): oracle + dict builder == the reference's dicts, k = 10 and 20"""
+    _, vec = gold
+    out, batch = gold_batch
+    svc = _service(tmp_path, gold)
+    levels = svc.client.levels()
+    for k in (10, 20):
+        raw, ids = oracle.flat_ip_topk(vec["corpus"], batch, k)
+        adj, oraw, oid, _ = oracle.reweight(raw, ids, levels)
+        for q in range(len(batch)):
+            assert svc._hits_to_dicts(adj[q], oraw[q], oid[q]) == out[str(k)][q], (q, k)
+
+
 def test_error_paths_return_empty_lists_like_the_reference(tmp_path, gold, monkeypatch):
     cases, vec = gold
     svc = _service(tmp_path, gold)
@@ -130,3 +149,26 @@ def test_hip_search_equals_the_reference_output(tmp_path, gold):
     assert svc_t.search(vec["queries"][tiny["query_index"]], tiny["top_k"]) == tiny["out"]
     svc_t.client.drop()
     assert svc_t.search(vec["queries"][1], 5) == cases["missing_collection"]
+
+
+@pytest.mark.gpu
+def test_hip_mfma_path_equals_the_reference_output_on_a_batch(tmp_path, gold, gold_batch):
+    """The reference's own output against the fp16-MFMA coarse kernel + certification + canonical rescoring: 160 queries in
+    one search_batch call take ICD_MODE_AUTO's coarse path (batches of <= 16 take the streaming kernel), among them the
+    designed duplicate-row / equal-adjusted-score / all-zero queries, which must come back through the exact fallback
+    with the same dicts. Host and device inputs."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from rag_project_icd10_amd._native import MODE_AUTO
+    out, batch = gold_batch
+    svc = _service(tmp_path, gold)
+    for k in (10, 20):
+        for q in (batch, torch.from_numpy(batch).cuda()):
+            got = svc.search_batch(q, k, as_dicts=True)
+            st = svc._ready_index().stats()
+            assert st["last_mode"] == MODE_AUTO and st["last_nq"] == len(batch)      # the coarse MFMA pass ran
+            assert st["last_fallback"] < len(batch) // 4                             # ... and certified most of the batch
+            assert len(got) == len(batch)
+            for qi in range(len(batch)):
+                assert got[qi] == out[str(k)][qi], (qi, k)

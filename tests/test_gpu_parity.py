@@ -147,6 +147,7 @@ def test_every_query_flagged_in_a_large_batch(oracle):
     corpus, levels = np.repeat(unit_rows(10, 768, 98), 200, axis=0), icd_levels(2000, 99)
     queries = unit_rows(6000, 768, 100)
     idx = IcdIndex(corpus, levels, max_nq=6000, max_k=10)
+    idx.set_second_pass(False)                       # (the second coarse pass would certify most of them: next block)
     s, i = idx.search(queries, 10, MODE_AUTO)
     st = idx.stats()
     assert st["last_fallback"] == 6000
@@ -155,6 +156,13 @@ def test_every_query_flagged_in_a_large_batch(oracle):
     assert np.array_equal(i[sample], oi) and _bits(s[sample]) == _bits(os_)
     se, ie = idx.search(queries, 10, MODE_EXACT)
     assert np.array_equal(i, ie) and _bits(s) == _bits(se)
+    # with the second pass (the default): ~21 lists of 16 hold all 200 copies of a query's best row, the 256-candidate
+    # window certifies most queries from them; what is left takes the dense fallback; same bits either way
+    idx.set_second_pass(True)
+    s2, i2 = idx.search(queries, 10, MODE_AUTO)
+    st2 = idx.stats()
+    assert st2["last_second_pass"] == 6000 and st2["last_fallback"] < 6000
+    assert np.array_equal(i2, i) and _bits(s2) == _bits(s)
     idx.close()
 
 
@@ -476,6 +484,33 @@ def test_sharded_search_single_rank_nccl(oracle):
         dist.destroy_process_group()
 
 
+def test_group_c_abi_with_a_one_rank_rccl_communicator(oracle):
+    """icd_group_* (include/icd_search.h): the row-sharded and the query-sharded search behind the C ABI with RCCL opened by
+    the library itself - a ONE-rank communicator here (ncclCommInitRank + the grouped ncclAllGather really run; two ranks
+    cannot share this box's one GPU). Must equal the oracle and the torch.distributed engine of ShardedSearch."""
+    import torch
+    from rag_project_icd10_amd._native import GROUP_QUERY_SHARD, GROUP_ROW_SHARD, IcdGroup, group_unique_id
+    n, nq, k = 5000, 300, 10
+    corpus, levels, queries = unit_rows(n, 768, 195), icd_levels(n, 196), unit_rows(nq, 768, 197)
+    os_, oi = oracle.flat_ip_topk(corpus, queries, k, id_base=7000)
+    want = oracle.reweight(os_, oi, levels, id_base=7000)
+    idx = IcdIndex(corpus, levels, max_nq=128, max_k=k, id_base=7000)       # (max_nq < nq: the wrapper / the library slice)
+    dq = torch.from_numpy(queries).cuda()
+    uid = group_unique_id()
+    assert len(uid) == 128 and any(uid)
+    for mode in (GROUP_ROW_SHARD, GROUP_QUERY_SHARD):
+        for with_comm in (True, False):
+            grp = IcdGroup(idx, mode, rank=0, world=1, unique_id=group_unique_id() if with_comm else None)
+            adj, raw, ids, lv = grp.search(dq, k)
+            torch.cuda.synchronize()
+            assert np.array_equal(ids.cpu().numpy(), want[2]) and _bits(adj.cpu().numpy()) == _bits(want[0])
+            assert _bits(raw.cpu().numpy()) == _bits(want[1]) and np.array_equal(lv.cpu().numpy(), want[3])
+            grp.close()
+    with pytest.raises(ValueError):
+        IcdGroup(idx, GROUP_ROW_SHARD, rank=0, world=2)                      # more than one rank needs rank 0's id
+    idx.close()
+
+
 def test_query_sharded_search_single_rank_nccl_and_config3_share(oracle):
     """BASELINE configs[3]: the corpus replicated, the query batch sharded over the ranks (QUERY_SHARD over the HIP index,
     RCCL group of one rank here; two ranks in tests/test_sharded_cpu.py), at the per-GPU share of the config: 125 000
@@ -560,6 +595,162 @@ def test_config2_shape_batched_equals_one_at_a_time(tmp_path, monkeypatch):
             assert a.score == b.score and a.enhanced_score == b.enhanced_score and a.original_score == b.original_score
             assert a.similarity_factors == b.similarity_factors and a.title == b.title
         assert got.match_confidence == one.match_confidence
+
+
+def _tight_family_corpus(nfam, per, dim, spread, nq, seed):
+    """families of near-identical rows IN CODE ORDER, the shape the ICD corpus has (semantic_text repeats the ancestors'
+    names, /root/reference/tools/build_database.py:156-171): spread 0.10 -> mutual cosine 0.99"""
+    rng = np.random.default_rng(seed)
+    cent = rng.standard_normal((nfam, dim)).astype(np.float32)
+    x = np.repeat(cent, per, axis=0) + spread * rng.standard_normal((nfam * per, dim)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    q = cent[rng.integers(0, nfam, nq)] + spread * rng.standard_normal((nq, dim)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return np.ascontiguousarray(x, dtype=np.float32), np.ascontiguousarray(q, dtype=np.float32)
+
+
+@pytest.mark.parametrize("k", [10, 20])
+def test_family_corpus_is_certified_within_the_call(oracle, k):
+    """300 families x 124 rows of mutual cosine 0.99, 10 000 queries, a FRESH index, no icd_index_set_chunks: the first
+    coarse pass gives a query 5-8 lists of 16 candidates, fewer than its family has rows inside 2 eps of each other, so it
+    certifies nothing; the second coarse pass (flagged queries only, ~20 lists each, sized on the device) must certify them
+    inside the same call: <= 1 % of the batch on the exact re-search, bit-exact results, a few ms per batch (8.9 / 18 ms
+    per batch when every query took the exact re-search). The next large batch starts with the wide partition."""
+    import time
+    import torch
+    corpus, queries = _tight_family_corpus(300, 124, 768, 0.10, 10000, 7)
+    n = corpus.shape[0]
+    levels = icd_levels(n, 8)
+    idx = IcdIndex(corpus, levels, max_nq=10000, max_k=20)
+    dq = torch.from_numpy(queries).cuda()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    adj, raw, ids, lv = idx.search_reweighted(dq, k)                  # the FIRST large batch of the index
+    torch.cuda.synchronize()
+    first_ms = (time.perf_counter() - t0) * 1e3
+    st = idx.stats()
+    assert st["last_mode"] == MODE_AUTO and st["wide_mode"] == 0
+    assert st["last_second_pass"] >= 0.9 * len(queries) and st["last_second_pass_lists"] >= 16   # the first pass certified (almost) nothing
+    assert st["last_fallback"] <= 0.01 * len(queries), st                                        # ... the second nearly everything
+    sample = np.arange(0, len(queries), 10)
+    os_, oi = oracle.flat_ip_topk(corpus, queries[sample], k)
+    want = oracle.reweight(os_, oi, levels)
+    assert np.array_equal(ids.cpu().numpy()[sample], want[2]) and _bits(adj.cpu().numpy()[sample]) == _bits(want[0])
+    assert _bits(raw.cpu().numpy()[sample]) == _bits(want[1])
+    # the second large batch: planned wide from the start (the counters of the first one have arrived), same results
+    a2, r2, i2, l2 = idx.search_reweighted(dq, k)
+    torch.cuda.synchronize()
+    st2 = idx.stats()
+    assert st2["wide_mode"] == 1 and st2["last_second_pass_lists"] == 0 and st2["last_fallback"] <= 0.01 * len(queries)
+    assert torch.equal(i2, ids) and torch.equal(a2, adj) and torch.equal(r2, raw)
+    for _ in range(3):
+        idx.search_reweighted(dq, k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        idx.search_reweighted(dq, k)
+    torch.cuda.synchronize()
+    wide_ms = (time.perf_counter() - t0) / 5 * 1e3
+    print(f"family corpus k={k}: first batch {first_ms:.2f} ms (second pass for {st['last_second_pass']} queries, {st['last_fallback']} exact), "
+          f"wide-mode batches {wide_ms:.2f} ms")
+    assert first_ms < 6.0 and wide_ms < 3.0
+    # a Gaussian batch on the same index is still exact (wide mode costs speed, never results), and a small batch is untouched
+    g = unit_rows(4000, 768, 99)
+    _check(oracle, idx, corpus, levels, g[:300], k, MODE_AUTO)
+    idx.close()
+
+
+def test_second_pass_switch_and_gaussian_batches_skip_it(oracle):
+    """Gaussian data: nothing is flagged, the second pass's two launches find an empty list, wide mode never turns on;
+    with the switch off a family corpus takes the exact re-search like before and returns the same bits"""
+    import torch
+    corpus, levels, queries = unit_rows(20000, 768, 5), icd_levels(20000, 6), unit_rows(4096, 768, 7)
+    idx = IcdIndex(corpus, levels, max_nq=4096, max_k=10)
+    for _ in range(2):
+        st = _check(oracle, idx, corpus, levels, queries[:2500], 10, MODE_AUTO)
+        assert st["last_second_pass"] == 0 and st["wide_mode"] == 0 and st["last_fallback"] == 0 and st["last_second_pass_lists"] > 0
+    idx.close()
+    fc, fq = _tight_family_corpus(100, 124, 768, 0.10, 6000, 11)           # 6 000 queries x 97 tiles: 6-7 lists of 16 per query
+    fl = icd_levels(len(fc), 12)
+    idx = IcdIndex(fc, fl, max_nq=6000, max_k=10)
+    a1 = [t.cpu().numpy() for t in idx.search_reweighted(torch.from_numpy(fq).cuda(), 10)]
+    st1 = idx.stats()
+    idx.set_second_pass(False)
+    a0 = [t.cpu().numpy() for t in idx.search_reweighted(torch.from_numpy(fq).cuda(), 10)]
+    st0 = idx.stats()
+    assert st0["last_second_pass_lists"] == 0 and st0["last_fallback"] >= st1["last_second_pass"] > 0
+    assert all(_bits(x) == _bits(y) for x, y in zip(a0, a1))
+    os_, oi = oracle.flat_ip_topk(fc, fq[:200], 10)
+    assert np.array_equal(a1[2][:200], oracle.reweight(os_, oi, fl)[2])
+    idx.close()
+
+
+def test_device_hier_rescoring_matches_host():
+    """icd_hier_rescore ALONE (through the C ABI) against HierarchicalSimilarityService.batch_calculate_similarities - the
+    host method the reference-generated fixture pins (tests/golden/hier_cases.json, test_golden_host_logic.py) - on all
+    1 000 golden diagnosis strings + 5 edge strings: final order, enhanced score, the record's score after the uncertainty
+    boost, the applied boost, and the six similarity factors, bit for bit (Python doubles). The hit lists are synthetic
+    (the search is not under test): 20 live-shaped hits per string with adjusted scores on both sides of the 0.95 / 1.0
+    rules, negative scores, exact ties (stable order), codes of every chapter, ".9" codes and hit lists shorter than k.
+    Reference: services/hierarchical_similarity_service.py:475-518,520-579, services/uncertainty_diagnosis_service.py:190-238."""
+    import torch
+    from conftest import GOLDEN
+    from rag_project_icd10_amd.services.hierarchical_similarity_service import HierarchicalSimilarityService, SimilarityFactors
+    strings = [l.strip() for l in open(os.path.join(GOLDEN, "diagnosis_strings.txt"), encoding="utf-8") if l.strip()]
+    strings = strings + ["待查", "？", " 疑似 ", "肺炎待查", "高血压 糖尿病 肿瘤 感染"]
+    nq, k, nrows = len(strings), 20, 6000
+    assert nq == 1005
+    rng = np.random.default_rng(99)
+    letters = "ABCEIJKNSZQ"
+    # unique codes (a hit is found again by its code): every chapter letter of the table and two outside it; one code in
+    # five matches the uncertainty service's \\.9\\d*$ (".9" + digits), the others have another digit behind the dot or a
+    # letter at the end; every 17th is a level-1 shaped code without a dot
+    codes = []
+    for i in range(nrows):
+        L = letters[i % 11]
+        if i % 17 == 0:
+            codes.append(f"{L}{i:05d}")
+        elif i % 5 == 0:
+            codes.append(f"{L}{i % 100:02d}.9{i:05d}" if i % 10 else f"{L}{i % 100:02d}.9")   # (".9" itself is not unique: see below)
+        else:
+            codes.append(f"{L}{i % 100:02d}.{(i // 3) % 9}{i:05d}" + ("x" if i % 13 == 0 else ""))
+    seen = set()
+    for i, c in enumerate(codes):                                                         # the bare ".9" codes repeat: keep the first of each
+        if c in seen:
+            codes[i] = f"{c}{i:05d}"
+        seen.add(codes[i])
+    assert len(set(codes)) == nrows
+    recs = [{"code": c, "preferred_zh": f"合成{i}", "level": 1 + i % 3, "parent_code": "", "category_path": "", "semantic_text": ""}
+            for i, c in enumerate(codes)]
+    ids = np.stack([rng.choice(nrows, k, replace=False) for _ in range(nq)]).astype(np.int64)
+    adj = np.sort(rng.uniform(0.2, 1.25, (nq, k)), axis=1)[:, ::-1].copy()               # search order: adjusted score descending
+    adj[::7, 3] = adj[::7, 2]                                                            # exact ties
+    adj[5::11, :4] = np.asarray([0.97, 0.9500000000000001, 0.95, 0.9499999999999999])    # around the > 0.95 rule
+    adj[3::13, -2:] = [-0.01, -0.3]                                                      # negative adjusted scores
+    raw = (adj / 1.2).astype(np.float32)
+    ids[9::19, 15:] = -1                                                                 # short hit lists (n < k): padded with -1
+    adj[9::19, 15:] = -np.inf
+    hs = HierarchicalSimilarityService()
+    tags = torch.from_numpy(np.asarray([hs.row_tag(c) for c in codes], np.uint8)).cuda()
+    order, enh, score, vs, hb, boost = hs.rescore_live_hits_batch(strings, torch.from_numpy(adj).cuda(), torch.from_numpy(ids).cuda(), tags)
+    order, enh, score, vs, hb, boost = (t.cpu().numpy() for t in (order, enh, score, vs, hb, boost))
+    sc = 0.3 if hs.embedding_service else 0.5
+    for q, text in enumerate(strings):
+        nhit = int((ids[q] >= 0).sum())
+        hits = [{"code": recs[i]["code"], "title": recs[i]["preferred_zh"], "score": float(adj[q, j]), "original_score": float(raw[q, j]),
+                 "metadata": {"level": recs[i]["level"], "parent_code": "", "category_path": "", "semantic_text": "",
+                              "has_complication": False, "main_code": "", "secondary_code": ""}}
+                for j, i in enumerate(ids[q][:nhit])]
+        pos = {h["code"]: j for j, h in enumerate(hits)}
+        want = hs.batch_calculate_similarities(text, {}, [dict(h) for h in hits])
+        assert len(want) == nhit and (order[q, nhit:] < 0).all(), text
+        ctx = hs.query_params(text)[1]
+        for j, (rec, s_host, f_host) in enumerate(want):
+            assert order[q, j] == pos[rec["code"]], (text, j)                            # final order (stable sorts included)
+            assert enh[q, j] == s_host == rec["enhanced_score"], (text, j)               # bit-exact doubles
+            assert score[q, j] == rec["score"], (text, j)                                # after the uncertainty boost
+            assert boost[q, j] == rec.get("uncertainty_boost", 0.0), (text, j)
+            assert SimilarityFactors(vs[q, j], hb[q, j], 0.0, sc, 0.0, ctx) == f_host, (text, j)
 
 
 def test_services_end_to_end_on_gpu(oracle, tmp_path, monkeypatch):

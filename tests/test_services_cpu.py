@@ -240,38 +240,3 @@ def test_corpus_store_stale_handle_never_truncates_committed_rows(tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), "icd10", ".lock"))
 
 
-def test_large_batches_ask_for_more_candidate_lists_after_a_mass_fallback():
-    """MilvusService.search_batch: the fallback count of the previous LARGE batch decides whether large batches get ~20
-    candidate lists per query (icd_index_set_chunks) - small batches never do, a rebuilt index starts over."""
-    from rag_project_icd10_amd.services.milvus_service import MilvusService
-
-    class StubIndex:
-        def __init__(self):
-            self.calls, self.last = [], {"last_nq": 0, "last_fallback": 0}
-        def stats(self):
-            return dict(self.last)
-        def set_chunks(self, c):
-            self.calls.append(c)
-
-    svc = MilvusService.__new__(MilvusService)
-    idx = StubIndex()
-    svc._adapt_candidate_lists(idx, 10000)                        # first large batch: automatic partition
-    idx.last = {"last_nq": 10000, "last_fallback": 3}             # ... which certified nearly everything
-    svc._adapt_candidate_lists(idx, 10000)
-    assert idx.calls == [0, 0]
-    idx.last = {"last_nq": 10000, "last_fallback": 9000}          # a corpus of tight families: mass fallback
-    svc._adapt_candidate_lists(idx, 300)                          # small batches keep the automatic partition
-    svc._adapt_candidate_lists(idx, 4096)
-    assert idx.calls == [0, 0, 0, 20]
-    idx.last = {"last_nq": 4096, "last_fallback": 0}
-    svc._adapt_candidate_lists(idx, 16)                           # (and it stays on for large batches only)
-    svc._adapt_candidate_lists(idx, 16384)
-    assert idx.calls[-2:] == [0, 20]
-    idx2 = StubIndex()                                            # a rebuilt index starts over
-    svc._adapt_candidate_lists(idx2, 8000)
-    assert idx2.calls == [0]
-    idx.last = {"last_nq": 100, "last_fallback": 100}             # a small batch's fallbacks never switch it on
-    svc2 = MilvusService.__new__(MilvusService)
-    svc2._adapt_candidate_lists(idx, 100)
-    svc2._adapt_candidate_lists(idx, 5000)
-    assert idx.calls[-1] == 0
