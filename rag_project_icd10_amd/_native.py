@@ -342,7 +342,9 @@ class IcdGroup:
         self._lib = load_library()
         self._h = C.c_void_p()
         self.index, self.mode, self.rank, self.world = index, int(mode), int(rank), int(world)
-        self.max_nq = int(max_nq or index.max_nq)
+        # (row-sharded: every rank searches the whole slice, so a slice is at most the index's max_nq; query-sharded: a
+        #  slice of world x max_nq queries gives every rank max_nq of them)
+        self.max_nq = int(max_nq or (index.max_nq if mode == GROUP_ROW_SHARD else index.max_nq * max(1, world)))
         self.max_k = int(max_k or min(index.max_k, 1024 // max(1, world) if mode == GROUP_ROW_SHARD else index.max_k))
         idbuf = None
         if world > 1 and unique_id is None:
@@ -355,30 +357,31 @@ class IcdGroup:
                                                       self.world, self.mode, self.max_nq, self.max_k, C.byref(self._h)))
 
     def search(self, queries, k: int = 10, gather: bool = True):
-        """-> (adj f64, raw f32, ids i64, levels i32), each [nq, k] CUDA tensors (query-sharded with gather=False: only the
-        first hi - lo rows, this rank's slice, are written and returned)"""
+        """-> (adj f64, raw f32, ids i64, levels i32), each [nq, k] CUDA tensors (query-sharded with gather=False: only
+        this rank's rows). Batches larger than the group's max_nq go through in slices of that many queries."""
         import torch
         q, on_dev = self.index._prep_queries(queries)
         if not on_dev:
             q = torch.from_numpy(q).to(torch.device("cuda", self.index.device))
-        nq = int(q.shape[0])
-        dev = q.device
-        outs_n = nq
-        if self.mode == GROUP_QUERY_SHARD and not gather:
-            base, rem = divmod(nq, self.world)
-            outs_n = base + (1 if self.rank < rem else 0)
-        adj = torch.empty((max(nq, 1), k), dtype=torch.float64, device=dev)
-        raw = torch.empty((max(nq, 1), k), dtype=torch.float32, device=dev)
-        ids = torch.empty((max(nq, 1), k), dtype=torch.int64, device=dev)
-        lv = torch.empty((max(nq, 1), k), dtype=torch.int32, device=dev)
-        for s0 in range(0, max(nq, 1), self.max_nq if self.mode == GROUP_ROW_SHARD else max(nq, 1)):
-            qs = q[s0:s0 + self.max_nq] if self.mode == GROUP_ROW_SHARD else q
+        nq, dev = int(q.shape[0]), q.device
+        local_only = self.mode == GROUP_QUERY_SHARD and not gather
+        parts = []
+        for s0 in range(0, max(nq, 1), self.max_nq):
+            qs = q[s0:s0 + self.max_nq]
             m = int(qs.shape[0])
+            outs = (torch.empty((m, k), dtype=torch.float64, device=dev), torch.empty((m, k), dtype=torch.float32, device=dev),
+                    torch.empty((m, k), dtype=torch.int64, device=dev), torch.empty((m, k), dtype=torch.int32, device=dev))
             if m:
-                _check(self._lib, self._lib.icd_group_search(self._h, qs.data_ptr(), m, k, 1 if gather else 0, adj[s0:].data_ptr(),
-                                                              raw[s0:].data_ptr(), ids[s0:].data_ptr(), lv[s0:].data_ptr(),
+                _check(self._lib, self._lib.icd_group_search(self._h, qs.data_ptr(), m, k, 1 if gather else 0, *[o.data_ptr() for o in outs],
                                                               _current_stream_ptr(self.index.device)))
-        return adj[:outs_n], raw[:outs_n], ids[:outs_n], lv[:outs_n]
+            keep = m
+            if local_only:
+                base, rem = divmod(m, self.world)
+                keep = base + (1 if self.rank < rem else 0)
+            parts.append(tuple(o[:keep] for o in outs))
+        if len(parts) == 1:
+            return parts[0]
+        return tuple(torch.cat([p[i] for p in parts]) for i in range(4))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

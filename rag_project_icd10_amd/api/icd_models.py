@@ -48,6 +48,45 @@ class Candidate(BaseModel):
         return None if value is None else convert_numpy_types(value)
 
 
+_CAND_FIELDS = frozenset(("code", "title", "score", "level", "parent_code", "enhanced_score", "original_score", "similarity_factors"))
+_trusted_ok: Optional[bool] = None
+
+
+def _trusted_candidate_unchecked(code, title, score, enhanced_score, original_score, similarity_factors) -> "Candidate":
+    c = Candidate.__new__(Candidate)
+    object.__setattr__(c, "__dict__", {"code": code, "title": title, "score": score, "level": 1, "parent_code": "",
+                                       "enhanced_score": enhanced_score, "original_score": original_score,
+                                       "similarity_factors": similarity_factors})
+    object.__setattr__(c, "__pydantic_fields_set__", set(_CAND_FIELDS))
+    object.__setattr__(c, "__pydantic_extra__", None)
+    object.__setattr__(c, "__pydantic_private__", None)
+    return c
+
+
+def trusted_candidate(code: str, title: str, score: float, enhanced_score: float, original_score: float, similarity_factors) -> "Candidate":
+    """A Candidate of a live hit (level 1, parent_code "": SURVEY F8) from values that are ALREADY what the validator would
+    produce - Python str / float straight from the batched device path - without one validator call per object
+    (10 000 of them per 1 000-string request: 33 -> 9 ms). The one rule with teeth is applied here: score >= 0
+    (models/icd_models.py:71 of the reference; a negative score must fail like the validated constructor does).
+    The first call checks that the object equals the validated constructor's, field for field and in model_dump();
+    if this pydantic lays its objects out differently, every call goes through the validated constructor instead."""
+    global _trusted_ok
+    if score < 0.0 or score != score:
+        return Candidate(code=code, title=title, score=score)   # raises the ValidationError the reference's path raises
+    if _trusted_ok is None:
+        try:
+            a = _trusted_candidate_unchecked(code, title, score, enhanced_score, original_score, similarity_factors)
+            b = Candidate(code=code, title=title, score=score, level=1, parent_code="", enhanced_score=enhanced_score,
+                          original_score=original_score, similarity_factors=similarity_factors)
+            _trusted_ok = bool(a == b and a.model_dump() == b.model_dump() and a.model_fields_set == b.model_fields_set)
+        except Exception:
+            _trusted_ok = False
+    if not _trusted_ok:
+        return Candidate(code=code, title=title, score=score, level=1, parent_code="", enhanced_score=enhanced_score,
+                         original_score=original_score, similarity_factors=similarity_factors)
+    return _trusted_candidate_unchecked(code, title, score, enhanced_score, original_score, similarity_factors)
+
+
 class DiagnosisMatch(BaseModel):
     model_config = ConfigDict(arbitrary_types_allowed=True)
     diagnosis_text: str = Field(..., description="提取的诊断文本")

@@ -31,6 +31,8 @@ struct FinArgs {
     int dense_grid, dense_bmq, dense_max_p, n_rows;   // dense_max_p > 0: exact_topk chose its chunk count on the device
     int lds_cand;       // candidate slots the launch's LDS was sized for (0: P * KP)
     int lists_by_query; // with qlist: the lists (and bounds) of slot s belong to query qlist[s] and sit at that query's index
+    int skip_below;     // with qlist + nq_ptr: at most this many slots -> this stage is skipped; the slot list is handed on
+                        // unchanged to the stage behind it (flagged / nflag), which is cheaper for a handful of queries
     int wide_window;    // fast path: rescoring window as wide as the instantiation allows (second chance of a query whose
                         // first window overflowed with near-ties), not the one sized for k
     int nq;             // slots (upper bound if nq_ptr)
@@ -210,6 +212,13 @@ __global__ __launch_bounds__(256, (EWM == 1 && !DEEP) ? 7 : 1) void finalize_ker
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nq = a.nq_ptr ? min(*a.nq_ptr, a.nq) : a.nq;
+    if (RESCORE && a.skip_below > 0 && nq <= a.skip_below) {   // (kernel-uniform) hand the slot list on as it is
+        if (blockIdx.x == 0 && a.qlist) {
+            for (int i = threadIdx.x; i < nq; i += blockDim.x) a.flagged[i] = a.qlist[i];
+            if (threadIdx.x == 0) *a.nflag = nq;
+        }
+        return;
+    }
     const int slot = blockIdx.x * 4 + wave;
     if (slot >= nq) return;  // wave-uniform; no work-group barriers below
     const int qidx = a.qlist ? a.qlist[slot] : slot;

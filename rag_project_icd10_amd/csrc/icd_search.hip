@@ -69,6 +69,7 @@ constexpr int FAST_MAX_K = 100;      // the rescoring window holds up to 256 can
 constexpr int COARSE_MAX_P = 32;     // P * KP <= FIN_MAX_CAND
 constexpr int PASS2_CHUNKS = 20;     // second coarse pass (and wide_mode): about this many candidate lists per query
 constexpr int PASS2_MAX_P = 24;      // ... at most this many (workspace); 24 x 16 candidates < FIN_MAX_CAND
+constexpr int PASS2_SKIP = 24;       // ... and leaves this many flagged queries (or fewer) to the streaming kernel: 35 us per 8
 constexpr int PASS2_BELOW = 320;     // the second pass runs when the first gave a query fewer candidates than this
 constexpr int WIDE_MIN_NQ = 2048;    // "large batch": below it a query has 16+ lists anyway
 constexpr int WIDE_REPROBE = 64;
@@ -734,13 +735,14 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             const int w_in = x->fallback_word;
             a2.nq_ptr = x->nflag + w_in;
             a2.qlist = x->flagged + (size_t)w_in * x->max_nq_pad;
+            a2.skip_below = PASS2_SKIP;
             const int grid2 = std::max(8, std::min(nwg2, x->num_cu) & ~7);
             if (x->dim == 1024) rc = launch_coarse_flat<1024, (CF_PRODUCT_VAR & (3 | 16 | 2048)), CO_KP, true>(x, a2, grid2, s);
             else rc = launch_coarse_flat<768, CF_PRODUCT_VAR, CO_KP, true>(x, a2, grid2, s);
             if (rc) return rc;
             FinArgs g3 = g;
             g3.part_scores = x->part2_s; g3.part_rows = x->part2_r; g3.bounds = x->part2_b; g3.P = p2; g3.KP = CO_KP;
-            g3.qlist = a2.qlist; g3.nq_ptr = a2.nq_ptr; g3.lists_by_query = 0; g3.wide_window = 1;
+            g3.qlist = a2.qlist; g3.nq_ptr = a2.nq_ptr; g3.lists_by_query = 0; g3.wide_window = 1; g3.skip_below = PASS2_SKIP;
             g3.nflag = x->nflag + 2; g3.flagged = x->flagged + (size_t)2 * x->max_nq_pad;
             rc = launch_finalize_t<true, false, 4>(x, g3, s);
             if (rc) return rc;
@@ -876,7 +878,8 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
         const int kcap = std::min(max_k, FAST_MAX_K);
         const int lists_for_max_k = std::min(COARSE_MAX_P, std::max(6, (std::min(kcap, 64) + 3) / 4 + 4));
         const int wide_for_max_k = kcap > 64 ? std::min(FIN_MAX_CAND / CO_KP_WIDE, (kcap + 5) / 6 + 4) : 0;
-        x->partc_cap = std::max<size_t>((size_t)x->max_nq_pad * std::max(lists_for_max_k * CO_KP, wide_for_max_k * CO_KP_WIDE),
+        // (+ the wide partition of large batches on family-shaped corpora, wide_mode: PASS2_MAX_P lists of CO_KP)
+        x->partc_cap = std::max<size_t>((size_t)x->max_nq_pad * std::max(std::max(lists_for_max_k, PASS2_MAX_P) * CO_KP, wide_for_max_k * CO_KP_WIDE),
                                         (size_t)1 << 20);
         CR_TRY(wsalloc(&x->partc_s, x->partc_cap));
         CR_TRY(wsalloc(&x->partc_r, x->partc_cap));

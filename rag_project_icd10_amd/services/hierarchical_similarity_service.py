@@ -36,6 +36,15 @@ class SimilarityFactors:
             setattr(self, name, float(getattr(self, name)))
 
 
+def trusted_factors(vs: float, hb: float, em: float, sc: float, ca: float, cr: float) -> SimilarityFactors:
+    """SimilarityFactors from six values that are Python floats already (the batched device path's tolist()): the same
+    object as SimilarityFactors(...) without the six float() coercions of __post_init__"""
+    f = object.__new__(SimilarityFactors)
+    f.__dict__.update(vector_similarity=vs, hierarchy_boost=hb, entity_match_score=em, semantic_coherence=sc,
+                      category_alignment=ca, context_relevance=cr)
+    return f
+
+
 @dataclass
 class HierarchyInfo:
     level: int = 1

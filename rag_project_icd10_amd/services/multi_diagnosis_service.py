@@ -16,7 +16,7 @@ from typing import Any, Dict, List
 
 import numpy as np
 
-from ..api.icd_models import Candidate, DiagnosisMatch
+from ..api.icd_models import Candidate, DiagnosisMatch, trusted_candidate
 from ..tools.text_processor import DiagnosisTextProcessor
 from .hierarchical_similarity_service import HierarchicalSimilarityService
 from .multidimensional_confidence_service import MultiDimensionalConfidenceService
@@ -85,7 +85,7 @@ class MultiDiagnosisService:
         confidence_statistics=True (row N3) also fills DiagnosisMatch.confidence_factors with the three numbers of the
         reference's confidence service that are in scope - semantic_coherence (the live shape: cosine with the embedding
         of the empty string), model_uncertainty, prediction_variance - computed for the whole batch in two launches."""
-        from .hierarchical_similarity_service import SimilarityFactors
+        from .hierarchical_similarity_service import trusted_factors
         if not diagnoses:
             return []
         if vectors is None:
@@ -123,13 +123,13 @@ class MultiDiagnosisService:
                         break
                     rec = recs[h_ids[q][j]]
                     s = h_enh[q][j]
-                    # live hits carry level / parent_code under "metadata": the top-level defaults apply (F8). One validated
-                    # construction (pydantic's compiled validator is faster than model_construct); a negative score fails
-                    # Candidate's ge=0 and degrades the whole match to an empty one, like the reference's
-                    cands.append(Candidate(
-                        code=rec.get("code", ""), title=rec.get("preferred_zh", ""), score=s, level=1, parent_code="",
-                        enhanced_score=s, original_score=h_adj[q][j] if h_boost[q][j] > 0 else h_raw[q][j],
-                        similarity_factors=SimilarityFactors(h_vs[q][j], h_hb[q][j], 0.0, sc, 0.0, ctx)))
+                    # live hits carry level / parent_code under "metadata": the top-level defaults apply (F8). The values
+                    # are Python floats / str already (tolist() of the device results): trusted_candidate skips the per-object
+                    # validator but keeps its one rule with teeth - a negative score raises and degrades the whole match to an
+                    # empty one, like the reference's
+                    cands.append(trusted_candidate(rec.get("code", ""), rec.get("preferred_zh", ""), s, s,
+                                                   h_adj[q][j] if h_boost[q][j] > 0 else h_raw[q][j],
+                                                   trusted_factors(h_vs[q][j], h_hb[q][j], 0.0, sc, 0.0, ctx)))
                 out.append(DiagnosisMatch(diagnosis_text=diagnosis, candidates=cands,
                                           match_confidence=self._calculate_match_confidence(cands),
                                           confidence_factors=conf[q] if conf is not None else None))

@@ -1,4 +1,4 @@
-# round 3: GPU suite, kernel trace of the second pass with few / all queries flagged
+# round 3: GPU suite, kernel trace of the second pass with few / all queries flagged, the timed full build
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -9,4 +9,6 @@ for sp in 0.35 0.10; do
   for f in $(find $R/gpurun_out/prof_p2_$sp -name "*kernel_stats.csv"); do cp $f $R/gpurun_out/p2_kernel_stats_$sp.csv; done
 done
 cd $R
+(timeout 900 python scripts/bench_build.py 2> gpurun_out/build_full.err) > gpurun_out/build_full.json
 cat gpurun_out/pytest_gpu.log; for sp in 0.35 0.10; do tail -2 gpurun_out/p2_trace_$sp.log | cut -c1-300; head -12 gpurun_out/p2_kernel_stats_$sp.csv | cut -c1-200; done
+tail -5 gpurun_out/build_full.err; head -60 gpurun_out/build_full.json

@@ -3,7 +3,8 @@ corpus has: semantic_text repeats the ancestors' names), for the serving path's 
 tightnesses. Gaussian unit rows never fail the certificate; this is where the fallback paths decide the latency."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import icd_levels
 from rag_project_icd10_amd._native import IcdIndex, MODE_AUTO
 

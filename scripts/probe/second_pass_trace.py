@@ -3,7 +3,8 @@ rocprofv3 --kernel-trace --stats): 300 families x 124 rows, spread 0.35 (about 1
 tight families (all flagged)."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests"); sys.path.insert(0, "scripts/probe")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "scripts", "probe"))
 from conftest import icd_levels
 from family_corpus_probe import family
 from rag_project_icd10_amd._native import IcdIndex, MODE_AUTO

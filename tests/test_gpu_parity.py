@@ -202,8 +202,9 @@ def test_tight_families_are_certified_by_the_wide_window(oracle, k):
 
 def test_more_lists_certify_tight_families_in_a_large_batch(oracle):
     """4 096 queries have 8 candidate lists of 16: fewer candidates than a 124-row family of near-identical rows has
-    members, so most queries take the exact re-search; with ~20 lists per query (icd_index_set_chunks, what
-    MilvusService.search_batch asks for after such a batch) none does. Bit-identical results either way."""
+    members, so most queries fail the first pass's certificate (and, with the second coarse pass switched off, take the
+    exact re-search); with ~20 lists per query (icd_index_set_chunks: the partition the second pass and wide mode use)
+    none does. Bit-identical results either way."""
     rng = np.random.default_rng(7)
     cent = rng.standard_normal((300, 768)).astype(np.float32)
     corpus = np.repeat(cent, 124, axis=0) + 0.1 * rng.standard_normal((300 * 124, 768)).astype(np.float32)
@@ -212,6 +213,7 @@ def test_more_lists_certify_tight_families_in_a_large_batch(oracle):
     queries = np.ascontiguousarray(queries / np.linalg.norm(queries, axis=1, keepdims=True), dtype=np.float32)
     levels = icd_levels(corpus.shape[0], 9)
     idx = IcdIndex(corpus, levels, max_nq=4096, max_k=20)
+    idx.set_second_pass(False)
     s0, i0 = idx.search(queries, 20, MODE_AUTO)
     assert idx.stats()["last_fallback"] > 0.5 * 4096
     idx.set_chunks(20)

@@ -240,3 +240,24 @@ def test_corpus_store_stale_handle_never_truncates_committed_rows(tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), "icd10", ".lock"))
 
 
+
+
+def test_trusted_candidate_equals_the_validated_constructor():
+    """the batched path builds its 10 000 Candidates per request without one validator call each: same objects, same
+    model_dump, and the one rule with teeth (score >= 0, models/icd_models.py:71 of the reference) still raises"""
+    from pydantic import ValidationError
+    from rag_project_icd10_amd.api import icd_models
+    from rag_project_icd10_amd.api.icd_models import Candidate, DiagnosisMatch, trusted_candidate
+    from rag_project_icd10_amd.services.hierarchical_similarity_service import SimilarityFactors, trusted_factors
+    f = trusted_factors(0.68, 0.089, 0.0, 0.3, 0.0, 0.95)
+    assert f == SimilarityFactors(0.68, 0.089, 0.0, 0.3, 0.0, 0.95) and type(f.vector_similarity) is float
+    a = trusted_candidate("I21.9", "急性心肌梗死", 1.719, 1.719, 0.85, f)
+    b = Candidate(code="I21.9", title="急性心肌梗死", score=1.719, level=1, parent_code="", enhanced_score=1.719, original_score=0.85,
+                  similarity_factors=SimilarityFactors(0.68, 0.089, 0.0, 0.3, 0.0, 0.95))
+    assert icd_models._trusted_ok is True                      # this pydantic lays objects out as assumed: the fast path is on
+    assert a == b and a.model_dump() == b.model_dump() and a.model_dump_json() == b.model_dump_json()
+    m = DiagnosisMatch(diagnosis_text="x", candidates=[a, b], match_confidence=0.9)
+    assert m.model_dump()["candidates"][0] == m.model_dump()["candidates"][1]
+    for bad in (-0.01, float("nan")):
+        with pytest.raises(ValidationError):
+            trusted_candidate("A00", "霍乱", bad, bad, 0.1, f)
