@@ -496,7 +496,8 @@ def run_rowshard(ctx, args, index_factory=hip_index_factory, sharded_factory=Non
             "config": {"workload": f"BASELINE configs[4]: {ctx.world} x {n} rows x {dim} corpus row-sharded (generated on device), "
                                    f"{nq} queries replicated, top_k={k}, slices of {sl}: local top-k -> all_gather -> merge + reweight",
                        "rows_per_gpu": n, "corpus_rows_total": ctx.world * n, "queries": nq, "slice": sl, "dim": dim, "top_k": k,
-                       "parallelism": f"row-sharded x{ctx.world}", "collective": "all_gather_into_tensor (RCCL)" if ctx.world > 1 else "none (one shard)",
+                       "parallelism": f"row-sharded x{ctx.world}", "collective": ("ncclAllGather inside icd_group_search (C ABI, RCCL opened by the library)" if getattr(sharded, "native_group", None) is not None
+                                      else "all_gather_into_tensor (torch.distributed)") if ctx.world > 1 else "none (one shard)",
                        "collective_ranks": dist.get_world_size() if ctx.world > 1 else 1},
             "whole_job_tflops": ctx.world * flops_gpu * steps / elapsed / 1e12,
             "ids_exact_on_sample": ids_ok, "raw_scores_exact_on_sample": raw_ok, "adjusted_sorted": sorted_ok,

@@ -265,6 +265,9 @@ __device__ __forceinline__ void compact_all_parallel(char *smem, Sel2 &st, uint3
 //        group 0 of the odd ones, after which lane l holds 64 scores of query l & 31 again (rows 16 rg + 8 (l >> 5) + 0..7)
 //        and the two-lane select below runs unchanged
 //   32 / 2048  every 16 / 24 tiles all four waves compact ALL their queries at once (compact_all_parallel) at the tile end
+//   131072 __builtin_amdgcn_s_setprio(1) behind every stage barrier, (0) in front of the next (cdna_hip_programming.md T5: on the
+//        8-phase GEMM template the pair keeps hipcc from moving MFMAs across the raw barriers; here the sched_barrier(0)
+//        pins already do that and one wave per SIMD has nobody to take priority from: A/B in profiles/r03_ab_setprio.log)
 //   TIMING ONLY (the results are not the scores; they size the parts of the kernel, profiles/r02_coarse_loop_decomposition.log):
 //   256 no s_barrier   512 no wait for the LDS-DMA pieces   4096 thresholds at +inf (nothing passes)
 //   8192 no select at all   16384 no LDS-DMA inside the tile loop   65536 (with 32768) no lane swaps
@@ -292,6 +295,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     constexpr bool PF2 = (VAR & 128) != 0;
     constexpr bool REV_WAIT = (VAR & 4) != 0;
     constexpr bool QUAD = (VAR & 16) != 0;
+    constexpr bool SETPRIO = (VAR & 131072) != 0;
     constexpr bool X16 = (VAR & 32768) != 0;   // v_mfma_f32_16x16x32_f16: a wave's 32 queries as two groups of 16 (see the VAR list)
     static_assert(!X16 || (QUAD && (VAR & 8) != 0 && D % 32 == 0), "the 16x16x32 form is built on the quad select and pinned queries");
     constexpr int EPOCH = ((VAR & 32) && (VAR & 2048)) ? 32 : ((VAR & 32) ? 16 : ((VAR & 2048) ? 24 : 0));   // tiles between the synchronised compactions of all queries
@@ -582,7 +586,9 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                 } else if constexpr (NOBAR) {
                     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(VM_MID) : "memory");
                 } else {
+                    if constexpr (SETPRIO) __builtin_amdgcn_s_setprio(0);
                     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(VM_MID) : "memory");
+                    if constexpr (SETPRIO) __builtin_amdgcn_s_setprio(1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (EARLY_THR && ks == KS - 2) {

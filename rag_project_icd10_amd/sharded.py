@@ -23,6 +23,7 @@ Two engines behind one class:
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Optional, Tuple
 
 import torch
@@ -78,8 +79,9 @@ class ShardedSearch:
     def from_index(cls, index, mode: str, group=None, native: Optional[bool] = None) -> "ShardedSearch":
         """index: rag_project_icd10_amd._native.IcdIndex over this rank's shard (row mode, created with
         id_base = first global row) or over the full corpus (query mode).
-        native (default: yes unless the process group's backend is not nccl): run the sharded search through the C ABI's
-        icd_group_* (RCCL inside the library); otherwise torch.distributed collectives between the library's kernels."""
+        native (default: yes unless the process group's backend is not nccl, or ICD_SHARDED_ENGINE=torch): run the sharded
+        search through the C ABI's icd_group_* (RCCL inside the library); otherwise torch.distributed collectives between
+        the library's kernels."""
         from . import _native
 
         def search_fn(q, k):
@@ -89,7 +91,7 @@ class ShardedSearch:
         self = cls(mode, search_fn=search_fn, merge_fn=_native.merge_topk,
                    local_reweighted_fn=index.search_reweighted, group=group)
         if native is None:
-            native = self.world == 1 or dist.get_backend(group) == "nccl"
+            native = os.environ.get("ICD_SHARDED_ENGINE", "native") != "torch" and (self.world == 1 or dist.get_backend(group) == "nccl")
         if native:
             uid = None
             if self.world > 1:   # rank 0's RCCL unique id travels through the existing process group (128 bytes)
