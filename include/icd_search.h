@@ -87,6 +87,9 @@ typedef struct icd_stats {
     int32_t last_mode;
     int64_t last_second_pass;   /* queries the first coarse pass could not certify and the second one took (AUTO mode) */
     int32_t last_second_pass_lists; /* candidate lists per query of that second pass (0: it was not part of the call) */
+    int32_t second_pass_armed;  /* 1: the next large search carries the second pass's launches (armed for the first searches of
+                                   an index and after any search that flagged more than the streaming kernel takes cheaply;
+                                   dropped after a few consecutive searches that flagged fewer) */
     int32_t wide_mode;          /* 1: large batches are planned with the second pass's list count from the start (the
                                    previous large batch needed the second pass for most of its queries) */
 } icd_stats;

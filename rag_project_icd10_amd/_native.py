@@ -52,7 +52,7 @@ class _Stats(C.Structure):
                 ("max_nq", C.c_int32), ("max_k", C.c_int32), ("fast_path", C.c_int32), ("rmax", C.c_float),
                 ("last_nq", C.c_int64), ("last_fallback", C.c_int64), ("last_chunks", C.c_int32),
                 ("last_mode", C.c_int32), ("last_second_pass", C.c_int64), ("last_second_pass_lists", C.c_int32),
-                ("wide_mode", C.c_int32)]
+                ("second_pass_armed", C.c_int32), ("wide_mode", C.c_int32)]
 
 
 class _Profile(C.Structure):

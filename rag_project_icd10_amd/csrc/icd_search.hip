@@ -71,6 +71,7 @@ constexpr int PASS2_CHUNKS = 20;     // second coarse pass (and wide_mode): abou
 constexpr int PASS2_MAX_P = 24;      // ... at most this many (workspace); 24 x 16 candidates < FIN_MAX_CAND
 constexpr int PASS2_SKIP = 24;       // ... and leaves this many flagged queries (or fewer) to the streaming kernel: 35 us per 8
 constexpr int PASS2_BELOW = 320;     // the second pass runs when the first gave a query fewer candidates than this
+constexpr int PASS2_DISARM_AFTER = 4; // the second pass's two launches are dropped after this many consecutive searches that needed neither
 constexpr int WIDE_MIN_NQ = 2048;    // "large batch": below it a query has 16+ lists anyway
 constexpr int WIDE_REPROBE = 64;
 constexpr int NUM_EV = 6;
@@ -139,6 +140,12 @@ struct icd_index {
     bool wide_mode = false;        // plan the first pass with PASS2_CHUNKS lists per query
     int wide_runs = 0;             // large searches since wide_mode was entered (every WIDE_REPROBE-th runs narrow again)
     bool last_narrow_large = false; // the last search was a large batch with the narrow plan and the second pass behind it
+    // The second pass costs a search that flags nothing two launches that read a counter and leave (~9 us per 10 000-query
+    // step). They are armed while nothing is known about the corpus (the first searches of an index) and whenever a recent
+    // search flagged more queries than the streaming kernel takes cheaply; after PASS2_DISARM_AFTER consecutive searches
+    // that flagged fewer they are left out (a batch that then flags many takes the exact re-search once and re-arms them).
+    int p2_clean = 0;              // consecutive evaluated searches with <= PASS2_SKIP queries flagged by the first finalize
+    bool p2_eval_pending = false;  // the last search's counters have not been looked at yet
     bool pass2_enabled = true;     // test hook (icd_index_set_second_pass)
     bool adapt_enabled = true;     // ... 2 = second pass without the adaptive list count
     bool profiling = false;
@@ -527,7 +534,12 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     // start with the second pass's list count (1.5 instead of 2.2 ms per 10 000 queries there; 7 % slower on Gaussian data,
     // which is why it is not the default). Every WIDE_REPROBE-th large search runs narrow again and decides anew.
     const bool large = nq >= WIDE_MIN_NQ;
-    if (x->last_narrow_large && hipEventQuery(x->ev_nflag) == hipSuccess) {
+    const bool counters_in = (x->last_narrow_large || x->p2_eval_pending) && hipEventQuery(x->ev_nflag) == hipSuccess;
+    if (x->p2_eval_pending && counters_in) {
+        x->p2_clean = x->h_nflag[0] > PASS2_SKIP ? 0 : std::min(x->p2_clean + 1, 1 << 20);
+        x->p2_eval_pending = false;
+    }
+    if (x->last_narrow_large && counters_in) {
         const int f0 = x->h_nflag[0], f2 = x->h_nflag[2];
         const long long n_prev = x->last_nq;
         if (n_prev > 0) {
@@ -624,7 +636,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         // one list (the shape icd_index_set_chunks asks for). Everything the host must know is independent of how many
         // queries will be flagged: U2, the list slots per query (worst case over all query tiles of the full batch), the
         // logical work-group count of a full batch. The kernel sizes the sweep from the flagged count on the device.
-        if (x->pass2_enabled && P * kp_c < PASS2_BELOW && x->part2_s) {
+        if (x->pass2_enabled && x->p2_clean < PASS2_DISARM_AFTER && P * kp_c < PASS2_BELOW && x->part2_s) {
             int U2 = std::max(1, (ctiles + PASS2_CHUNKS - 1) / PASS2_CHUNKS);
             p2 = lists_needed_lt(U2, ctiles);
             while ((p2 > PASS2_MAX_P || (size_t)nq * p2 * CO_KP > x->part2_cap) && U2 < ctiles) {
@@ -750,6 +762,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             x->last_p2 = p2; x->last_p2_word = w_in;
         }
         x->last_narrow_large = x->adapt_enabled && large && p2 > 0 && !wide_now && x->chunks_override == 0;
+        x->p2_eval_pending = x->pass2_enabled && pc * kp_c < PASS2_BELOW;   // (a search the second pass applies to, armed or not)
     }
     rec(x, 3, s);
     const int *fl_list = x->flagged + (size_t)x->fallback_word * x->max_nq_pad;
@@ -1101,6 +1114,7 @@ int icd_index_stats(icd_index *idx, icd_stats *out) {
     out->last_second_pass = (idx->last_p2 > 0 && idx->h_nflag && idx->last_nq > 0) ? idx->h_nflag[idx->last_p2_word] : 0;
     out->last_second_pass_lists = idx->last_p2;
     out->wide_mode = idx->wide_mode ? 1 : 0;
+    out->second_pass_armed = (idx->pass2_enabled && idx->p2_clean < PASS2_DISARM_AFTER) ? 1 : 0;
     out->last_chunks = idx->last_chunks; out->last_mode = idx->last_mode;
     return ICD_OK;
 }
@@ -1115,6 +1129,7 @@ int icd_index_set_second_pass(icd_index *idx, int32_t enabled) {
     idx->pass2_enabled = enabled != 0;
     idx->adapt_enabled = enabled == 1;
     if (!idx->pass2_enabled || !idx->adapt_enabled) { idx->wide_mode = false; idx->last_narrow_large = false; }
+    idx->p2_clean = 0; idx->p2_eval_pending = false;   // (re-armed)
     return ICD_OK;
 }
 

@@ -687,6 +687,34 @@ def test_second_pass_switch_and_gaussian_batches_skip_it(oracle):
     idx.close()
 
 
+def test_second_pass_launches_are_dropped_after_clean_searches_and_rearmed(oracle):
+    """the second pass's two launches ride along while nothing is known about the corpus and after any search that flagged
+    more queries than the streaming kernel takes cheaply; a few consecutive clean searches drop them (a Gaussian corpus pays
+    nothing in steady state), one dirty search re-arms them. Results are exact in every state."""
+    import torch
+    corpus, levels, queries = unit_rows(20000, 768, 5), icd_levels(20000, 6), unit_rows(2500, 768, 7)
+    idx = IcdIndex(corpus, levels, max_nq=2500, max_k=10)
+    dq = torch.from_numpy(queries).cuda()
+    lists = []
+    for _ in range(7):
+        idx.search_reweighted(dq, 10)
+        st = idx.stats()                                   # (waits for the search: the next one sees its counters)
+        lists.append(st["last_second_pass_lists"])
+    assert all(x > 0 for x in lists[:4]) and all(x == 0 for x in lists[5:]), lists
+    assert idx.stats()["second_pass_armed"] == 0
+    zeros = torch.zeros((2500, 768), device="cuda")       # every score ties at 0: the first finalize certifies nothing
+    a0 = idx.search_reweighted(zeros, 10)
+    st = idx.stats()
+    assert st["last_second_pass_lists"] == 0 and st["last_fallback"] == 2500        # disarmed: straight to the exact re-search
+    a1 = idx.search_reweighted(zeros, 10)                                           # ... which re-armed the second pass
+    st = idx.stats()
+    assert st["last_second_pass_lists"] > 0 and st["second_pass_armed"] == 1
+    assert all(torch.equal(x, y) for x, y in zip(a0, a1))
+    assert bool((a0[2][:, 0] == 0).all()) and bool((a0[2][0] == torch.arange(10, device="cuda")).all())   # ties: row id ascending
+    _check(oracle, idx, corpus, levels, queries[:300], 10, MODE_AUTO)
+    idx.close()
+
+
 def test_device_hier_rescoring_matches_host():
     """icd_hier_rescore ALONE (through the C ABI) against HierarchicalSimilarityService.batch_calculate_similarities - the
     host method the reference-generated fixture pins (tests/golden/hier_cases.json, test_golden_host_logic.py) - on all
