@@ -50,6 +50,8 @@ struct FinArgs {
     int cexp;                    // the corpus's scale exponent
     int *nflag;    // fallback counter
     int *flagged;  // fallback list
+    const int *counters;   // nullable (last launch of a search): the search's four fallback counters ...
+    int *host_counters;    // ... are copied to this pinned host array by block 0 (icd_index_stats reads them after the stream's event)
     // level table
     const int *levels;  // [n] or null
     long long id_base;
@@ -202,15 +204,15 @@ __device__ __forceinline__ int fin_merge(const FinArgs &a, size_t pbase, int nca
     return nvalid;
 }
 
-// DEEP: the rescoring keeps 2 x 12 row pieces in flight per lane instead of 8 - fewer dependent round trips for a
-// launch whose waves all fit on the chip at once (latency matters), more registers / fewer resident waves for a
-// large one (throughput matters: measured slower at 10 000 queries). The host picks by the query count.
+// DEEP: (round 1-2: a deeper per-lane prefetch of the rescoring rows for small launches; the quad-cooperative walk below
+// made it moot - the parameter is kept so that the host's instantiation table stays as it is)
 // EWM: rescoring candidates per lane the instantiation can hold (1 for k <= 32: the common case keeps its registers and
 // resident waves; 4 for k up to 100).
 template <bool RESCORE, bool DEEP = false, int EWM = 4>
-__global__ __launch_bounds__(256, (EWM == 1 && !DEEP) ? 7 : 1) void finalize_kernel(FinArgs a) {   // (7 waves per SIMD: <= 72 VGPRs)
+__global__ __launch_bounds__(256, EWM == 1 ? 7 : 1) void finalize_kernel(FinArgs a) {   // (7 waves per SIMD: <= 72 VGPRs)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (!RESCORE && a.host_counters && blockIdx.x == 0 && threadIdx.x < 4) a.host_counters[threadIdx.x] = a.counters[threadIdx.x];
     const int nq = a.nq_ptr ? min(*a.nq_ptr, a.nq) : a.nq;
     if (RESCORE && a.skip_below > 0 && nq <= a.skip_below) {   // (kernel-uniform) hand the slot list on as it is
         if (blockIdx.x == 0 && a.qlist) {
@@ -314,69 +316,66 @@ __global__ __launch_bounds__(256, (EWM == 1 && !DEEP) ? 7 : 1) void finalize_ker
             }
             return;
         }
-        // 4. canonical rescoring of the window (scalar fmaf chain, d ascending)
-        const float4 *q4 = reinterpret_cast<const float4 *>(qvec);
-        const int n4 = a.dim >> 2;   // multiple of 8 (dim % 32 == 0)
-        auto chain = [&](uint32_t row) -> float {
-            const float4 *c4 = reinterpret_cast<const float4 *>(a.corpus + (size_t)row * a.dim);
-            float acc = 0.0f;
-            if constexpr (DEEP) {
-                constexpr int RB = 12;
-                float4 cur[RB], nxt[RB];
-                const int nb = n4 / RB * RB;   // (dims that are not a multiple of 48 floats finish in the plain loop)
-#pragma unroll
-                for (int j = 0; j < RB; ++j) cur[j] = c4[j < n4 ? j : 0];
-                for (int i0 = 0; i0 < nb; i0 += RB) {
-                    const bool more = i0 + 2 * RB <= nb;
-                    if (more) {
-#pragma unroll
-                        for (int j = 0; j < RB; ++j) nxt[j] = c4[i0 + RB + j];
-                    }
-#pragma unroll
-                    for (int j = 0; j < RB; ++j) {
-                        const float4 qv = q4[i0 + j];
-                        acc = __builtin_fmaf(qv.x, cur[j].x, acc);
-                        acc = __builtin_fmaf(qv.y, cur[j].y, acc);
-                        acc = __builtin_fmaf(qv.z, cur[j].z, acc);
-                        acc = __builtin_fmaf(qv.w, cur[j].w, acc);
-                    }
-                    if (more) {
-#pragma unroll
-                        for (int j = 0; j < RB; ++j) cur[j] = nxt[j];
-                    }
-                }
-                for (int i = nb; i < n4; ++i) {
-                    const float4 cv = c4[i];
-                    const float4 qv = q4[i];
-                    acc = __builtin_fmaf(qv.x, cv.x, acc);
-                    acc = __builtin_fmaf(qv.y, cv.y, acc);
-                    acc = __builtin_fmaf(qv.z, cv.z, acc);
-                    acc = __builtin_fmaf(qv.w, cv.w, acc);
-                }
-            } else {
-                // (deeper software prefetch of the row costs registers and with them resident waves: slower for big launches)
-#pragma unroll 8
-                for (int i = 0; i < n4; ++i) {
-                    const float4 cv = c4[i];
-                    const float4 qv = q4[i];
-                    acc = __builtin_fmaf(qv.x, cv.x, acc);
-                    acc = __builtin_fmaf(qv.y, cv.y, acc);
-                    acc = __builtin_fmaf(qv.z, cv.z, acc);
-                    acc = __builtin_fmaf(qv.w, cv.w, acc);
-                }
-            }
-            return acc;
-        };
+        // 4. canonical rescoring of the window (scalar fmaf chain, d ascending).
+        // The window is a PREFIX of the coarse ranking (rank = lane + 64 e): W rows. One lane walking its own 3 KB row costs 24
+        // dependent round trips (8 pieces of 16 B in flight) with a dozen lanes active and a dozen cache lines touched per
+        // load instruction. Here FOUR lanes share a row, 16 rows at a time: lane 4 g + i loads piece 4 b + i of every 64-B
+        // block b of row g - four times the bytes in flight per row, a quarter of the round trips and of the load
+        // instructions (finalize 0.098 -> 0.072 ms per 10 000 queries at k = 10). The chain stays strictly sequential in d:
+        // within a block all four lanes run their four fmaf from the SAME running value, then the quad adopts lane 0's
+        // result, repeats and adopts lane 1's, ... (one DPP quad broadcast per step; three of the four lanes' arithmetic is
+        // discarded each time, VALU slots this kernel has to spare). Same fmaf order, d ascending: the same bits.
         u64 xkey[EWM];
 #pragma unroll
         for (int e = 0; e < EWM; ++e) xkey[e] = 0ull;
+        {
+            int W = 0;
 #pragma unroll
-        for (int e = 0; e < EWM; ++e) {
-            if (e >= EW) break;
-            if (mine[e] != 0ull && coarse[e] >= L) {
-                const uint32_t row = key_row(mine[e]);
-                const float acc = chain(row);
-                if (acc == acc && acc != -INFINITY) xkey[e] = make_key(acc, row);
+            for (int e = 0; e < EWM; ++e) W += __popcll(__ballot(e < EW && mine[e] != 0ull && coarse[e] >= L));
+            const int gi = lane >> 2, qi = lane & 3;
+            float *hand = reinterpret_cast<float *>(adjbuf);   // (free until emit_outputs)
+            const int nblk = a.dim >> 4;   // 64-B blocks per row; a multiple of 8 for the fast path's dims (768, 1024)
+            for (int g0 = 0; g0 < W; g0 += 16) {
+                const int r = g0 + gi;
+                const uint32_t row = key_row(sorted[r < W ? r : g0]);   // (past the window: a valid row, result unused)
+                const f32x4 *c4 = reinterpret_cast<const f32x4 *>(a.corpus + (size_t)row * a.dim) + qi;
+                const f32x4 *q4q = reinterpret_cast<const f32x4 *>(qvec) + qi;
+                float acc = 0.0f;
+#define ICD_QUAD_STEP(ctrl)                                                                          \
+                    {                                                                                \
+                        float t = acc;                                                               \
+                        t = __builtin_fmaf(qv.x, cv.x, t);                                           \
+                        t = __builtin_fmaf(qv.y, cv.y, t);                                           \
+                        t = __builtin_fmaf(qv.z, cv.z, t);                                           \
+                        t = __builtin_fmaf(qv.w, cv.w, t);                                           \
+                        acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), ctrl, 0xf, 0xf, false)); \
+                    }
+                // (eight blocks = eight independent 16-B loads per lane in flight per trip; the inner trip count is a constant
+                //  because hipcc does not unroll a runtime-count loop around the convergent DPP move)
+                for (int b0 = 0; b0 < nblk; b0 += 8) {
+                    f32x4 cvv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) cvv[u] = c4[4 * (b0 + u)];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const f32x4 cv = cvv[u];
+                        const f32x4 qv = q4q[4 * (b0 + u)];
+                        ICD_QUAD_STEP(0x00)   // quad_perm [0,0,0,0]: everyone continues from lane 0's four steps
+                        ICD_QUAD_STEP(0x55)   // [1,1,1,1]
+                        ICD_QUAD_STEP(0xAA)   // [2,2,2,2]
+                        ICD_QUAD_STEP(0xFF)   // [3,3,3,3]
+                    }
+                }
+#undef ICD_QUAD_STEP
+                // every lane of quad g holds the score of rank g0 + g: hand it to the lane (and element) that owns that rank
+                if (qi == 0) hand[gi] = acc;   // (same wave: LDS serves its operations in order)
+                const int e_g = g0 >> 6, l0 = g0 & 63;
+                if (lane >= l0 && lane < l0 + 16 && g0 + (lane - l0) < W) {
+                    const float sc = hand[lane - l0];
+#pragma unroll
+                    for (int e = 0; e < EWM; ++e)
+                        if (e == e_g && sc == sc && sc != -INFINITY) xkey[e] = make_key(sc, key_row(mine[e]));
+                }
             }
         }
         // 5. rank the rescored candidates and keep the best k

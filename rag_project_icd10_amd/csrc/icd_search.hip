@@ -126,7 +126,8 @@ struct icd_index {
     float *lists_s = nullptr; int *lists_r = nullptr; size_t lists_cap = 0;   // streaming kernel: [slot][4 nwg][KP]
     int *nflag = nullptr; int *flagged = nullptr;   // fallback counters [4] and lists [3][max_nq_pad]: after the first finalize, after its wide-window retry, after the second coarse pass
     int fallback_word = 0;                           // which counter / list the last search's exact re-search read
-    int *h_nflag = nullptr;                          // pinned host copy of nflag[4], refreshed by every search (async, on its stream)
+    int *h_nflag = nullptr;                          // pinned (mapped) host copy of nflag[4], written by the last kernel of every search
+    int *h_nflag_dev = nullptr;                      // its device-side address
     hipEvent_t ev_nflag = nullptr;                   // recorded behind that copy: icd_index_stats waits for it and nothing else
     unsigned int *scratch_u32 = nullptr;  // [0]=rmax bits, [1]=any_bad
     // output staging (used when the caller's buffers are host memory)
@@ -476,6 +477,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         g.P_dense = px_dense; g.sparse_max = sparse_max; g.lds_cand = std::max(px, stream ? p_sparse : px_dense) * kpx;
         g.dense_grid = mtx * std::max(1, px_dense); g.dense_bmq = bmq; g.dense_max_p = (stream && mfma) ? p_sparse : 0; g.n_rows = (int)x->n;
         g.nq = nq; g.nq_ptr = nq_ptr; g.qlist = qlist;
+        g.counters = x->nflag; g.host_counters = x->h_nflag_dev;   // (the last launch of every search: no separate copy)
         rc = launch_finalize<false>(x, g, s);
         rec(x, 5, s);
         (void)ex;
@@ -918,8 +920,9 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     CR_TRY(wsalloc(&x->lists_r, x->lists_cap));
     CR_TRY(wsalloc(&x->nflag, 4));
     CR_TRY(hipMemset(x->nflag, 0, 4 * sizeof(int)));
-    CR_TRY(hipHostMalloc(reinterpret_cast<void **>(&x->h_nflag), 4 * sizeof(int), hipHostMallocDefault));
+    CR_TRY(hipHostMalloc(reinterpret_cast<void **>(&x->h_nflag), 4 * sizeof(int), hipHostMallocMapped));
     memset(x->h_nflag, 0, 4 * sizeof(int));
+    CR_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&x->h_nflag_dev), x->h_nflag, 0));
     CR_TRY(hipEventCreateWithFlags(&x->ev_nflag, hipEventDisableTiming));
     CR_TRY(wsalloc(&x->dbg, (size_t)8192 * 16));
     CR_TRY(hipMemset(x->dbg, 0, (size_t)8192 * 16 * 8));
@@ -971,9 +974,8 @@ static int search_common(icd_index *x, const float *queries, int64_t nq, int32_t
     int rc = search_device(x, dq, (int)nq, k, mode, dev, s);
     if (rc) return rc;
     rec(x, NUM_EV, s);
-    // the fallback counters travel to pinned host memory behind the search, on its stream: icd_index_stats reads them
-    // after waiting for THIS event only (no device-wide synchronisation: other streams - an encoder - keep running)
-    HIP_TRY(hipMemcpyAsync(x->h_nflag, x->nflag, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    // the search's last kernel has written the fallback counters to pinned host memory: icd_index_stats reads them after
+    // waiting for THIS event only (no device-wide synchronisation: other streams - an encoder - keep running)
     HIP_TRY(hipEventRecord(x->ev_nflag, s));
     if (!out_on_device) {
         const size_t no = (size_t)nq * k;

@@ -1,0 +1,9 @@
+(timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -6) > gpurun_out/pytest_gpu.log
+(timeout 600 python scripts/probe/family_corpus_probe.py large 2>&1 | grep -v amdgpu.ids | tail -18) > gpurun_out/family_probe_large.log
+(timeout 600 python scripts/gpu_fuzz.py --cases 48 --seed 31 2>&1 | tail -5) > gpurun_out/fuzz.log
+(timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | tail -1) > gpurun_out/bench.log
+cat gpurun_out/pytest_gpu.log; cut -c1-250 gpurun_out/family_probe_large.log; cat gpurun_out/fuzz.log; python - <<'PY'
+import json
+l=json.loads(open('gpurun_out/bench.log').read())
+print(l['value'], l['ms_per_step'], l['kernel_ms'], l['extra']['windows'], l['ids_exact'])
+PY
