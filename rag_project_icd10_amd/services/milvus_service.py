@@ -125,6 +125,14 @@ class MilvusService:
         self._row_tags = None
         self._loaded = False
 
+    def supports_device_rescoring(self) -> bool:
+        """True when search_batch returns device tensors that icd_hier_rescore can take (an index in HBM on a GPU)"""
+        try:
+            import torch
+            return torch.cuda.is_available() and self._ready_index() is not None
+        except Exception:
+            return False
+
     def row_tags(self):
         """uint8 [n] on the index's GPU: what the device-side hierarchical rescoring needs to know about each row's code
         (HierarchicalSimilarityService.row_tag); built on first use after a load."""

@@ -49,6 +49,22 @@ class MultiDiagnosisService:
                     "extraction_metadata": {"enhanced_results_count": 0, "avg_extraction_confidence": 0.0}}
         confs = [d.get("diagnosis_confidence", 0.5) for d in enhanced]
         # one encoder batch + one search batch for the whole request
+        matches = None
+        if self.ner_service is None and getattr(self.milvus_service, "supports_device_rescoring", lambda: False)():
+            # no entities to match (the reference's rescoring then depends on the query string and the hits' codes only):
+            # the whole request stays on the device - encode -> search(2 top_k) -> rescoring -> top_k winners come back.
+            # Same DiagnosisMatch objects as the host path below (tests/test_gpu_parity.py, all 1 000 golden strings).
+            try:
+                matches = self.match_diagnoses_batch(diagnoses, top_k=top_k)
+            except Exception as exc:
+                logger.error("device-side request path failed (%s): host path", exc)
+                matches = None
+        if matches is not None:
+            return {"original_text": text, "extracted_diagnoses": diagnoses, "matches": matches,
+                    "total_matches": sum(len(m.candidates) for m in matches), "processing_mode": mode,
+                    "extraction_metadata": {"enhanced_results_count": len(enhanced),
+                                            "avg_extraction_confidence": sum(confs) / len(confs),
+                                            "extraction_method": "simple", "drug_filtering_enabled": False}}
         vectors = self.embedding_service.encode_query_batch(diagnoses)
         try:
             hit_lists = self.milvus_service.search_batch(vectors, top_k * 2, as_dicts=True)

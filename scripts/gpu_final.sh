@@ -1,9 +1,14 @@
-# round-end evidence: tests, smoke, bench (default + rowshard), e2e, rocprof kernel stats + PMC passes
+# round-end evidence: tests, smoke, bench (default + rowshard), e2e, the timed full build, rocprof kernel stats + PMC passes
+# usage: scripts/gpu_final.sh r03
+TAG=${1:-r03}
 mkdir -p gpurun_out
 (timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -6) > gpurun_out/pytest_gpu.log
 (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3) > gpurun_out/smoke.log
-(timeout 600 python bench.py --steps 50 --warmup 5 2>&1 | tail -1) > gpurun_out/bench.log
-(timeout 600 python bench.py --workload rowshard --steps 3 2>&1 | tail -1) > gpurun_out/bench_rowshard.log
-(timeout 600 python scripts/bench_e2e.py 2>/dev/null | tail -50) > gpurun_out/e2e.json
-bash scripts/gpu_pmc.sh r02 > gpurun_out/pmc_r02.log 2>&1
-cat gpurun_out/pytest_gpu.log gpurun_out/smoke.log; cut -c1-600 gpurun_out/bench.log; cut -c1-300 gpurun_out/bench_rowshard.log; grep -A12 stages_ms gpurun_out/e2e.json; tail -25 gpurun_out/pmc_r02.log | cut -c1-400
+(timeout 900 python bench.py --steps 50 --warmup 5 2>/dev/null | tail -1) > gpurun_out/bench.log
+(timeout 600 python bench.py --workload rowshard --steps 3 2>/dev/null | tail -1) > gpurun_out/bench_rowshard.log
+(timeout 600 python scripts/bench_e2e.py 2>/dev/null | tail -60) > gpurun_out/e2e.json
+(timeout 600 python scripts/bench_build.py 2>/dev/null) > gpurun_out/build_full.json
+# two ranks on this box's ONE device: RCCL refuses duplicate devices; the gloo control flow with the HIP index on one device is what can run
+(ICD_BENCH_BACKEND=gloo ICD_BENCH_ONE_DEVICE=1 timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --rows-per-gpu 400000 --rowshard-queries 20000 2>&1 | tail -2) > gpurun_out/bench_2rank_one_device.log
+bash scripts/gpu_pmc.sh $TAG > gpurun_out/pmc_$TAG.log 2>&1
+cat gpurun_out/pytest_gpu.log gpurun_out/smoke.log; cut -c1-700 gpurun_out/bench.log; cut -c1-400 gpurun_out/bench_rowshard.log; grep -A14 stages_ms gpurun_out/e2e.json; cut -c1-600 gpurun_out/bench_2rank_one_device.log; tail -30 gpurun_out/pmc_$TAG.log | cut -c1-400

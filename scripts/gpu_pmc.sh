@@ -1,38 +1,57 @@
 # rocprofv3 evidence for profiles/: kernel trace + stats of bench.py, then PMC counters in SEPARATE passes
-# (never combined with a trace domain other than --kernel-trace). usage: scripts/gpu_pmc.sh r02
-TAG=${1:-r02}
+# (never combined with a trace domain other than --kernel-trace). usage: scripts/gpu_pmc.sh r03
+TAG=${1:-r03}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/rocprof_bench_$TAG.log 2>&1
+# (1) per-kernel durations of the default bench line (with its extras: the real size, the clustered data, --mode exact)
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/rocprof_bench_$TAG.log 2>&1
+# (2) PMC passes of the headline workload alone
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
   d=$R/gpurun_out/pmc_${TAG}_$(echo $set | cut -d' ' -f1)
-  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $d -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $d.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $d -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --repeats 0 > $d.log 2>&1
+done
+# (3) the row-sharded workload (one 1.25 M-row shard): kernel stats + HBM traffic of a coarse launch
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_rowshard -- python3 $R/bench.py --workload rowshard --steps 1 --rowshard-steps 1 > $R/gpurun_out/rocprof_rowshard_$TAG.log 2>&1
+for set in "FETCH_SIZE" "WRITE_SIZE"; do
+  d=$R/gpurun_out/pmcrs_${TAG}_$set
+  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $d -- python3 $R/bench.py --workload rowshard --steps 1 --rowshard-steps 1 > $d.log 2>&1
 done
 cd $R
 python3 - $TAG <<'PY'
 import csv, glob, collections, json, sys
 tag = sys.argv[1]
-out = {}
-for f in sorted(glob.glob(f'gpurun_out/pmc_{tag}_*/**/*counter_collection.csv', recursive=True)):
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for row in csv.DictReader(open(f)):
-        agg[row.get('Kernel_Name', '')][row['Counter_Name']].append(float(row['Counter_Value']))
-    for k, v in agg.items():
-        for c, x in v.items():
-            out.setdefault(k, {})[c] = sum(x) / len(x)
+def collect(pattern):
+    out = {}
+    for f in sorted(glob.glob(pattern, recursive=True)):
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for row in csv.DictReader(open(f)):
+            agg[row.get('Kernel_Name', '')][row['Counter_Name']].append(float(row['Counter_Value']))
+        for k, v in agg.items():
+            for c, x in v.items():
+                out.setdefault(k, {})[c] = sum(x) / len(x)
+    return out
+def traffic_of(out):
+    t = {}
+    for k, v in out.items():
+        if 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
+            # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request: doubled (MI355X_MICROARCH.md, HBM)
+            t[k] = {"fetch_size_kib": v['FETCH_SIZE'], "write_size_kib": v['WRITE_SIZE'],
+                    "traffic_bytes": 2 * v['FETCH_SIZE'] * 1024 + v['WRITE_SIZE'] * 1024}
+    return t
+out = collect(f'gpurun_out/pmc_{tag}_*/**/*counter_collection.csv')
 json.dump(out, open(f'gpurun_out/{tag}_pmc_counters.json', 'w'), indent=1)
-traffic = {}
-for k, v in out.items():
-    if 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
-        # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request: doubled (MI355X_MICROARCH.md, HBM)
-        traffic[k] = {"fetch_size_kib": v['FETCH_SIZE'], "write_size_kib": v['WRITE_SIZE'],
-                      "traffic_bytes": 2 * v['FETCH_SIZE'] * 1024 + v['WRITE_SIZE'] * 1024}
-json.dump(traffic, open(f'gpurun_out/{tag}_pmc_traffic.json', 'w'), indent=1)
+json.dump(traffic_of(out), open(f'gpurun_out/{tag}_pmc_traffic.json', 'w'), indent=1)
+rs = collect(f'gpurun_out/pmcrs_{tag}_*/**/*counter_collection.csv')
+json.dump(traffic_of(rs), open(f'gpurun_out/{tag}_pmc_traffic_rowshard.json', 'w'), indent=1)
 for k, v in out.items():
     if 'coarse' in k or 'finalize_kernel<true' in k:
         print(k[:70], {c: round(x, 1) for c, x in v.items()})
+for k, v in traffic_of(rs).items():
+    if 'coarse' in k:
+        print('rowshard', k[:70], v)
 PY
-for f in $(find gpurun_out/prof_$TAG -name "*kernel_stats.csv"); do head -12 $f; cp $f gpurun_out/${TAG}_bench_kernel_stats.csv; done
+for f in $(find gpurun_out/prof_$TAG -name "*kernel_stats.csv"); do head -14 $f; cp $f gpurun_out/${TAG}_bench_kernel_stats.csv; done
+for f in $(find gpurun_out/prof_${TAG}_rowshard -name "*kernel_stats.csv"); do head -6 $f; cp $f gpurun_out/${TAG}_rowshard_kernel_stats.csv; done
 tail -1 gpurun_out/rocprof_bench_$TAG.log | cut -c1-400

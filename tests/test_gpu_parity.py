@@ -823,6 +823,14 @@ def test_services_end_to_end_on_gpu(oracle, tmp_path, monkeypatch):
     from rag_project_icd10_amd.services.multi_diagnosis_service import MultiDiagnosisService
     res = MultiDiagnosisService(es, ms).match_multiple_diagnoses("霍乱，伤寒；副伤寒", top_k=3)
     assert res["extracted_diagnoses"] == ["霍乱", "伤寒", "副伤寒"] and res["total_matches"] == 9
+    # /query's request path stays on the device when there are no entities to match; the host path (dict marshalling +
+    # batch_calculate_similarities per diagnosis, the reference's own shape) must give the same DiagnosisMatch objects
+    assert ms.supports_device_rescoring()
+    ms.supports_device_rescoring = lambda: False
+    res_host = MultiDiagnosisService(es, ms).match_multiple_diagnoses("霍乱，伤寒；副伤寒", top_k=3)
+    del ms.supports_device_rescoring
+    assert [m.model_dump() for m in res["matches"]] == [m.model_dump() for m in res_host["matches"]]
+    assert {k: v for k, v in res.items() if k != "matches"} == {k: v for k, v in res_host.items() if k != "matches"}
     for m in res["matches"]:
         single = ms.search(es.encode_query(m.diagnosis_text), 6)
         assert {c.code for c in m.candidates} <= {h["code"] for h in single}
