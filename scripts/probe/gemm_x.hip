@@ -1,0 +1,151 @@
+// gemm_x.hip — probe for a different decomposition of the coarse pass ("design X"): is a plain
+// Q x C^T sweep with TWO waves per SIMD and BOTH operands streamed through LDS faster on this chip than the shipped loop
+// (queries in registers, one wave per SIMD: 1 141 TFLOP/s without any select)?
+//
+//   work-group   8 waves (2 per SIMD), tile = 256 queries x 128 corpus rows, BK = 64 halves per stage
+//   wave (qg, rh) 64 queries x 64 rows: 4 x 4 accumulators of v_mfma_f32_16x16x32_f16 (64 VGPRs); per k-step of 32 it
+//                reads 4 row fragments + 4 query fragments (ds_read_b128) for 16 MFMAs: 0.5 reads per MFMA, as the product
+//   stage        48 KB = 16 KB of rows + 32 KB of queries by LDS-DMA (6 one-KiB pieces per wave), 16-B chunks XOR-swizzled
+//                on the source side; ring of S stages; one raw s_barrier per stage, counted vmcnt
+//   sweep        work-group w takes query tile w / LISTS and the row tiles [t0, t1) of its list, like the product's lists
+// No select, no output but a checksum: this measures the ceiling of the decomposition, nothing else.
+//   hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form=1 -o gemm_x gemm_x.hip && ./gemm_x
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int D = 768, BK = 64, KS = D / BK;
+constexpr int TQ = 256, TR = 128;
+constexpr int A_BYTES = TR * BK * 2, B_BYTES = TQ * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;   // 16 KB + 32 KB
+
+template <int S>
+__global__ __launch_bounds__(512, 1) void gemm_x(const _Float16 *q16, const _Float16 *c16, int ctiles, int tiles_per_wg, int lists, float *out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qg = wave & 3, rh = wave >> 2;
+    const int r16 = lane & 15, g16 = lane >> 4;
+    const int mtile = blockIdx.x / lists, li = blockIdx.x % lists;
+    const int t0 = li * tiles_per_wg, t1 = min(ctiles, t0 + tiles_per_wg);
+    if (t0 >= t1) return;
+    // LDS-DMA source offsets of this wave's six pieces of a stage: A pieces 2w, 2w+1 (8 rows each), B pieces 4w .. 4w+3
+    uint32_t a_off[2], b_off[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 8 + (lane >> 3);
+        a_off[i] = (uint32_t)row * (D * 2) + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        b_off[i] = (uint32_t)row * (D * 2) + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+    }
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(c16), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(q16) + (size_t)mtile * TQ * D, 0, 0x7FFFFFFF, 0x00020000);
+    auto issue = [&](int tile, int ks, int slot) {
+        char *sb = smem + slot * STAGE_BYTES;
+        const int trow = min(tile, ctiles - 1);
+        const uint32_t asoff = (uint32_t)trow * (uint32_t)(TR * D * 2) + (uint32_t)ks * (BK * 2);
+        const uint32_t bsoff = (uint32_t)ks * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(crs, (__attribute__((address_space(3))) void *)(sb + (wave * 2 + i) * 1024), 16, a_off[i], asoff, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (__attribute__((address_space(3))) void *)(sb + A_BYTES + (wave * 4 + i) * 1024), 16, b_off[i], bsoff, 0, 0);
+    };
+    // fragment read offsets inside a stage: row / query r16 of a 16-group, chunk 4 k2 + g16
+    uint32_t rd[2];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) rd[k2] = (uint32_t)r16 * 128u + (uint32_t)(((4 * k2 + g16) ^ ((r16 >> 1) & 7)) * 16);
+    const uint32_t a_base = (uint32_t)(rh * 64) * 128u, b_base = (uint32_t)A_BYTES + (uint32_t)(qg * 64) * 128u;
+
+    f32x4 acc[4][4];
+    float keep = 0.f;
+    const int ntiles = t1 - t0, nstages = ntiles * KS;
+    // prologue
+#pragma unroll
+    for (int p = 0; p < S - 1; ++p) issue(t0 + p / KS, p % KS, p % S);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(6 * (S - 2)) : "memory");
+    for (int g = 0; g < nstages; ++g) {
+        const int ks = g % KS, slot = g % S;
+        if (ks == 0) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
+        }
+        {   // every wave is past stage g-1: its slot takes stage g+S-1
+            const int n = g + S - 1;
+            issue(t0 + n / KS, n % KS, n % S);
+        }
+        const char *sb = smem + slot * STAGE_BYTES;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            half8 af[4], bf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const half8 *>(sb + a_base + rd[k2] + t * 2048);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bf[t] = *reinterpret_cast<const half8 *>(sb + b_base + rd[k2] + t * 2048);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        if (ks == KS - 1) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) keep += acc[a][b][0] + acc[a][b][3];
+        }
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(6 * (S - 2)) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    out[blockIdx.x * 512 + tid] = keep;
+}
+
+int main(int argc, char **argv) {
+    const int nq = 10240, n = 37120, ctiles = n / TR, mtiles = nq / TQ;   // 40 query tiles x 290 row tiles
+    const int iters = 20;
+    std::vector<_Float16> hq((size_t)nq * D), hc((size_t)(n + TR) * D);
+    srand(1);
+    for (auto &x : hq) x = (_Float16)((rand() / (float)RAND_MAX) * 2.f - 1.f);
+    for (auto &x : hc) x = (_Float16)((rand() / (float)RAND_MAX) * 2.f - 1.f);
+    _Float16 *dq, *dc; float *o;
+    hipMalloc(&dq, hq.size() * 2); hipMalloc(&dc, hc.size() * 2);
+    hipMemcpy(dq, hq.data(), hq.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dc, hc.data(), hc.size() * 2, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    // 40 query tiles: 256 work-groups ~ 6.4 lists per query tile -> tiles per work-group so that the grid is ~256 (one round)
+    for (int lists : {6, 7, 13}) {
+        const int tiles_per_wg = (ctiles + lists - 1) / lists;
+        const int grid = mtiles * lists;
+        hipMalloc(&o, (size_t)grid * 512 * 4);
+        for (int S : {2, 3}) {
+            const size_t lds = (size_t)S * STAGE_BYTES;
+            auto launch = [&]() {
+                if (S == 2) hipLaunchKernelGGL(gemm_x<2>, dim3(grid), dim3(512), lds, 0, dq, dc, ctiles, tiles_per_wg, lists, o);
+                else hipLaunchKernelGGL(gemm_x<3>, dim3(grid), dim3(512), lds, 0, dq, dc, ctiles, tiles_per_wg, lists, o);
+            };
+            if (S == 2) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_x<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            else hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_x<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            for (int w = 0; w < 100; ++w) launch();
+            hipDeviceSynchronize();
+            hipError_t err = hipGetLastError();
+            if (err != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(err)); return 1; }
+            hipEventRecord(e0);
+            for (int it = 0; it < iters; ++it) launch();
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            const double flop = 2.0 * nq * (double)n * D * iters;
+            printf("lists %2d (grid %3d, %2d tiles per work-group) S=%d: %.4f ms per launch, %.0f TFLOP/s (%.3f of 2500)\n", lists, grid, tiles_per_wg, S,
+                   ms / iters, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 2500.0);
+        }
+        hipFree(o);
+    }
+    return 0;
+}

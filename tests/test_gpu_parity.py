@@ -554,6 +554,28 @@ def test_query_sharded_search_single_rank_nccl_and_config3_share(oracle):
         dist.destroy_process_group()
 
 
+def test_config4_per_gpu_share_at_full_size():
+    """BASELINE configs[4] at its stated per-GPU size, through the bench's own leg: a 1 250 000 x 768 shard generated on the
+    device, the 100 000-query batch in slices of 16 384 through ShardedSearch(ROW) -> icd_group_search (local top-k, the
+    all-gather step, merge + reweight), one pass; the 64-query sample is checked against the oracle over the whole shard
+    (ids, raw and adjusted scores bit for bit), every slice's output is sorted, and nearly everything stays certified."""
+    import argparse
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        os.environ.pop(k, None)
+    ctx = bench.Ctx()
+    assert ctx.world == 1
+    args = argparse.Namespace(steps=1, warmup=1, k=10, rows_per_gpu=1_250_000, rowshard_queries=100_000, rowshard_slice=16384, rowshard_steps=1)
+    line = bench.run_rowshard(ctx, args)
+    assert line["config"]["queries"] == 100_000 and line["config"]["rows_per_gpu"] == 1_250_000 and "configs[4]" in line["config"]["workload"]
+    assert line["ids_exact_on_sample"] and line["raw_scores_exact_on_sample"] and line["adjusted_scores_exact_on_sample"] and line["adjusted_sorted"]
+    assert line["sample_queries"] == 64 and "oracle" in line["sample_checked_against"]
+    assert line["fallback_queries_last_slice"] <= 20 and line["value"] > 1e5 and 0.2 < line["roofline"]["frac"] < 1.0
+
+
 def test_config2_shape_batched_equals_one_at_a_time(tmp_path, monkeypatch):
     """BASELINE configs[2] at its stated size: the 1 000 golden diagnosis strings -> encoder on ROCm -> search over
     40 474 rows -> level reweight -> hierarchical rescoring. The batched path (one encoder batch, one search_batch, the
