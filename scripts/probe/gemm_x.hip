@@ -19,11 +19,14 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int D = 768, BK = 64, KS = D / BK;
-constexpr int TQ = 256, TR = 128;
-constexpr int A_BYTES = TR * BK * 2, B_BYTES = TQ * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;   // 16 KB + 32 KB
+constexpr int TQ = 256;
 
-template <int S>
-__global__ __launch_bounds__(512, 1) void gemm_x(const _Float16 *q16, const _Float16 *c16, int ctiles, int tiles_per_wg, int lists, float *out) {
+// RG = 16-row groups per wave: 4 -> tile of 128 rows (16 KB of rows + 32 KB of queries per stage), 8 -> 256 rows (32 + 32 KB:
+// half the LDS-DMA bytes per FLOP, 128 accumulator registers per wave - the geometry of the guide's 256 x 256 template)
+template <int S, int RG>
+__device__ __forceinline__ void gemm_x_body(const _Float16 *q16, const _Float16 *c16, int ctiles, int tiles_per_wg, int lists, float *out) {
+    constexpr int TR = 32 * RG, NA = TR / 64;   // rows per tile, A pieces per wave and stage
+    constexpr int A_BYTES = TR * BK * 2, B_BYTES = TQ * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -33,10 +36,10 @@ __global__ __launch_bounds__(512, 1) void gemm_x(const _Float16 *q16, const _Flo
     const int t0 = li * tiles_per_wg, t1 = min(ctiles, t0 + tiles_per_wg);
     if (t0 >= t1) return;
     // LDS-DMA source offsets of this wave's six pieces of a stage: A pieces 2w, 2w+1 (8 rows each), B pieces 4w .. 4w+3
-    uint32_t a_off[2], b_off[4];
+    uint32_t a_off[NA], b_off[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave * 2 + i) * 8 + (lane >> 3);
+    for (int i = 0; i < NA; ++i) {
+        const int row = (wave * NA + i) * 8 + (lane >> 3);
         a_off[i] = (uint32_t)row * (D * 2) + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
     }
 #pragma unroll
@@ -52,8 +55,8 @@ __global__ __launch_bounds__(512, 1) void gemm_x(const _Float16 *q16, const _Flo
         const uint32_t asoff = (uint32_t)trow * (uint32_t)(TR * D * 2) + (uint32_t)ks * (BK * 2);
         const uint32_t bsoff = (uint32_t)ks * (BK * 2);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(crs, (__attribute__((address_space(3))) void *)(sb + (wave * 2 + i) * 1024), 16, a_off[i], asoff, 0, 0);
+        for (int i = 0; i < NA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(crs, (__attribute__((address_space(3))) void *)(sb + (wave * NA + i) * 1024), 16, a_off[i], asoff, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (__attribute__((address_space(3))) void *)(sb + A_BYTES + (wave * 4 + i) * 1024), 16, b_off[i], bsoff, 0, 0);
@@ -62,20 +65,21 @@ __global__ __launch_bounds__(512, 1) void gemm_x(const _Float16 *q16, const _Flo
     uint32_t rd[2];
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) rd[k2] = (uint32_t)r16 * 128u + (uint32_t)(((4 * k2 + g16) ^ ((r16 >> 1) & 7)) * 16);
-    const uint32_t a_base = (uint32_t)(rh * 64) * 128u, b_base = (uint32_t)A_BYTES + (uint32_t)(qg * 64) * 128u;
+    const uint32_t a_base = (uint32_t)(rh * 16 * RG) * 128u, b_base = (uint32_t)A_BYTES + (uint32_t)(qg * 64) * 128u;
 
-    f32x4 acc[4][4];
+    f32x4 acc[RG][4];
     float keep = 0.f;
     const int ntiles = t1 - t0, nstages = ntiles * KS;
     // prologue
 #pragma unroll
     for (int p = 0; p < S - 1; ++p) issue(t0 + p / KS, p % KS, p % S);
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(6 * (S - 2)) : "memory");
+    constexpr int NP = NA + 4;   // LDS-DMA pieces per wave and stage
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(NP * (S - 2)) : "memory");
     for (int g = 0; g < nstages; ++g) {
         const int ks = g % KS, slot = g % S;
         if (ks == 0) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < RG; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
         }
@@ -86,66 +90,75 @@ __global__ __launch_bounds__(512, 1) void gemm_x(const _Float16 *q16, const _Flo
         const char *sb = smem + slot * STAGE_BYTES;
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
-            half8 af[4], bf[4];
+            half8 af[RG], bf[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const half8 *>(sb + a_base + rd[k2] + t * 2048);
+            for (int t = 0; t < RG; ++t) af[t] = *reinterpret_cast<const half8 *>(sb + a_base + rd[k2] + t * 2048);
 #pragma unroll
             for (int t = 0; t < 4; ++t) bf[t] = *reinterpret_cast<const half8 *>(sb + b_base + rd[k2] + t * 2048);
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < RG; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
         if (ks == KS - 1) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < RG; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) keep += acc[a][b][0] + acc[a][b][3];
         }
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(6 * (S - 2)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(NP * (S - 2)) : "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     out[blockIdx.x * 512 + tid] = keep;
 }
 
+#define ICD_GX(SV, RGV)                                                                                              \
+    __global__ __launch_bounds__(512, 1) void gemm_x_##SV##_##RGV(const _Float16 *q, const _Float16 *c, int ct, int tpw, int l, float *o) { \
+        gemm_x_body<SV, RGV>(q, c, ct, tpw, l, o);                                                                        \
+    }
+ICD_GX(2, 4)
+ICD_GX(3, 4)
+ICD_GX(2, 8)
+
+#define RUN_CASE(SV, RGV)                                                                                                   \
+    do {                                                                                                                    \
+        constexpr int TR = 32 * RGV;                                                                                        \
+        const int ctiles = n / TR, mtiles = nq / TQ;                                                                        \
+        const int tiles_per_wg = (ctiles + lists - 1) / lists, grid = mtiles * lists;                                       \
+        const size_t lds = (size_t)SV * (TR * BK * 2 + TQ * BK * 2);                                                        \
+        float *o;                                                                                                           \
+        hipMalloc(&o, (size_t)grid * 512 * 4);                                                                              \
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_x_##SV##_##RGV), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+        for (int w = 0; w < 100; ++w) hipLaunchKernelGGL(gemm_x_##SV##_##RGV, dim3(grid), dim3(512), lds, 0, dq, dc, ctiles, tiles_per_wg, lists, o); \
+        hipDeviceSynchronize();                                                                                             \
+        if (hipGetLastError() != hipSuccess) { printf("launch failed\n"); return 1; }                                       \
+        hipEventRecord(e0);                                                                                                 \
+        for (int it = 0; it < iters; ++it) hipLaunchKernelGGL(gemm_x_##SV##_##RGV, dim3(grid), dim3(512), lds, 0, dq, dc, ctiles, tiles_per_wg, lists, o); \
+        hipEventRecord(e1);                                                                                                 \
+        hipEventSynchronize(e1);                                                                                            \
+        float ms;                                                                                                           \
+        hipEventElapsedTime(&ms, e0, e1);                                                                                   \
+        hipFree(o);                                                                                                         \
+        const double flop = 2.0 * nq * (double)n * D * iters;                                                               \
+        printf("tile 256 x %3d, lists %2d (grid %3d, %2d tiles per work-group) S=%d (%3zu KB LDS): %.4f ms per launch, %.0f TFLOP/s (%.3f of 2500)\n", TR, \
+               lists, grid, tiles_per_wg, SV, lds / 1024, ms / iters, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 2500.0); \
+    } while (0)
+
 int main(int argc, char **argv) {
-    const int nq = 10240, n = 37120, ctiles = n / TR, mtiles = nq / TQ;   // 40 query tiles x 290 row tiles
-    const int iters = 20;
-    std::vector<_Float16> hq((size_t)nq * D), hc((size_t)(n + TR) * D);
+    const int nq = 10240, n = 37120, lists = 6, iters = 20;   // 40 query tiles x 290 / 145 row tiles; 240 work-groups
+    std::vector<_Float16> hq((size_t)nq * D), hc((size_t)(n + 256) * D);
     srand(1);
     for (auto &x : hq) x = (_Float16)((rand() / (float)RAND_MAX) * 2.f - 1.f);
     for (auto &x : hc) x = (_Float16)((rand() / (float)RAND_MAX) * 2.f - 1.f);
-    _Float16 *dq, *dc; float *o;
+    _Float16 *dq, *dc;
     hipMalloc(&dq, hq.size() * 2); hipMalloc(&dc, hc.size() * 2);
     hipMemcpy(dq, hq.data(), hq.size() * 2, hipMemcpyHostToDevice);
     hipMemcpy(dc, hc.data(), hc.size() * 2, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    // 40 query tiles: 256 work-groups ~ 6.4 lists per query tile -> tiles per work-group so that the grid is ~256 (one round)
-    for (int lists : {6, 7, 13}) {
-        const int tiles_per_wg = (ctiles + lists - 1) / lists;
-        const int grid = mtiles * lists;
-        hipMalloc(&o, (size_t)grid * 512 * 4);
-        for (int S : {2, 3}) {
-            const size_t lds = (size_t)S * STAGE_BYTES;
-            auto launch = [&]() {
-                if (S == 2) hipLaunchKernelGGL(gemm_x<2>, dim3(grid), dim3(512), lds, 0, dq, dc, ctiles, tiles_per_wg, lists, o);
-                else hipLaunchKernelGGL(gemm_x<3>, dim3(grid), dim3(512), lds, 0, dq, dc, ctiles, tiles_per_wg, lists, o);
-            };
-            if (S == 2) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_x<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            else hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_x<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            for (int w = 0; w < 100; ++w) launch();
-            hipDeviceSynchronize();
-            hipError_t err = hipGetLastError();
-            if (err != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(err)); return 1; }
-            hipEventRecord(e0);
-            for (int it = 0; it < iters; ++it) launch();
-            hipEventRecord(e1); hipEventSynchronize(e1);
-            float ms; hipEventElapsedTime(&ms, e0, e1);
-            const double flop = 2.0 * nq * (double)n * D * iters;
-            printf("lists %2d (grid %3d, %2d tiles per work-group) S=%d: %.4f ms per launch, %.0f TFLOP/s (%.3f of 2500)\n", lists, grid, tiles_per_wg, S,
-                   ms / iters, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 2500.0);
-        }
-        hipFree(o);
+    for (int rep = 0; rep < 2; ++rep) {
+        RUN_CASE(2, 4);
+        RUN_CASE(3, 4);
+        RUN_CASE(2, 8);
     }
     return 0;
 }
