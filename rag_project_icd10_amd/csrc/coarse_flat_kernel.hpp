@@ -267,7 +267,9 @@ __device__ __forceinline__ void compact_all_parallel(char *smem, Sel2 &st, uint3
 //   32 / 2048  every 16 / 24 tiles all four waves compact ALL their queries at once (compact_all_parallel) at the tile end
 //   131072 __builtin_amdgcn_s_setprio(1) behind every stage barrier, (0) in front of the next (cdna_hip_programming.md T5: on the
 //        8-phase GEMM template the pair keeps hipcc from moving MFMAs across the raw barriers; here the sched_barrier(0)
-//        pins already do that and one wave per SIMD has nobody to take priority from: A/B in profiles/r03_ab_setprio.log)
+//        pins already do that and one wave per SIMD has nobody to take priority from: A/B in profiles/r03_ab_setprio_and_exchange_interval.log)
+//   262144 / 524288  the shared-threshold exchange of a tile end (load of the query's published threshold, adopt or publish) only on
+//        every 2nd / 4th tile (and always on a list's last tile but one) instead of every tile
 //   TIMING ONLY (the results are not the scores; they size the parts of the kernel, profiles/r02_coarse_loop_decomposition.log):
 //   256 no s_barrier   512 no wait for the LDS-DMA pieces   4096 thresholds at +inf (nothing passes)
 //   8192 no select at all   16384 no LDS-DMA inside the tile loop   65536 (with 32768) no lane swaps
@@ -296,6 +298,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     constexpr bool REV_WAIT = (VAR & 4) != 0;
     constexpr bool QUAD = (VAR & 16) != 0;
     constexpr bool SETPRIO = (VAR & 131072) != 0;
+    constexpr int EXCH = (VAR & 524288) ? 4 : ((VAR & 262144) ? 2 : 1);   // tiles between two shared-threshold exchanges
     constexpr bool X16 = (VAR & 32768) != 0;   // v_mfma_f32_16x16x32_f16: a wave's 32 queries as two groups of 16 (see the VAR list)
     static_assert(!X16 || (QUAD && (VAR & 8) != 0 && D % 32 == 0), "the 16x16x32 form is built on the quad select and pinned queries");
     constexpr int EPOCH = ((VAR & 32) && (VAR & 2048)) ? 32 : ((VAR & 32) ? 16 : ((VAR & 2048) ? 24 : 0));   // tiles between the synchronised compactions of all queries
@@ -594,7 +597,9 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                 if constexpr (EARLY_THR && ks == KS - 2) {
                     // the query's shared threshold for the end of this tile: issued here, older than this stage's and the
                     // next stage's LDS-DMA pieces, so a counted wait at the tile end covers it without draining them
-                    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(seen_early) : "v"(my_shared) : "memory");
+                    if (EXCH == 1 || (tile & (EXCH - 1)) == EXCH - 1) {
+                        asm volatile("global_load_dword %0, %1, off sc1" : "=v"(seen_early) : "v"(my_shared) : "memory");
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (!NODMA) {   // every wave is past stage g-1: its slot takes stage g+S-1
@@ -651,7 +656,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             // A list still reports the threshold it ends on as its bound, and the largest bound over the lists - what
             // finalize certifies against - is the largest of the lists' OWN k'-th best scores with or without sharing;
             // the weaker lists just stop collecting rows that could never matter. Stale reads are harmless.
-            {
+            if (EXCH == 1 || (tile & (EXCH - 1)) == EXCH - 1) {
                 uint32_t seen;
                 if constexpr (EARLY_THR) {
                     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(seen_early) : "i"(NOVM ? 0 : 4 * (S - 2)) : "memory");

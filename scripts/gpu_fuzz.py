@@ -6,7 +6,9 @@
 Every case draws (rows, queries, dim, k, data kind, mode, id_base), searches through the C ABI and compares ids (exact),
 scores (bit-identical) and the reweighted outputs with oracle/ on a query sample. Data kinds: gaussian unit rows,
 clustered rows (near ties: forces the exact fallback), rows with exact duplicates, a batch whose fp16 image overflows,
-corpora and batches scaled far below fp16's normal range ("tiny").
+corpora and batches scaled far below fp16's normal range ("tiny"), corpora of tight families of near-identical rows in code
+order with large batches ("family": the first coarse pass certifies little, the second coarse pass / the wide-window retry
+must; the searches of one index alternate so that the armed, disarmed and wide-mode states all occur).
 """
 import argparse
 import os
@@ -27,6 +29,11 @@ def rows(rng, n, dim, kind):
     else:
         x = rng.standard_normal((n, dim)).astype(np.float32)
     x /= np.linalg.norm(x, axis=1, keepdims=True)
+    if kind == "family":      # families of ~124 near-identical rows, in code order (cosine ~0.99 within a family)
+        per = 124
+        cent = rng.standard_normal(((n + per - 1) // per, dim)).astype(np.float32)
+        x = np.repeat(cent, per, axis=0)[:n] + 0.1 * rng.standard_normal((n, dim)).astype(np.float32)
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
     if kind == "dups" and n > 20:
         src = rng.integers(0, n, n // 10)
         dst = rng.integers(0, n, n // 10)
@@ -47,15 +54,20 @@ def main():
     for case in range(args.cases):
         dim = int(rng.choice([768, 768, 768, 1024, 96, 256]))
         n = int(rng.choice([1, 7, 127, 128, 129, 1000, 4097, 20000, 37000, 100003]))
-        nq = int(rng.choice([1, 2, 9, 16, 17, 64, 65, 128, 129, 1000, 3000]))
+        nq = int(rng.choice([1, 2, 9, 16, 17, 64, 65, 128, 129, 1000, 3000, 6000]))
         k = int(rng.choice([1, 5, 10, 10, 10, 12, 13, 50, 100]))
-        kind = str(rng.choice(["gauss", "gauss", "clustered", "dups", "overflow", "zeros", "scaled", "tiny", "tiny"]))
+        kind = str(rng.choice(["gauss", "gauss", "clustered", "dups", "overflow", "zeros", "scaled", "tiny", "tiny", "family", "family"]))
+        if kind == "family":
+            dim, n, nq = int(rng.choice([768, 768, 1024])), int(rng.choice([4097, 20000, 37000])), int(rng.choice([1000, 3000, 6000]))
         mode = MODE_AUTO if rng.random() < 0.8 else MODE_EXACT
         id_base = int(rng.choice([0, 0, 5_000_000_000]))
         if n * dim > 100003 * 768 or (n >= 100000 and nq > 1000):
             nq = min(nq, 1000)
         corpus = rows(rng, n, dim, "gauss" if kind in ("overflow", "zeros", "scaled", "tiny") else kind)
         queries = rows(rng, nq, dim, "gauss" if kind in ("overflow", "dups", "zeros", "scaled", "tiny") else kind)
+        if kind == "family":      # queries near rows of the corpus
+            queries = corpus[rng.integers(0, n, nq)] + 0.02 * rng.standard_normal((nq, dim)).astype(np.float32)
+            queries = np.ascontiguousarray(queries / np.linalg.norm(queries, axis=1, keepdims=True), dtype=np.float32)
         if kind == "tiny":        # whole corpus / batch far below fp16's normal range (2^-14), or only parts of them
             corpus *= np.float32(10.0 ** rng.uniform(-30, -4))
             if rng.random() < 0.5:
@@ -74,6 +86,10 @@ def main():
         levels = np.where(r < 0.1243, 1, np.where(r < 0.4234, 2, 3)).astype(np.int32)
         idx = IcdIndex(corpus, levels, max_nq=nq, max_k=k, id_base=id_base)
         s, i = idx.search(queries, k, mode)
+        if kind == "family":      # more searches on the same index: counters arrive, the second pass disarms / wide mode switches on
+            for _ in range(int(rng.integers(0, 6))):
+                idx.search(queries, k, mode)
+                idx.stats()
         adj, raw, ids, lv = idx.search_reweighted(queries, k, mode)
         st = idx.stats()
         idx.close()
@@ -85,7 +101,7 @@ def main():
               and np.array_equal(lv[sample], want[3]))
         bad += 0 if ok else 1
         print(f"{'ok  ' if ok else 'FAIL'} case {case:3d}: n={n} nq={nq} dim={dim} k={k} kind={kind} mode={'auto' if mode == MODE_AUTO else 'exact'} "
-              f"id_base={id_base} -> last_mode={st['last_mode']} lists={st['last_chunks']} fallback={st['last_fallback']}", flush=True)
+              f"id_base={id_base} -> last_mode={st['last_mode']} lists={st['last_chunks']} second_pass={st['last_second_pass']} wide={st['wide_mode']} fallback={st['last_fallback']}", flush=True)
     print(f"gpu_fuzz: {args.cases - bad} ok, {bad} failed in {time.time() - t0:.1f} s")
     sys.exit(1 if bad else 0)
 

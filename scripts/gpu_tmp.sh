@@ -1,1 +1,3 @@
-timeout -k 10 120 scripts/probe/gemm_x 2>&1 | tail -8
+bash scripts/gpu_ab_flat.sh "34971 297115 559259" 5 > /dev/null 2>&1
+grep -E "###|coarse=|FAIL" gpurun_out/ab_flat.log | sed -e 's/.*coarse=\([0-9.]*\).*fallback=\([0-9]*\).*/\1 fb=\2/' | paste - - 
+grep -c PASS gpurun_out/ab_flat.log
