@@ -267,9 +267,12 @@ __device__ __forceinline__ void compact_all_parallel(char *smem, Sel2 &st, uint3
 //   32 / 2048  every 16 / 24 tiles all four waves compact ALL their queries at once (compact_all_parallel) at the tile end
 //   131072 __builtin_amdgcn_s_setprio(1) behind every stage barrier, (0) in front of the next (cdna_hip_programming.md T5: on the
 //        8-phase GEMM template the pair keeps hipcc from moving MFMAs across the raw barriers; here the sched_barrier(0)
-//        pins already do that and one wave per SIMD has nobody to take priority from: A/B in profiles/r03_ab_setprio_and_exchange_interval.log)
+//        pins already do that and one wave per SIMD has nobody to take priority from: A/B in profiles/r03_ab_coarse_variants.log)
 //   262144 / 524288  the shared-threshold exchange of a tile end (load of the query's published threshold, adopt or publish) only on
 //        every 2nd / 4th tile (and always on a list's last tile but one) instead of every tile
+//   1048576  ONE barrier per TWO stages: ring of six 16-KB slots (no compaction scratch: the rare tie-ranking path ranks with
+//        v_readlane), the mid-stage wait + barrier of the even stages publishes the next two stages and is followed by
+//        the LDS-DMA pieces of two stages (eight, two behind each MFMA group); odd stages run without wait or barrier
 //   TIMING ONLY (the results are not the scores; they size the parts of the kernel, profiles/r02_coarse_loop_decomposition.log):
 //   256 no s_barrier   512 no wait for the LDS-DMA pieces   4096 thresholds at +inf (nothing passes)
 //   8192 no select at all   16384 no LDS-DMA inside the tile loop   65536 (with 32768) no lane swaps
@@ -277,8 +280,8 @@ __device__ __forceinline__ void compact_all_parallel(char *smem, Sel2 &st, uint3
 // the next tile's MFMA gaps, the first two selects built for the 16x16x32 shape before the lane swap let it keep this
 // one - bit 32768 IS that shape and is part of the product) live in experiments/r02_flat_variants/ with their logs.
 constexpr int CF_PRODUCT_VAR = 1 + 2 + 8 + 128 + 16 + 2048 + 32768;   // measured: profiles/r02_ab_flat_variants.log, profiles/r02_coarse_variants_rg_w8_all.log (+ 16 + 2048: -2 %; + 32768: -2 % at 37 000 rows, -4 % on 1.25 M-row shards)
-__host__ __device__ constexpr int cf_ring_stages(int) { return CO_S; }
-__host__ __device__ constexpr int cf_lds_bytes(int var) { return cf_ring_stages(var) * CO_STAGE_BYTES + CO_BM * CO_CAP * 8 + 4 * 256; }
+__host__ __device__ constexpr int cf_ring_stages(int var) { return (var & 1048576) ? 6 : CO_S; }
+__host__ __device__ constexpr int cf_lds_bytes(int var) { return cf_ring_stages(var) * CO_STAGE_BYTES + CO_BM * CO_CAP * 8 + ((var & 1048576) ? 0 : 4 * 256); }
 #define ICD_CF_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); \
     __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -304,8 +307,11 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     constexpr int EPOCH = ((VAR & 32) && (VAR & 2048)) ? 32 : ((VAR & 32) ? 16 : ((VAR & 2048) ? 24 : 0));   // tiles between the synchronised compactions of all queries
     constexpr bool NOBAR = (VAR & 256) != 0, NOVM = (VAR & 512) != 0, STAMPS = (VAR & 1024) != 0;
     constexpr bool NOPASS = (VAR & 4096) != 0, NOSEL = (VAR & 8192) != 0, NODMA = (VAR & 16384) != 0;
+    constexpr bool PAIRBAR = (VAR & 1048576) != 0;
     constexpr int S = cf_ring_stages(VAR);            // ring slots
-    constexpr int VM_MID = NOVM ? 63 : 4 * (S - 3);   // LDS-DMA pieces that may stay in flight at the mid-stage wait
+    constexpr int VM_MID = NOVM ? 63 : (PAIRBAR ? 4 : 4 * (S - 3));   // LDS-DMA pieces that may stay in flight at the mid-stage wait
+    constexpr int PRO = PAIRBAR ? 4 : S - 1;          // stages issued by a list's prologue
+    constexpr int VM_TILE_END = NOVM ? 0 : (PAIRBAR ? 8 : 4 * (S - 2));   // pieces younger than the early threshold load at the tile end
     constexpr int KS = D / CO_BK;      // stages per tile
     constexpr int NF = D / 16;         // query fragments per lane
     static_assert(KS % S == 0, "ring slot must be a compile-time function of the stage");
@@ -458,7 +464,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                 // between compactions (kept 16 + 2 x (16 + the 8 of one check interval) = 64 slots); only when some lane
                 // is past its quota does the wave run the full check (partner counts, compaction)
                 if (__builtin_amdgcn_ballot_w64(Ops::used(st, h) > CO_QUOTA) != 0ull)
-                    Ops::check(st, lane, smem, wave_qbase, wave_scratch, false, CO_LIMIT, STAMPS ? st_comp : nullptr, CO_QUOTA);
+                    Ops::template check<PAIRBAR>(st, lane, smem, wave_qbase, wave_scratch, false, CO_LIMIT, STAMPS ? st_comp : nullptr, CO_QUOTA);
             }
         };
 
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             }
             if constexpr (q % 2 == 1) {   // every 8 registers: the overflow guard of filter_reg
                 if (__builtin_amdgcn_ballot_w64(Ops::used(st, h) > CO_QUOTA) != 0ull)
-                    Ops::check(st, lane, smem, wave_qbase, wave_scratch, false, CO_LIMIT, STAMPS ? st_comp : nullptr, CO_QUOTA);
+                    Ops::template check<PAIRBAR>(st, lane, smem, wave_qbase, wave_scratch, false, CO_LIMIT, STAMPS ? st_comp : nullptr, CO_QUOTA);
             }
         };
         static_assert(!QUAD || Ops::ROW_OFF == 256, "ds_write2st64_b32 offset1:1 = the row array of the query's buffer");
@@ -512,10 +518,9 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
         // prologue: stages 0..S-2 in flight, stage 0 published, its first fragments read
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (query fragment loads: the vmcnt accounting starts from zero)
 #pragma unroll
-        for (int p = 0; p < S - 2; ++p) issue_stage(p / KS, p % KS, p % S);
-        issue_stage((S - 2) / KS, (S - 2) % KS, (S - 2) % S);
+        for (int p = 0; p < PRO; ++p) issue_stage(p / KS, p % KS, p % S);
         half8 afn[4], bfn[4];
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(4 * (S - 2)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(4 * (PRO - 1)) : "memory");
         read_frags(afn, 0, 0);
         if constexpr (PF2) read_frags(bfn, 0, 1);
         if constexpr (STAMPS) ICD_CF_STAMP(st_prev);
@@ -588,6 +593,8 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                     st_body += ta - st_prev; st_vm += tb - ta; st_bar += tc - tb; st_prev = tc;
                 } else if constexpr (NOBAR) {
                     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(VM_MID) : "memory");
+                } else if constexpr (PAIRBAR && (ks & 1) == 1) {
+                    // (odd stage: the next stage was published together with this one, nothing is issued, nobody waits)
                 } else {
                     if constexpr (SETPRIO) __builtin_amdgcn_s_setprio(0);
                     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(VM_MID) : "memory");
@@ -602,9 +609,14 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (!NODMA) {   // every wave is past stage g-1: its slot takes stage g+S-1
+                if constexpr (!NODMA && !PAIRBAR) {   // every wave is past stage g-1: its slot takes stage g+S-1
                     constexpr int nks = ks + S - 1;
                     issue_stage(tile + nks / KS, nks % KS, nks % S);
+                }
+                if constexpr (!NODMA && PAIRBAR && (ks & 1) == 0) {   // every wave is past stages g-2, g-1: their slots take g+4, g+5
+                    constexpr int n4 = ks + 4, n5 = ks + 5;
+                    issue_stage(tile + n4 / KS, n4 % KS, n4 % S);
+                    issue_stage(tile + n5 / KS, n5 % KS, n5 % S);
                 }
                 if constexpr (PF2) {
                     read_frags(afn, nslot, 0);
@@ -628,7 +640,8 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, M4 / 4, 1);
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
+                        if constexpr (!PAIRBAR) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
+                        else if constexpr ((ks & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 2, 1);   // (two stages' pieces)
                     }
                     __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
                     __builtin_amdgcn_sched_group_barrier(0x008, M4, 1);
@@ -659,7 +672,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             if (EXCH == 1 || (tile & (EXCH - 1)) == EXCH - 1) {
                 uint32_t seen;
                 if constexpr (EARLY_THR) {
-                    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(seen_early) : "i"(NOVM ? 0 : 4 * (S - 2)) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(seen_early) : "i"(VM_TILE_END) : "memory");
                     seen = seen_early;
                 } else {
                     seen = __hip_atomic_load(my_shared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -245,6 +245,8 @@ struct Sel2Ops {
     // after a 16-register group: compact the queries that could overflow in the next group
     // limit: compact the queries whose entry count exceeds it (CAP - 32 = overflow guard for the next
     // 16-register group; a lower value at tile ends compacts early, while all waves are in step)
+    // NOSCRATCH: the tie-ranking path ranks with v_readlane instead of the 256-B LDS scratch (a kernel whose LDS is full)
+    template <bool NOSCRATCH = false>
     __device__ static __forceinline__ void check(Sel2 &s, int lane, char *smem, uint32_t wave_qbase,
                                                  uint32_t wave_scratch, bool force, int limit = CAP - 32,
                                                  unsigned long long *prof = nullptr, int quota = CAP) {
@@ -320,8 +322,11 @@ struct Sel2Ops {
                 }
             }
             const uint32_t key = valid ? ((order_f32(v) & ~63u) | (uint32_t)(63 - lane)) : 0u;
-            *reinterpret_cast<uint32_t *>(smem + wave_scratch + lane * 4) = key;
             int rank = 0;
+            if constexpr (NOSCRATCH) {
+                for (int j = 0; j < 64; ++j) rank += (readlane<uint32_t>(key, j) > key) ? 1 : 0;   // (empty slots carry key 0 and never count)
+            } else {
+            *reinterpret_cast<uint32_t *>(smem + wave_scratch + lane * 4) = key;
             // Rank against the keys in 16-key chunks, only the chunks that hold entries ([0, nlo) at the
             // front, [64 - nhi, 64) at the back; empty slots carry key 0 and never count). The reads are
             // an asm block on purpose: for a compiler-visible ds_read in this loop hipcc emits
@@ -345,6 +350,7 @@ struct Sel2Ops {
                     rank += (k2.x > key) + (k2.y > key) + (k2.z > key) + (k2.w > key);
                     rank += (k3.x > key) + (k3.y > key) + (k3.z > key) + (k3.w > key);
                 }
+            }
             }
             if (valid && rank < KP) {
                 *reinterpret_cast<float *>(smem + qb + rank * 4) = v;
