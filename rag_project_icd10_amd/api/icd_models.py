@@ -49,6 +49,7 @@ class Candidate(BaseModel):
 
 
 _CAND_FIELDS = frozenset(("code", "title", "score", "level", "parent_code", "enhanced_score", "original_score", "similarity_factors"))
+_CAND_FIELDS_SET = set(_CAND_FIELDS)   # shared by every trusted Candidate of trusted_candidates (assigning a field adds a name it already holds)
 _trusted_ok: Optional[bool] = None
 
 
@@ -85,6 +86,29 @@ def trusted_candidate(code: str, title: str, score: float, enhanced_score: float
         return Candidate(code=code, title=title, score=score, level=1, parent_code="", enhanced_score=enhanced_score,
                          original_score=original_score, similarity_factors=similarity_factors)
     return _trusted_candidate_unchecked(code, title, score, enhanced_score, original_score, similarity_factors)
+
+
+def trusted_candidates(recs, ids, scores, originals, factors) -> List["Candidate"]:
+    """trusted_candidate for one hit list in ONE call (the per-object Python call is most of what is left of the cost):
+    recs: the corpus records; ids / scores / originals / factors: parallel sequences of a query's winners. A negative or NaN
+    score raises the ValidationError of the validated constructor (the caller degrades the match to an empty one)."""
+    if _trusted_ok is not True:   # (not yet checked, or this pydantic differs: the checked path, one object at a time)
+        return [trusted_candidate(recs[i].get("code", ""), recs[i].get("preferred_zh", ""), s, s, o, f)
+                for i, s, o, f in zip(ids, scores, originals, factors)]
+    out = []
+    new, setattr_, fields_set = Candidate.__new__, object.__setattr__, _CAND_FIELDS_SET
+    for i, s, o, f in zip(ids, scores, originals, factors):
+        if not s >= 0.0:
+            Candidate(code="", title="", score=s)   # raises
+        rec = recs[i]
+        c = new(Candidate)
+        setattr_(c, "__dict__", {"code": rec.get("code", ""), "title": rec.get("preferred_zh", ""), "score": s, "level": 1,
+                                 "parent_code": "", "enhanced_score": s, "original_score": o, "similarity_factors": f})
+        setattr_(c, "__pydantic_fields_set__", fields_set)
+        setattr_(c, "__pydantic_extra__", None)
+        setattr_(c, "__pydantic_private__", None)
+        out.append(c)
+    return out
 
 
 class DiagnosisMatch(BaseModel):

@@ -40,9 +40,21 @@ def trusted_factors(vs: float, hb: float, em: float, sc: float, ca: float, cr: f
     """SimilarityFactors from six values that are Python floats already (the batched device path's tolist()): the same
     object as SimilarityFactors(...) without the six float() coercions of __post_init__"""
     f = object.__new__(SimilarityFactors)
-    f.__dict__.update(vector_similarity=vs, hierarchy_boost=hb, entity_match_score=em, semantic_coherence=sc,
-                      category_alignment=ca, context_relevance=cr)
+    f.__dict__ = {"vector_similarity": vs, "hierarchy_boost": hb, "entity_match_score": em, "semantic_coherence": sc,
+                  "category_alignment": ca, "context_relevance": cr}
     return f
+
+
+def trusted_factors_row(vs_row, hb_row, sc: float, cr: float) -> list:
+    """trusted_factors for one query's winners in one call (live hits: no entity match, no category alignment)"""
+    new, cls = object.__new__, SimilarityFactors
+    out = []
+    for vs, hb in zip(vs_row, hb_row):
+        f = new(cls)
+        f.__dict__ = {"vector_similarity": vs, "hierarchy_boost": hb, "entity_match_score": 0.0, "semantic_coherence": sc,
+                      "category_alignment": 0.0, "context_relevance": cr}
+        out.append(f)
+    return out
 
 
 @dataclass

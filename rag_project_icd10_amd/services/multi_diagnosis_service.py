@@ -16,7 +16,7 @@ from typing import Any, Dict, List
 
 import numpy as np
 
-from ..api.icd_models import Candidate, DiagnosisMatch, trusted_candidate
+from ..api.icd_models import Candidate, DiagnosisMatch, trusted_candidate, trusted_candidates
 from ..tools.text_processor import DiagnosisTextProcessor
 from .hierarchical_similarity_service import HierarchicalSimilarityService
 from .multidimensional_confidence_service import MultiDimensionalConfidenceService
@@ -101,7 +101,7 @@ class MultiDiagnosisService:
         confidence_statistics=True (row N3) also fills DiagnosisMatch.confidence_factors with the three numbers of the
         reference's confidence service that are in scope - semantic_coherence (the live shape: cosine with the embedding
         of the empty string), model_uncertainty, prediction_variance - computed for the whole batch in two launches."""
-        from .hierarchical_similarity_service import trusted_factors
+        from .hierarchical_similarity_service import trusted_factors_row
         if not diagnoses:
             return []
         if vectors is None:
@@ -130,29 +130,39 @@ class MultiDiagnosisService:
             conf = [{"semantic_coherence": coh[q], "model_uncertainty": stats[q][4], "prediction_variance": stats[q][5]}
                     for q in range(len(diagnoses))]
         out = []
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.disable()   # (tens of thousands of acyclic objects are born here: the collector's generation-0 passes over them are pure cost)
+        try:
+            self._build_matches(out, diagnoses, kk, h_ord, h_enh, h_adj, h_raw, h_boost, h_ids, h_vs, h_hb, recs, sc, qps, conf, trusted_factors_row)
+        finally:
+            if gc_was_on:
+                gc.enable()
+        return out
+
+    def _build_matches(self, out, diagnoses, kk, h_ord, h_enh, h_adj, h_raw, h_boost, h_ids, h_vs, h_hb, recs, sc, qps, conf, trusted_factors_row):
         for q, diagnosis in enumerate(diagnoses):
-            cands = []
             try:
-                ctx = qps[q][1]
+                # how many winners exist (order < 0 from there on); live hits carry level / parent_code under "metadata": the
+                # top-level defaults apply (F8). The values are Python floats / str already (tolist() of the device results):
+                # the trusted constructors skip the per-object validator but keep its one rule with teeth - a negative score
+                # raises and degrades the whole match to an empty one, like the reference's
+                n = kk
+                row_ord = h_ord[q]
                 for j in range(kk):
-                    if h_ord[q][j] < 0:
+                    if row_ord[j] < 0:
+                        n = j
                         break
-                    rec = recs[h_ids[q][j]]
-                    s = h_enh[q][j]
-                    # live hits carry level / parent_code under "metadata": the top-level defaults apply (F8). The values
-                    # are Python floats / str already (tolist() of the device results): trusted_candidate skips the per-object
-                    # validator but keeps its one rule with teeth - a negative score raises and degrades the whole match to an
-                    # empty one, like the reference's
-                    cands.append(trusted_candidate(rec.get("code", ""), rec.get("preferred_zh", ""), s, s,
-                                                   h_adj[q][j] if h_boost[q][j] > 0 else h_raw[q][j],
-                                                   trusted_factors(h_vs[q][j], h_hb[q][j], 0.0, sc, 0.0, ctx)))
+                enh_q, adj_q, raw_q, boost_q = h_enh[q], h_adj[q], h_raw[q], h_boost[q]
+                originals = [adj_q[j] if boost_q[j] > 0 else raw_q[j] for j in range(n)]
+                cands = trusted_candidates(recs, h_ids[q][:n], enh_q[:n], originals,
+                                           trusted_factors_row(h_vs[q][:n], h_hb[q][:n], sc, qps[q][1]))
                 out.append(DiagnosisMatch(diagnosis_text=diagnosis, candidates=cands,
                                           match_confidence=self._calculate_match_confidence(cands),
                                           confidence_factors=conf[q] if conf is not None else None))
             except Exception as exc:
                 logger.error("match failed for %s: %s", diagnosis, exc)
                 out.append(DiagnosisMatch(diagnosis_text=diagnosis, candidates=[], match_confidence=0.0))
-        return out
 
     def _match_from_hits(self, diagnosis: str, hits: List[Dict[str, Any]], top_k: int,
                          query_entities: Dict[str, Any] = None) -> DiagnosisMatch:

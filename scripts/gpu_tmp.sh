@@ -1,3 +1,3 @@
-bash scripts/gpu_ab_flat.sh "34971 1083547" 6 > /dev/null 2>&1
-grep -E "###|coarse=|FAIL" gpurun_out/ab_flat.log | sed -e 's/.*coarse=\([0-9.]*\).*fallback=\([0-9]*\).*/\1 fb=\2/' | paste - - 
-grep -c PASS gpurun_out/ab_flat.log; grep -c FAIL gpurun_out/ab_flat.log
+(timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -5) > gpurun_out/pytest_gpu.log
+(timeout 600 python scripts/bench_e2e.py 2>/dev/null | tail -60) > gpurun_out/e2e.json
+cat gpurun_out/pytest_gpu.log; grep -A16 stages_ms gpurun_out/e2e.json

@@ -261,3 +261,17 @@ def test_trusted_candidate_equals_the_validated_constructor():
     for bad in (-0.01, float("nan")):
         with pytest.raises(ValidationError):
             trusted_candidate("A00", "霍乱", bad, bad, 0.1, f)
+    # the per-query form (one call per hit list) gives the same objects and keeps the rule
+    from rag_project_icd10_amd.api.icd_models import trusted_candidates
+    from rag_project_icd10_amd.services.hierarchical_similarity_service import trusted_factors_row
+    recs = [{"code": "A00", "preferred_zh": "霍乱"}, {"code": "I21.9"}, {}]
+    fr = trusted_factors_row([0.9, 0.8, 0.7], [0.045, 0.06, 0.03], 0.5, 0.25)
+    assert fr == [SimilarityFactors(0.9, 0.045, 0.0, 0.5, 0.0, 0.25), SimilarityFactors(0.8, 0.06, 0.0, 0.5, 0.0, 0.25), SimilarityFactors(0.7, 0.03, 0.0, 0.5, 0.0, 0.25)]
+    got = trusted_candidates(recs, [2, 0, 1], [1.2, 1.1, 0.0], [0.9, 0.8, 0.7], fr)
+    want = [Candidate(code=recs[i].get("code", ""), title=recs[i].get("preferred_zh", ""), score=s, level=1, parent_code="", enhanced_score=s,
+                      original_score=o, similarity_factors=ff) for i, s, o, ff in zip([2, 0, 1], [1.2, 1.1, 0.0], [0.9, 0.8, 0.7], fr)]
+    assert got == want and [c.model_dump() for c in got] == [c.model_dump() for c in want]
+    got[0].score = 2.0                                         # assigning a field of one object leaves the others alone
+    assert got[1].score == 1.1 and got[0].model_fields_set == want[0].model_fields_set
+    with pytest.raises(ValidationError):
+        trusted_candidates(recs, [0, 1], [0.5, -1e-9], [0.1, 0.1], fr[:2])
