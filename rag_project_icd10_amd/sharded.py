@@ -102,8 +102,13 @@ class ShardedSearch:
                     t = t.to(torch.device("cuda", index.device))
                 dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
                 uid = bytes(t.cpu().numpy().tobytes())
-            self.native_group = _native.IcdGroup(index, _native.GROUP_ROW_SHARD if mode == ROW_SHARD else _native.GROUP_QUERY_SHARD,
-                                                 rank=self.rank, world=self.world, unique_id=uid)
+            try:
+                self.native_group = _native.IcdGroup(index, _native.GROUP_ROW_SHARD if mode == ROW_SHARD else _native.GROUP_QUERY_SHARD,
+                                                     rank=self.rank, world=self.world, unique_id=uid)
+            except _native.IcdError as exc:   # (no librccl, communicator refused, ...): the torch.distributed engine still works
+                import logging
+                logging.getLogger(__name__).warning("icd_group_create failed (%s): sharded search runs on torch.distributed collectives", exc)
+                self.native_group = None
         return self
 
     # ---- search ---------------------------------------------------------------------------------------------

@@ -5,13 +5,19 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd /tmp
-# (1) per-kernel durations of the default bench line (with its extras: the real size, the clustered data, --mode exact)
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/rocprof_bench_$TAG.log 2>&1
+# (1) per-kernel durations: the headline workload alone; the default line with its extras (real size, clustered data, --mode exact);
+#     the exact fp32-MFMA kernel alone at the bench size
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $R/gpurun_out/rocprof_bench_$TAG.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_extras -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/rocprof_bench_extras_$TAG.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_exact -- python3 $R/bench.py --mode exact --steps 10 --warmup 3 --no-cpu-baseline --no-extras --repeats 0 > $R/gpurun_out/rocprof_exact_$TAG.log 2>&1
 # (2) PMC passes of the headline workload alone
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
   d=$R/gpurun_out/pmc_${TAG}_$(echo $set | cut -d' ' -f1)
   timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $d -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --repeats 0 > $d.log 2>&1
 done
+# (2b) the exact fp32-MFMA kernel: one pass (MFMA count and busy cycles, clock)
+d=$R/gpurun_out/pmcx_${TAG}
+timeout 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $d -- python3 $R/bench.py --mode exact --steps 4 --warmup 2 --no-cpu-baseline --no-extras --repeats 0 > $d.log 2>&1
 # (3) the row-sharded workload (one 1.25 M-row shard): kernel stats + HBM traffic of a coarse launch
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_rowshard -- python3 $R/bench.py --workload rowshard --steps 1 --rowshard-steps 1 > $R/gpurun_out/rocprof_rowshard_$TAG.log 2>&1
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
@@ -43,6 +49,8 @@ def traffic_of(out):
 out = collect(f'gpurun_out/pmc_{tag}_*/**/*counter_collection.csv')
 json.dump(out, open(f'gpurun_out/{tag}_pmc_counters.json', 'w'), indent=1)
 json.dump(traffic_of(out), open(f'gpurun_out/{tag}_pmc_traffic.json', 'w'), indent=1)
+ex = collect(f'gpurun_out/pmcx_{tag}/**/*counter_collection.csv')
+json.dump({k: v for k, v in ex.items() if 'exact_topk' in k}, open(f'gpurun_out/{tag}_pmc_counters_exact_mode.json', 'w'), indent=1)
 rs = collect(f'gpurun_out/pmcrs_{tag}_*/**/*counter_collection.csv')
 json.dump(traffic_of(rs), open(f'gpurun_out/{tag}_pmc_traffic_rowshard.json', 'w'), indent=1)
 for k, v in out.items():
@@ -52,6 +60,8 @@ for k, v in traffic_of(rs).items():
     if 'coarse' in k:
         print('rowshard', k[:70], v)
 PY
-for f in $(find gpurun_out/prof_$TAG -name "*kernel_stats.csv"); do head -14 $f; cp $f gpurun_out/${TAG}_bench_kernel_stats.csv; done
+for f in $(find gpurun_out/prof_$TAG -name "*kernel_stats.csv"); do head -10 $f; cp $f gpurun_out/${TAG}_bench_kernel_stats.csv; done
+for f in $(find gpurun_out/prof_${TAG}_extras -name "*kernel_stats.csv"); do cp $f gpurun_out/${TAG}_bench_with_extras_kernel_stats.csv; done
+for f in $(find gpurun_out/prof_${TAG}_exact -name "*kernel_stats.csv"); do head -3 $f; cp $f gpurun_out/${TAG}_bench_exact_mode_kernel_stats.csv; done
 for f in $(find gpurun_out/prof_${TAG}_rowshard -name "*kernel_stats.csv"); do head -6 $f; cp $f gpurun_out/${TAG}_rowshard_kernel_stats.csv; done
 tail -1 gpurun_out/rocprof_bench_$TAG.log | cut -c1-400
