@@ -106,11 +106,17 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(ConvertArgs a) {
     }
     const int srow = a.perm_mod > 0 ? (int)(((long long)row * a.perm_mul) % a.perm_mod) : row;
     const float *s = a.src + (size_t)srow * a.dim;
+    // the row is read ONCE and stays in registers (the fp16 path exists for dim 768 and 1024 only: at most four float4 per
+    // lane); the second pass over it used to be a second round trip
+    constexpr int NV = 4;
+    float4 v[NV];
     float m = 0.0f;
     bool bad = false;
-    for (int i = lane * 4; i < a.dim; i += 256) {
-        const float4 v = *reinterpret_cast<const float4 *>(s + i);
-        const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        const int i = lane * 4 + 256 * t;
+        v[t] = i < a.dim ? *reinterpret_cast<const float4 *>(s + i) : float4{0.f, 0.f, 0.f, 0.f};
+        const float f[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             bad |= !(fabsf(f[j]) <= 3.402823466e38f);   // NaN and infinities
@@ -129,14 +135,20 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(ConvertArgs a) {
     }
     const int e = anybad ? 0 : (a.mode == 1 ? a.fixed_exp : scale_exp_for(m));
     float ss = 0.0f;
-    for (int i = lane * 4; i < a.dim; i += 256) {
-        const float4 v = *reinterpret_cast<const float4 *>(s + i);
-        const float f[4] = {v.x, v.y, v.z, v.w};
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float x = ldexpf(f[j], e);   // exact (a component 2^126 below the row's largest flushes: far below fp16's grid)
-            ss = __builtin_fmaf(x, x, ss);
-            d[i + j] = (_Float16)x;
+    for (int t = 0; t < NV; ++t) {
+        const int i = lane * 4 + 256 * t;
+        if (i < a.dim) {
+            const float f[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
+            half4 h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x = ldexpf(f[j], e);   // exact (a component 2^126 below the row's largest flushes: far below fp16's grid)
+                ss = __builtin_fmaf(x, x, ss);
+                h[j] = (_Float16)x;
+            }
+            *reinterpret_cast<half4 *>(d + i) = h;   // one 8-byte store per lane
         }
     }
 #pragma unroll
