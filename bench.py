@@ -252,10 +252,14 @@ def hip_index_factory(corpus, levels, device, max_nq, max_k, id_base=0):
 
 
 def oracle_check(corpus, levels, queries, k, out, world=1):
-    """parity of EVERY query of a batch against the CPU oracle (the checker, outside any timed region)"""
+    """parity of a batch against the CPU oracle (the checker, outside any timed region): EVERY query at N = 1; at N > 1 rank 0
+    has 1 / N of the host's cores, so it checks every N-th query of its batch (the same ~10 s of oracle time)"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
     adj, raw, ids, lv = (x.cpu().numpy() for x in out)
+    if world > 1:
+        sel = np.arange(0, len(queries), world)
+        queries, adj, raw, ids, lv = queries[sel], adj[sel], raw[sel], ids[sel], lv[sel]
     t0 = time.perf_counter()
     # (torchrun exports OMP_NUM_THREADS=1 to its ranks: give the checker its share of the host's cores explicitly)
     os_, oi = orc.flat_ip_topk(corpus, queries, k, nthreads=max(1, (os.cpu_count() or 1) // max(1, world)))

@@ -17,6 +17,13 @@ constexpr int FIN_MAX_CAND = 512;  // P * KP
 constexpr int FIN_MAX_K = 128;     // largest k of a search
 constexpr int FIN_MAX_T = 256;     // largest rescoring window (RESCORE): the best T coarse candidates, T/64 per lane
 constexpr int FIN_EF = FIN_MAX_CAND / 64;
+#ifndef ICD_FIN_WALK
+#define ICD_FIN_WALK 8
+#endif
+constexpr int FIN_WALK = ICD_FIN_WALK;   // 64-B blocks of a row a lane keeps in flight per trip of the rescoring walk (divides 48 and 64)
+#ifndef ICD_FIN_OCC
+#define ICD_FIN_OCC 7
+#endif
 
 struct FinArgs {
     const float *part_scores;  // [slot][P][KP]
@@ -209,7 +216,7 @@ __device__ __forceinline__ int fin_merge(const FinArgs &a, size_t pbase, int nca
 // EWM: rescoring candidates per lane the instantiation can hold (1 for k <= 32: the common case keeps its registers and
 // resident waves; 4 for k up to 100).
 template <bool RESCORE, bool DEEP = false, int EWM = 4>
-__global__ __launch_bounds__(256, EWM == 1 ? 7 : 1) void finalize_kernel(FinArgs a) {   // (7 waves per SIMD: <= 72 VGPRs)
+__global__ __launch_bounds__(256, EWM == 1 ? ICD_FIN_OCC : 1) void finalize_kernel(FinArgs a) {   // (7 waves per SIMD: <= 72 VGPRs)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (!RESCORE && a.host_counters && blockIdx.x == 0 && threadIdx.x < 4) a.host_counters[threadIdx.x] = a.counters[threadIdx.x];
@@ -352,12 +359,12 @@ __global__ __launch_bounds__(256, EWM == 1 ? 7 : 1) void finalize_kernel(FinArgs
                     }
                 // (eight blocks = eight independent 16-B loads per lane in flight per trip; the inner trip count is a constant
                 //  because hipcc does not unroll a runtime-count loop around the convergent DPP move)
-                for (int b0 = 0; b0 < nblk; b0 += 8) {
-                    f32x4 cvv[8];
+                for (int b0 = 0; b0 < nblk; b0 += FIN_WALK) {
+                    f32x4 cvv[FIN_WALK];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) cvv[u] = c4[4 * (b0 + u)];
+                    for (int u = 0; u < FIN_WALK; ++u) cvv[u] = c4[4 * (b0 + u)];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < FIN_WALK; ++u) {
                         const f32x4 cv = cvv[u];
                         const f32x4 qv = q4q[4 * (b0 + u)];
                         ICD_QUAD_STEP(0x00)   // quad_perm [0,0,0,0]: everyone continues from lane 0's four steps
