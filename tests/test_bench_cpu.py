@@ -115,3 +115,13 @@ def test_bench_child_failure_fails_the_parent():
     p = _run_bench(["--gpus", "2", "--no-rowshard"], {"ICD_BENCH_TEST_FAIL_RANK": "1"})
     assert p.returncode != 0
     assert not [l for l in p.stdout.splitlines() if l.strip().startswith("{")]   # no result line from a failed run
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` on a box with fewer than N GPUs (none here) must not print an N = 1 line: it exits non-zero
+    before starting anything"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "ICD_BENCH_DEVICE", "ICD_BENCH_ONE_DEVICE")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], env=env, capture_output=True, text=True,
+                       timeout=120, cwd=ROOT)
+    assert p.returncode != 0 and "GPU(s) visible" in p.stderr and not p.stdout.strip()
