@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define ICD_ABI_VERSION 2   /* 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
+#define ICD_ABI_VERSION 3   /* 3: icd_stats.sparse_fallback_armed appended (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
 #define ICD_MAX_K 128
 
 typedef struct icd_index icd_index;
@@ -92,6 +92,10 @@ typedef struct icd_stats {
                                    dropped after a few consecutive searches that flagged fewer) */
     int32_t wide_mode;          /* 1: large batches are planned with the second pass's list count from the start (the
                                    previous large batch needed the second pass for most of its queries) */
+    int32_t sparse_fallback_armed; /* 1: the exact re-search behind the last AUTO search carried the streaming kernel's two
+                                   launches (few flagged queries: ~0.05 ms); 0: they were left out after a long run of
+                                   searches with nothing flagged, and the fp32-MFMA kernel takes any count (~0.4 ms, once:
+                                   the run restarts and the required length doubles). Results are exact either way. */
 } icd_stats;
 
 /* per-kernel device time of the most recent search, measured with hipEvents on the search stream.

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libicdsearch.so")
 MODE_AUTO = 0   # fp16-MFMA coarse pass + certified exact rescoring (+ exact fallback); same results as EXACT
 MODE_EXACT = 1  # fp32-MFMA kernel only
 MAX_K = 128
-ABI_VERSION = 2   # include/icd_search.h ICD_ABI_VERSION: a stale libicdsearch.so is refused with a clear message
+ABI_VERSION = 3   # include/icd_search.h ICD_ABI_VERSION: a stale libicdsearch.so is refused with a clear message
 
 EXPORTED_SYMBOLS = (
     "icd_abi_version", "icd_last_error", "icd_device_count", "icd_index_create", "icd_index_destroy",
@@ -52,7 +52,7 @@ class _Stats(C.Structure):
                 ("max_nq", C.c_int32), ("max_k", C.c_int32), ("fast_path", C.c_int32), ("rmax", C.c_float),
                 ("last_nq", C.c_int64), ("last_fallback", C.c_int64), ("last_chunks", C.c_int32),
                 ("last_mode", C.c_int32), ("last_second_pass", C.c_int64), ("last_second_pass_lists", C.c_int32),
-                ("second_pass_armed", C.c_int32), ("wide_mode", C.c_int32)]
+                ("second_pass_armed", C.c_int32), ("wide_mode", C.c_int32), ("sparse_fallback_armed", C.c_int32)]
 
 
 class _Profile(C.Structure):

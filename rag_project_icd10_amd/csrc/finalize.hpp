@@ -57,7 +57,8 @@ struct FinArgs {
     int cexp;                    // the corpus's scale exponent
     int *nflag;    // fallback counter
     int *flagged;  // fallback list
-    const int *counters;   // nullable (last launch of a search): the search's four fallback counters ...
+    int *counters;         // nullable (last launch of a search): the search's four fallback counters (+ [4], the run length below) ...
+    int track_run;         // finalize<false> of a fast-path search: counters[4] = consecutive searches whose re-search had nothing to do
     int *host_counters;    // ... are copied to this pinned host array by block 0 (icd_index_stats reads them after the stream's event)
     // level table
     const int *levels;  // [n] or null
@@ -219,7 +220,17 @@ template <bool RESCORE, bool DEEP = false, int EWM = 4>
 __global__ __launch_bounds__(256, EWM == 1 ? ICD_FIN_OCC : 1) void finalize_kernel(FinArgs a) {   // (7 waves per SIMD: <= 72 VGPRs)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (!RESCORE && a.host_counters && blockIdx.x == 0 && threadIdx.x < 4) a.host_counters[threadIdx.x] = a.counters[threadIdx.x];
+    if (!RESCORE && a.host_counters && blockIdx.x == 0) {
+        if (threadIdx.x < 4) a.host_counters[threadIdx.x] = a.counters[threadIdx.x];
+        if (threadIdx.x == 4) {   // (one launch per search, block 0 only: no race on the run length)
+            int run = a.counters[4];
+            if (a.track_run) {
+                run = (a.nq_ptr && *a.nq_ptr == 0) ? min(run + 1, 1 << 30) : 0;
+                a.counters[4] = run;
+            }
+            a.host_counters[4] = run;
+        }
+    }
     const int nq = a.nq_ptr ? min(*a.nq_ptr, a.nq) : a.nq;
     if (RESCORE && a.skip_below > 0 && nq <= a.skip_below) {   // (kernel-uniform) hand the slot list on as it is
         if (blockIdx.x == 0 && a.qlist) {

@@ -71,6 +71,7 @@ constexpr int PASS2_CHUNKS = 20;     // second coarse pass (and wide_mode): abou
 constexpr int PASS2_MAX_P = 24;      // ... at most this many (workspace); 24 x 16 candidates < FIN_MAX_CAND
 constexpr int PASS2_SKIP = 24;       // ... and leaves this many flagged queries (or fewer) to the streaming kernel: 35 us per 8
 constexpr int PASS2_BELOW = 320;     // the second pass runs when the first gave a query fewer candidates than this
+constexpr int SPARSE_DISARM_AFTER = 96; // the streaming kernel's two fallback launches are dropped after this many consecutive searches with NO flagged query (doubles at every incident)
 constexpr int PASS2_DISARM_AFTER = 4; // the second pass's two launches are dropped after this many consecutive searches that needed neither
 constexpr int WIDE_MIN_NQ = 2048;    // "large batch": below it a query has 16+ lists anyway
 constexpr int WIDE_REPROBE = 64;
@@ -124,7 +125,7 @@ struct icd_index {
     float *part2_s = nullptr; int *part2_r = nullptr; float *part2_b = nullptr; size_t part2_cap = 0;   // lists of the second coarse pass
     float *partx_s = nullptr; int *partx_r = nullptr; size_t partx_cap = 0;
     float *lists_s = nullptr; int *lists_r = nullptr; size_t lists_cap = 0;   // streaming kernel: [slot][4 nwg][KP]
-    int *nflag = nullptr; int *flagged = nullptr;   // fallback counters [4] and lists [3][max_nq_pad]: after the first finalize, after its wide-window retry, after the second coarse pass
+    int *nflag = nullptr; int *flagged = nullptr;   // [8]: fallback counters [0..3], [4] = consecutive fast-path searches whose exact re-search had nothing to do (kept by the device); lists [3][max_nq_pad] and lists [3][max_nq_pad]: after the first finalize, after its wide-window retry, after the second coarse pass
     int fallback_word = 0;                           // which counter / list the last search's exact re-search read
     int *h_nflag = nullptr;                          // pinned (mapped) host copy of nflag[4], written by the last kernel of every search
     int *h_nflag_dev = nullptr;                      // its device-side address
@@ -147,6 +148,17 @@ struct icd_index {
     // that flagged fewer they are left out (a batch that then flags many takes the exact re-search once and re-arms them).
     int p2_clean = 0;              // consecutive evaluated searches with <= PASS2_SKIP queries flagged by the first finalize
     bool p2_eval_pending = false;  // the last search's counters have not been looked at yet
+    // The exact re-search behind every search is four launches: streaming kernel + list reduction (few flagged queries:
+    // one corpus sweep per 8) and fp32-MFMA kernel + finalize (many). With nothing flagged each reads a counter and leaves.
+    // After `sparse_need` consecutive searches whose re-search had nothing to do (counted on the device, so searches the
+    // host never looked at count too) the streaming pair is left out and the MFMA kernel takes any count >= 1. Measured at
+    // 10 000 x 37 000 (profiles/r03_sparse_fallback_policy.log): the pair costs a clean search ~3.4 us (0.5 %); without it
+    // a search with 1-8 flagged queries takes 1.25 instead of 0.72 ms, once - the run restarts and the requirement
+    // doubles. The break-even of the two is ~150 clean searches (ski rental); 96 stays below it (at most 2.6 x the
+    // cost of the best fixed choice in hindsight, 2 x at the break-even).
+    int sparse_need = SPARSE_DISARM_AFTER;
+    int sparse_run_seen = 0;       // the device's run length when the host last saw a completed search
+    bool sparse_disarmed = false;  // the last fast-path search went without the streaming pair
     bool pass2_enabled = true;     // test hook (icd_index_set_second_pass)
     bool adapt_enabled = true;     // ... 2 = second pass without the adaptive list count
     bool profiling = false;
@@ -436,10 +448,11 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         while (p > 1 && (size_t)nq * p * kp > cap) --p;
         return p;
     };
-    auto run_exact = [&](const int *qlist, const int *nq_ptr, int px, bool mfma, bool stream) -> int {
+    auto run_exact = [&](const int *qlist, const int *nq_ptr, int px, bool mfma, bool stream, bool stream_launch = true, bool track_run = false) -> int {
+        const int sparse_here = stream_launch ? sparse_max : 0;   // (streaming pair left out: the MFMA kernel takes every count >= 1)
         if (!nq_ptr) x->last_chunks = px;   // (the fallback keeps the coarse pass's chunk count)
         int rc = ICD_OK;
-        if (stream) {
+        if (stream && stream_launch) {
             int used = px;
             rc = run_stream(qlist, nq_ptr, nq, mfma ? px : 0, &used);   // alone: fewest output lists
             if (rc) return rc;
@@ -461,7 +474,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             }
             ExactArgs a{};
             a.corpus = x->corpus; a.queries = dq; a.qlist = qlist; a.nq_ptr = nq_ptr; a.nq = nq;
-            a.min_active = stream ? sparse_max : 0;
+            a.min_active = stream ? sparse_here : 0;
             a.adaptive_max_p = stream ? p_sparse : 0;   // fallback: the chunk count follows the actual flagged count
             a.n = (int)x->n; a.dim = x->dim; a.P = pm;
             a.rows_per_chunk = ((row_tiles + pm - 1) / pm) * 128;
@@ -474,7 +487,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         rec(x, 4, s);
         FinArgs g = f;
         g.part_scores = x->partx_s; g.part_rows = x->partx_r; g.P = px; g.KP = kpx;
-        g.P_dense = px_dense; g.sparse_max = sparse_max; g.lds_cand = std::max(px, stream ? p_sparse : px_dense) * kpx;
+        g.P_dense = px_dense; g.sparse_max = sparse_here; g.track_run = track_run ? 1 : 0; g.lds_cand = std::max(px, stream ? p_sparse : px_dense) * kpx;
         g.dense_grid = mtx * std::max(1, px_dense); g.dense_bmq = bmq; g.dense_max_p = (stream && mfma) ? p_sparse : 0; g.n_rows = (int)x->n;
         g.nq = nq; g.nq_ptr = nq_ptr; g.qlist = qlist;
         g.counters = x->nflag; g.host_counters = x->h_nflag_dev;   // (the last launch of every search: no separate copy)
@@ -536,7 +549,14 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     // start with the second pass's list count (1.5 instead of 2.2 ms per 10 000 queries there; 7 % slower on Gaussian data,
     // which is why it is not the default). Every WIDE_REPROBE-th large search runs narrow again and decides anew.
     const bool large = nq >= WIDE_MIN_NQ;
-    const bool counters_in = (x->last_narrow_large || x->p2_eval_pending) && hipEventQuery(x->ev_nflag) == hipSuccess;
+    const bool counters_in = hipEventQuery(x->ev_nflag) == hipSuccess;   // (every search enqueued so far has completed)
+    if (counters_in) {
+        const int run = x->h_nflag[4];
+        if (x->sparse_disarmed && run < x->sparse_need) x->sparse_need = std::min(x->sparse_need * 2, 1 << 16);   // an incident
+        x->sparse_run_seen = run;
+    }
+    const bool sparse_off = x->adapt_enabled && x->sparse_run_seen >= x->sparse_need;
+    x->sparse_disarmed = sparse_off;
     if (x->p2_eval_pending && counters_in) {
         x->p2_clean = x->h_nflag[0] > PASS2_SKIP ? 0 : std::min(x->p2_clean + 1, 1 << 20);
         x->p2_eval_pending = false;
@@ -779,9 +799,9 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         if ((size_t)nq * px * kpx > x->partx_cap) return fail(ICD_ERR_INVALID, "workspace too small for nq=%d k=%d", nq, k);
         const int tiles_per = (row_tiles + px - 1) / px;
         px = (row_tiles + tiles_per - 1) / tiles_per;
-        return run_exact(fl_list, fl_count, px, true, false);
+        return run_exact(fl_list, fl_count, px, true, false, true, true);
     }
-    return run_exact(fl_list, fl_count, p_sparse, true, stream_ok);
+    return run_exact(fl_list, fl_count, p_sparse, true, stream_ok, !sparse_off, true);
 }
 
 }  // namespace
@@ -918,10 +938,10 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     x->lists_cap = std::max((size_t)ST_MAX_ACTIVE * 1024 * exact_kp_for(max_k), (size_t)ST_FALLBACK_MAX_ACTIVE * 1024 * 16);
     CR_TRY(wsalloc(&x->lists_s, x->lists_cap));
     CR_TRY(wsalloc(&x->lists_r, x->lists_cap));
-    CR_TRY(wsalloc(&x->nflag, 4));
-    CR_TRY(hipMemset(x->nflag, 0, 4 * sizeof(int)));
-    CR_TRY(hipHostMalloc(reinterpret_cast<void **>(&x->h_nflag), 4 * sizeof(int), hipHostMallocMapped));
-    memset(x->h_nflag, 0, 4 * sizeof(int));
+    CR_TRY(wsalloc(&x->nflag, 8));
+    CR_TRY(hipMemset(x->nflag, 0, 8 * sizeof(int)));
+    CR_TRY(hipHostMalloc(reinterpret_cast<void **>(&x->h_nflag), 8 * sizeof(int), hipHostMallocMapped));
+    memset(x->h_nflag, 0, 8 * sizeof(int));
     CR_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&x->h_nflag_dev), x->h_nflag, 0));
     CR_TRY(hipEventCreateWithFlags(&x->ev_nflag, hipEventDisableTiming));
     CR_TRY(wsalloc(&x->dbg, (size_t)8192 * 16));
@@ -1117,6 +1137,7 @@ int icd_index_stats(icd_index *idx, icd_stats *out) {
     out->last_second_pass_lists = idx->last_p2;
     out->wide_mode = idx->wide_mode ? 1 : 0;
     out->second_pass_armed = (idx->pass2_enabled && idx->p2_clean < PASS2_DISARM_AFTER) ? 1 : 0;
+    out->sparse_fallback_armed = idx->sparse_disarmed ? 0 : 1;
     out->last_chunks = idx->last_chunks; out->last_mode = idx->last_mode;
     return ICD_OK;
 }
@@ -1132,6 +1153,8 @@ int icd_index_set_second_pass(icd_index *idx, int32_t enabled) {
     idx->adapt_enabled = enabled == 1;
     if (!idx->pass2_enabled || !idx->adapt_enabled) { idx->wide_mode = false; idx->last_narrow_large = false; }
     idx->p2_clean = 0; idx->p2_eval_pending = false;   // (re-armed)
+    idx->sparse_need = SPARSE_DISARM_AFTER; idx->sparse_run_seen = 0; idx->sparse_disarmed = false;
+    if (idx->nflag) { HIP_TRY(hipSetDevice(idx->device)); HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipMemset(idx->nflag + 4, 0, sizeof(int))); idx->h_nflag[4] = 0; }
     return ICD_OK;
 }
 

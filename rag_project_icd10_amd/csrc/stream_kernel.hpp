@@ -25,7 +25,7 @@ namespace icd {
 constexpr int ST_QB = 8;          // queries per pass (template QB <= ST_QB: fewer for tiny batches)
 constexpr int ST_PF = 1;          // dim must be a multiple of 32 * ST_PF
 constexpr int ST_MAX_ACTIVE = 64; // direct calls: batches up to this size take the streaming kernel (EXACT mode)
-constexpr int ST_FALLBACK_MAX_ACTIVE = 192;   // AUTO fallback: flagged lists up to this long (less for large k: workspace)
+constexpr int ST_FALLBACK_MAX_ACTIVE = 144;   // AUTO fallback: flagged lists up to this long (less for large k: workspace). One sweep per 8 queries costs ~37 us at 37 000 rows, the MFMA kernel ~0.68 ms for any count up to a few thousand: they meet near 146 (profiles/r03_sparse_fallback_policy.log)
 constexpr int ST_STAGE_BYTES = 8192;   // one wave stage: 64 rows x 32 floats
 constexpr int ST_PAD_ROWS = 512;       // zero rows the index keeps behind the corpus (stages may run past n)
 
@@ -93,8 +93,11 @@ template <int KP, int E, int QB>
 __global__ __launch_bounds__(256) void stream_topk_kernel(StreamArgs a) {
     constexpr int CAP = 64 * E;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nq = a.nq_ptr ? min(*a.nq_ptr, a.nq) : a.nq;
-    if (nq <= 0 || nq > a.max_active) return;   // work-group-uniform
+    // (the gate looks at the device's count itself: a.nq is already clamped to max_active by the host, and a list longer
+    //  than that belongs to the MFMA kernel alone - round 3: the clamped count used to pass the gate and cost 24 sweeps)
+    const int cnt = a.nq_ptr ? *a.nq_ptr : a.nq;
+    if (cnt <= 0 || cnt > a.max_active) return;   // work-group-uniform
+    const int nq = min(cnt, a.nq);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int dim = a.dim, nsl = dim >> 5, D = a.ring_stages;
@@ -251,8 +254,9 @@ struct ReduceArgs {
 __global__ __launch_bounds__(256) void reduce_lists_kernel(ReduceArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nq = a.nq_ptr ? min(*a.nq_ptr, a.nq) : a.nq;
-    if (nq <= 0 || nq > a.max_active) return;
+    const int cnt = a.nq_ptr ? *a.nq_ptr : a.nq;
+    if (cnt <= 0 || cnt > a.max_active) return;
+    const int nq = min(cnt, a.nq);
     const int w = blockIdx.x * 4 + wave;
     const int slot = w / a.P_out, g = w - slot * a.P_out;
     if (slot >= nq) return;

@@ -1,6 +1,7 @@
-for n in 37000 40474 37000 40474; do (timeout 300 python bench.py --n $n --steps 20 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | tail -1) > gpurun_out/b_$n.log; python - $n <<'PY'
-import json,sys
-l=json.loads(open(f'gpurun_out/b_{sys.argv[1]}.log').read())
-print(sys.argv[1], round(l['ms_per_step'],4), l['kernel_ms'], round(l['roofline']['frac'],4), l['coarse_chunks'])
-PY
-done
+set -e
+cd $GRAFT_REPO_ROOT
+python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+python scripts/probe/sparse_incident.py > gpurun_out/sparse_incident.log 2>&1
+cat gpurun_out/sparse_incident.log
+python scripts/gpu_fuzz.py --seed 77 --cases 40 > gpurun_out/fuzz77.log 2>&1
+tail -2 gpurun_out/fuzz77.log

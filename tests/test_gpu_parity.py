@@ -740,6 +740,57 @@ def test_second_pass_launches_are_dropped_after_clean_searches_and_rearmed(oracl
     idx.close()
 
 
+def test_streaming_fallback_launches_are_dropped_after_a_long_clean_run_and_an_incident_is_exact(oracle):
+    """the exact re-search behind every AUTO search is four launches; after 96 consecutive searches with nothing flagged
+    (counted on the device: searches the host never waited for count too) the streaming kernel's two are left out and the
+    fp32-MFMA kernel takes any count. A flagged query in that state is still answered exactly, restarts the run and
+    doubles the required length."""
+    import torch
+    need = 96
+    corpus, levels, queries = unit_rows(6000, 768, 15), icd_levels(6000, 16), unit_rows(96, 768, 17)
+    idx = IcdIndex(corpus, levels, max_nq=96, max_k=10)
+    dq = torch.from_numpy(queries).cuda()
+
+    def clean(count):
+        for _ in range(count):                             # enqueued back to back, whether or not the host sees them complete
+            idx.search_reweighted(dq, 10)
+        return idx.stats()                                 # (waits for the last search: the NEXT one sees the run length)
+
+    want = idx.search_reweighted(dq, 10)
+    st = idx.stats()
+    assert st["sparse_fallback_armed"] == 1 and st["last_fallback"] == 0
+    assert clean(need - 6)["sparse_fallback_armed"] == 1   # a run of need - 5
+    clean(5)
+    got = idx.search_reweighted(dq, 10)
+    st = idx.stats()
+    assert st["sparse_fallback_armed"] == 0 and st["last_fallback"] == 0
+    assert all(torch.equal(x, y) for x, y in zip(got, want))
+    dirty = dq.clone()
+    dirty[5] = 0                                           # every score ties at 0: not certifiable
+    dirty[40] = 0
+    a0 = idx.search_reweighted(dirty, 10)
+    st = idx.stats()
+    assert st["sparse_fallback_armed"] == 0 and st["last_fallback"] == 2          # ... the MFMA kernel alone took them
+    a1 = idx.search_reweighted(dirty, 10)                                         # re-armed: the streaming kernel again
+    st = idx.stats()
+    assert st["sparse_fallback_armed"] == 1 and st["last_fallback"] == 2
+    assert all(torch.equal(x, y) for x, y in zip(a0, a1))
+    assert bool((a0[2][5] == torch.arange(10, device="cuda")).all())              # ties: row id ascending
+    keep = [i for i in range(96) if i not in (5, 40)]
+    assert all(torch.equal(x[keep], y[keep]) for x, y in zip(a0, want))
+    clean(need + 10)                                       # `need` clean searches are not enough a second time (2 * need now)
+    idx.search_reweighted(dq, 10)
+    assert idx.stats()["sparse_fallback_armed"] == 1
+    clean(need)
+    idx.search_reweighted(dq, 10)
+    assert idx.stats()["sparse_fallback_armed"] == 0
+    idx.set_second_pass(True, adaptive=False)              # the test hook's non-adaptive setting keeps all four launches
+    idx.search_reweighted(dq, 10)
+    assert idx.stats()["sparse_fallback_armed"] == 1
+    _check(oracle, idx, corpus, levels, queries, 10, MODE_AUTO)
+    idx.close()
+
+
 def test_device_hier_rescoring_matches_host():
     """icd_hier_rescore ALONE (through the C ABI) against HierarchicalSimilarityService.batch_calculate_similarities - the
     host method the reference-generated fixture pins (tests/golden/hier_cases.json, test_golden_host_logic.py) - on all
