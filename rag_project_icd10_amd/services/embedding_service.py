@@ -22,6 +22,7 @@ Encoder NUMERICAL parity with the reference is unpinned.
 """
 from __future__ import annotations
 
+import itertools
 import logging
 import os
 from typing import Any, Dict, List, Optional
@@ -69,6 +70,119 @@ class _Encoder(torch.nn.Module):
             mask = attention_mask.unsqueeze(-1).to(hidden.dtype)
             pooled = (hidden * mask).sum(1) / mask.sum(1).clamp(min=1e-9)
         return torch.nn.functional.normalize(pooled.float(), p=2, dim=1)
+
+
+class _PackedBert:
+    """The same BERT encoder arithmetic over PACKED tokens: no padding anywhere but inside the attention.
+
+    A padded batch spends its GEMMs on pad tokens (1 000 diagnosis strings: 25 776 padded against 18 290 real tokens at 256
+    per sub-batch) and cuts them into sub-batches too small to fill the chip (M = 7 k rows: 100 TFLOP/s fp32 against
+    135 at M = 20 k). Here every Linear / LayerNorm / GELU of the encoder runs once over [T, hidden] for ALL tokens of a
+    chunk, Q / K / V are one fused GEMM, and only the attention itself sees a padded view: the sequences, sorted by
+    length, are cut into a few groups of similar length, each gathered to [n_g, L_g] (pads read a zero row), attended
+    with a key mask, and scattered back (profiles/r03_encoder_packed.log). Same weights as the module it is built from
+    (shared storage, except the fused QKV copy); post-LN BERT with absolute positions and erf-GELU only - anything else
+    keeps the padded HF forward. Arithmetic restated from transformers' BertModel (BertEmbeddings: (word + type) +
+    position -> LayerNorm; BertSelfAttention via scaled_dot_product_attention; BertSelfOutput / BertOutput: dense ->
+    LayerNorm(x + residual)), the published architecture the reference reaches through sentence-transformers.
+    """
+
+    GROUP_RATIO = 0.75   # a group of sequences for the attention: lengths within this factor of its longest
+    MAX_GROUPS = 12
+
+    @staticmethod
+    def supported(bert) -> bool:
+        cfg = bert.config
+        return (type(bert).__name__ == "BertModel" and getattr(cfg, "position_embedding_type", None) in (None, "absolute")
+                and getattr(cfg, "hidden_act", "gelu") == "gelu" and not getattr(cfg, "is_decoder", False))
+
+    def __init__(self, bert):
+        self.bert = bert
+        cfg = bert.config
+        self.heads = int(cfg.num_attention_heads)
+        self.hidden = int(cfg.hidden_size)
+        self.eps = float(cfg.layer_norm_eps)
+        self.layers = []
+        for l in bert.encoder.layer:
+            a = l.attention.self
+            self.layers.append({
+                "wqkv": torch.cat([a.query.weight, a.key.weight, a.value.weight], 0).detach().contiguous(),
+                "bqkv": torch.cat([a.query.bias, a.key.bias, a.value.bias], 0).detach().contiguous(),
+                "attn_out": l.attention.output, "inter": l.intermediate.dense, "out": l.output,
+            })
+
+    @classmethod
+    def plan_groups(cls, lengths):
+        """lengths sorted descending -> [(first sequence, count, longest)]: greedy cuts where a sequence falls below
+        GROUP_RATIO of the group's longest; the ratio loosens until at most MAX_GROUPS remain"""
+        ratio = cls.GROUP_RATIO
+        while True:
+            groups, start = [], 0
+            for i in range(1, len(lengths) + 1):
+                if i == len(lengths) or lengths[i] < ratio * lengths[start]:
+                    groups.append((start, i - start, lengths[start]))
+                    start = i
+            if len(groups) <= cls.MAX_GROUPS or ratio <= 0.05:
+                return groups
+            ratio *= 0.8
+
+    @torch.no_grad()
+    def hidden_states(self, ids_sorted, device):
+        """ids_sorted: token id lists, longest first. Returns (last hidden state of every token, packed [T, hidden], in
+        that order; the plan: lengths, first packed row of every sequence, attention groups)."""
+        F = torch.nn.functional
+        lengths = [len(x) for x in ids_sorted]
+        n, T = len(lengths), sum(lengths)
+        lens_np = np.asarray(lengths, dtype=np.int64)
+        starts = np.concatenate([[0], np.cumsum(lens_np)])
+        flat = np.fromiter(itertools.chain.from_iterable(ids_sorted), dtype=np.int64, count=T)
+        pos = np.arange(T, dtype=np.int64) - np.repeat(starts[:-1], lens_np)
+        groups = []
+        for first, count, longest in self.plan_groups(lengths):
+            col = np.arange(longest, dtype=np.int64)[None, :]
+            key = col < lens_np[first:first + count, None]
+            grid = np.where(key, starts[first:first + count, None] + col, T)   # pads point at the zero row behind the tokens
+            # (the key mask as the additive bias SDPA would make of a boolean one - once per group, not once per layer;
+            #  a group without pads needs none)
+            bias = None if bool(key.all()) else torch.from_numpy(np.where(key, 0.0, -np.inf).astype(np.float32)).to(device, non_blocking=True)[:, None, None, :]
+            groups.append((count, longest, torch.from_numpy(grid.reshape(-1)).to(device, non_blocking=True), bias))
+        ids_t = torch.from_numpy(flat).to(device, non_blocking=True)
+        pos_t = torch.from_numpy(pos).to(device, non_blocking=True)
+        emb = self.bert.embeddings
+        x = emb.word_embeddings(ids_t) + emb.token_type_embeddings.weight[0]
+        x = x + emb.position_embeddings(pos_t)
+        x = emb.LayerNorm(x)
+        H, nh = self.hidden, self.heads
+        dh = H // nh
+        groups = [(c, L, g, None if m is None else m.to(x.dtype)) for c, L, g, m in groups]
+        qkv = torch.zeros((T + 1, 3 * H), dtype=x.dtype, device=device)   # row T: the pads' zero row
+        ctx = torch.empty((T + 1, H), dtype=x.dtype, device=device)       # row T: where the pads' outputs land
+        for l in self.layers:
+            torch.addmm(l["bqkv"], x, l["wqkv"].t(), out=qkv[:T])
+            for count, longest, grid, key in groups:
+                g = qkv.index_select(0, grid).view(count, longest, 3, nh, dh)
+                q, k, v = (g[:, :, i].transpose(1, 2) for i in range(3))
+                o = F.scaled_dot_product_attention(q, k, v, attn_mask=key)
+                ctx.index_copy_(0, grid, o.transpose(1, 2).reshape(count * longest, H))
+            x = l["attn_out"].LayerNorm(l["attn_out"].dense(ctx[:T]) + x)
+            x = l["out"].LayerNorm(l["out"].dense(F.gelu(l["inter"](x))) + x)
+        return x, (lengths, starts, groups)
+
+    @torch.no_grad()
+    def forward(self, ids_sorted, device, pooling: str):
+        """ids_sorted: token id lists, longest first. Returns the pooled, UN-normalised [n, hidden] in that order."""
+        x, (lengths, starts, groups) = self.hidden_states(ids_sorted, device)
+        n, H = len(lengths), self.hidden
+        if pooling == "cls":
+            return x.index_select(0, torch.from_numpy(starts[:-1].copy()).to(device))
+        xe = torch.cat([x, x.new_zeros((1, H))], 0)
+        pooled = torch.empty((n, H), dtype=x.dtype, device=device)
+        first = 0
+        for count, longest, grid, key in groups:
+            lens = torch.tensor(lengths[first:first + count], dtype=x.dtype, device=device).clamp(min=1e-9)
+            pooled[first:first + count] = xe.index_select(0, grid).view(count, longest, H).sum(1) / lens[:, None]
+            first += count
+        return pooled
 
 
 class UnsupportedPoolingError(ValueError):
@@ -189,6 +303,9 @@ class EmbeddingService:
             self.model.bert.to(dtype)
         self._dim = int(bert.config.hidden_size)
         self._graphs = {} if os.getenv("ICD_EMBEDDING_GRAPHS", "1") == "1" else None
+        # large batches: the encoder over packed tokens (ICD_EMBEDDING_PACKED=0: the padded HF forward everywhere)
+        self._packed = (_PackedBert(self.model.bert) if os.getenv("ICD_EMBEDDING_PACKED", "1") == "1" and _PackedBert.supported(self.model.bert)
+                        else None)
 
     # ---- text preparation (reference :68-73) ------------------------------------------------------------
     def _prepare_text_for_embedding(self, text: str) -> str:
@@ -211,6 +328,19 @@ class EmbeddingService:
             return out if to_device else out.cpu().numpy()
         ids = self._tokenize(texts)
         order = sorted(range(n), key=lambda i: -len(ids[i]))  # length buckets: least padding per batch
+        if self._packed is not None and batch_size > self._GRAPH_BATCHES[-1] and n > self._GRAPH_BATCHES[-1]:
+            # chunks of at most PACK_TOKENS tokens (activation memory: ~40 KB per token in fp32), longest strings first
+            s = 0
+            while s < n:
+                e, tokens = s, 0
+                while e < n and (e == s or tokens + len(ids[order[e]]) <= self.PACK_TOKENS):
+                    tokens += len(ids[order[e]])
+                    e += 1
+                idx = order[s:e]
+                pooled = self._packed.forward([ids[i] for i in idx], self.device, self.pooling)
+                out[torch.tensor(idx, device=self.device)] = torch.nn.functional.normalize(pooled.float(), p=2, dim=1)
+                s = e
+            return out if to_device else out.cpu().numpy()
         pad = self._tokenizer.pad_token_id if self._tokenizer is not None else _CharTokenizer.pad_id
         for s in range(0, n, batch_size):
             idx = order[s:s + batch_size]
@@ -230,6 +360,7 @@ class EmbeddingService:
     # Batches of <= 32 strings are padded to a (batch, width) bucket and replayed; padded tokens carry mask 0 (no
     # effect on attention or pooling). Larger batches are compute-bound and run eagerly. Capture failure -> eager.
     _GRAPH_BATCHES = (1, 2, 4, 8, 16, 32)
+    PACK_TOKENS = 65536
     _GRAPH_WIDTHS = (16, 32, 64, 128)
 
     def _forward(self, tok, mask):

@@ -100,6 +100,8 @@ class _TokenClassifier:
     model: a module whose forward(input_ids=, attention_mask=) returns an object with `.logits` [B, T, L];
     tokenizer: a transformers fast tokenizer (offset mapping) or a _CharOffsetTokenizer; id2label: {int: str}."""
 
+    PACK_TOKENS = 65536
+
     def __init__(self, model, tokenizer, id2label: Dict[int, str], device: str = "cpu", max_batch: int = 256):
         import torch
         self.torch = torch
@@ -108,6 +110,18 @@ class _TokenClassifier:
         self.id2label = {int(k): v for k, v in id2label.items()}
         self.device = device
         self.max_batch = max_batch
+        # BERT token classifiers (`.bert` + `.classifier`): batches above 32 strings run the encoder over packed tokens
+        # (embedding_service._PackedBert: no GEMM work on pad tokens, one GEMM per Linear over the whole batch) and the
+        # classifier head over the same packed rows. Anything else, and small batches, keep the padded forward.
+        self._packed = None
+        try:
+            from .embedding_service import _PackedBert
+            bert = getattr(self.model, "bert", None)
+            if (os.getenv("ICD_NER_PACKED", "1") == "1" and bert is not None and hasattr(self.model, "classifier")
+                    and _PackedBert.supported(bert)):
+                self._packed = _PackedBert(bert)
+        except Exception as exc:   # pragma: no cover - an optimisation, never fatal
+            logger.warning("packed NER forward unavailable (%s): padded batches", exc)
 
     # -- tokenisation: ids, character offsets, token strings, special-token mask ---------------------------------
     def _encode(self, text: str):
@@ -136,6 +150,25 @@ class _TokenClassifier:
         order = sorted(range(len(encoded)), key=lambda i: len(encoded[i][0]))   # length-sorted: little padding per batch
         pad = getattr(self.tokenizer, "pad_token_id", None)
         pad = 0 if pad is None else pad
+        if self._packed is not None and len(order) > 32 and self.max_batch > 32:
+            with torch.no_grad():
+                rev = order[::-1]                                  # longest first
+                s = 0
+                while s < len(rev):                                # chunks of at most PACK_TOKENS tokens
+                    e, tokens = s, 0
+                    while e < len(rev) and (e == s or tokens + len(encoded[rev[e]][0]) <= self.PACK_TOKENS):
+                        tokens += len(encoded[rev[e]][0])
+                        e += 1
+                    idx = rev[s:e]
+                    hidden, (lengths, starts, _) = self._packed.hidden_states([encoded[i][0] for i in idx], self.device)
+                    logits = self.model.classifier(hidden)
+                    score, label = torch.softmax(logits.float(), dim=-1).max(dim=-1)
+                    score, label = score.cpu().numpy(), label.cpu().numpy()
+                    for r, i in enumerate(idx):
+                        a, b = int(starts[r]), int(starts[r + 1])
+                        out[i] = (label[a:b].tolist(), score[a:b])
+                    s = e
+            return out
         with torch.no_grad():
             for s in range(0, len(order), self.max_batch):
                 idx = order[s:s + self.max_batch]

@@ -71,3 +71,28 @@ def test_encode_query_batch_256_matches_cpu_and_stays_on_device(services):
     assert np.max(np.abs(np.linalg.norm(a, axis=1) - 1.0)) <= 1e-5
     for i in (0, 17, len(texts) - 6, len(texts) - 3):                      # the batch row == the one-at-a-time call
         assert np.max(np.abs(a[i] - gpu.encode_query(texts[i]))) <= TOL
+
+
+def test_packed_forward_matches_the_padded_hf_forward(services, monkeypatch):
+    """large batches run the encoder over packed tokens (one GEMM per Linear over all tokens, padding only inside the
+    attention): the same embeddings as transformers' padded BertModel forward, on the CPU and on ROCm, with mean and CLS
+    pooling, and whatever the chunking"""
+    gpu, cpu = services
+    texts = _strings()
+    assert gpu._packed is not None and cpu._packed is not None
+    packed = gpu.encode_query_batch(texts, batch_size=256)
+    monkeypatch.setattr(cpu, "_packed", None)
+    monkeypatch.setattr(gpu, "_packed", None)
+    padded_cpu = cpu.encode_query_batch(texts, batch_size=256)            # HF BertModel, padded, fp32 on the CPU
+    padded_gpu = gpu.encode_query_batch(texts, batch_size=256)
+    monkeypatch.undo()
+    assert np.max(np.abs(packed - padded_cpu)) <= TOL and np.max(np.abs(packed - padded_gpu)) <= TOL
+    monkeypatch.setattr(gpu, "PACK_TOKENS", 700)                           # many chunks
+    assert np.max(np.abs(gpu.encode_query_batch(texts, batch_size=256) - packed)) <= TOL
+    monkeypatch.undo()
+    monkeypatch.setattr(gpu, "pooling", "cls")
+    cls_packed = gpu.encode_query_batch(texts, batch_size=256)
+    monkeypatch.setattr(gpu, "_packed", None)
+    monkeypatch.setattr(gpu.model, "pooling", "cls")
+    cls_padded = gpu.encode_query_batch(texts, batch_size=256)
+    assert np.max(np.abs(cls_packed - cls_padded)) <= TOL and np.max(np.abs(cls_packed - packed)) > 1e-3

@@ -101,6 +101,28 @@ def test_token_classifier_equals_transformers_pipeline(gold):
     assert sum(len(o["groups"]) for o in outs) > 100
 
 
+def test_token_classifier_over_packed_tokens_equals_transformers_pipeline(gold, monkeypatch):
+    """batches above 32 strings: the encoder runs over packed tokens and the classifier head over the same rows
+    (_TokenClassifier._packed): the groups of transformers' own pipeline (the fixture), the scores of the padded forward"""
+    model, tok, id2label = tiny_model(gold)
+    clf = _TokenClassifier(model, tok, id2label, "cpu", max_batch=256)
+    assert clf._packed is not None
+    outs = gold["pipeline"]["outputs"]
+    texts = [o["text"] for o in outs]
+    assert len(texts) > 32
+    packed = clf(texts)
+    monkeypatch.setattr(clf, "PACK_TOKENS", 120)          # several chunks
+    chunked = clf(texts)
+    monkeypatch.setattr(clf, "_packed", None)
+    padded = clf(texts)
+    for o, a, b, c in zip(outs, packed, chunked, padded):
+        for got in (a, b):
+            assert [(g["entity_group"], g["word"], g["start"], g["end"]) for g in got] == \
+                   [(g["entity_group"], g["word"], g["start"], g["end"]) for g in o["groups"]], o["text"]
+            assert all(abs(float(g["score"]) - w["score"]) <= 2e-5 for g, w in zip(got, o["groups"]))
+            assert all(abs(float(g["score"]) - float(w["score"])) <= 2e-6 for g, w in zip(got, c))
+
+
 def test_model_load_failure_falls_back_to_the_rules(monkeypatch):
     monkeypatch.setenv("MEDICAL_NER_MODEL", "/nonexistent/ner-model")
     monkeypatch.delenv("ICD_NER_ALLOW_SYNTHETIC", raising=False)

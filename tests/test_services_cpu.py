@@ -47,6 +47,35 @@ def test_embedding_prefixes_and_shapes(emb):
     assert qb.shape == (2, 768) and np.allclose(qb[1], v, atol=2e-6)
 
 
+def test_packed_encoder_equals_the_padded_hf_forward(emb, monkeypatch):
+    """batches above 32 strings run the BERT encoder over packed tokens (embedding_service._PackedBert): the same
+    embeddings as transformers' padded BertModel forward with its attention mask - mean and CLS pooling, any chunking,
+    one-token and over-long strings; the attention groups cover every sequence once"""
+    from rag_project_icd10_amd.services.embedding_service import _PackedBert
+    texts = [l.rstrip("\n") for l in open(os.path.join(GOLDEN, "diagnosis_strings.txt"), encoding="utf-8")][:90]
+    texts += ["", " ", "肺", "x" * 128, "高血压" * 60]
+    assert emb._packed is not None
+    packed = emb.encode_query_batch(texts, batch_size=256)
+    monkeypatch.setattr(emb, "PACK_TOKENS", 300)
+    chunked = emb.encode_query_batch(texts, batch_size=256)
+    monkeypatch.setattr(emb, "_packed", None)
+    padded = emb.encode_query_batch(texts, batch_size=256)
+    monkeypatch.undo()
+    assert packed.shape == (95, 768) and np.max(np.abs(packed - padded)) <= 2e-6 and np.max(np.abs(chunked - padded)) <= 2e-6
+    assert np.max(np.abs(np.linalg.norm(packed, axis=1) - 1)) <= 1e-5
+    monkeypatch.setattr(emb, "pooling", "cls")
+    cls_packed = emb.encode_query_batch(texts, batch_size=256)
+    monkeypatch.setattr(emb, "_packed", None)
+    monkeypatch.setattr(emb.model, "pooling", "cls")
+    assert np.max(np.abs(cls_packed - emb.encode_query_batch(texts, batch_size=256))) <= 2e-6
+    monkeypatch.undo()
+    assert np.allclose(emb.encode_batch(["query: " + t for t in texts[:40]], show_progress=False), packed[:40], atol=2e-6)   # (/embed: sub-batches of 32, padded)
+    for lengths in ([51, 40, 39, 20, 20, 19, 3], [7], [9] * 40, list(range(128, 2, -1))):
+        groups = _PackedBert.plan_groups(lengths)
+        assert sum(c for _, c, _ in groups) == len(lengths) and len(groups) <= _PackedBert.MAX_GROUPS
+        assert all(lengths[f] == longest and f == sum(c for _, c, _ in groups[:i]) for i, (f, c, longest) in enumerate(groups))
+
+
 def test_corpus_store_roundtrip(tmp_path):
     st = CorpusStore.open(str(tmp_path), "icd10", 8)
     assert not st.exists()
