@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define ICD_ABI_VERSION 3   /* 3: icd_stats.sparse_fallback_armed appended (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
+#define ICD_ABI_VERSION 3   /* 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
 #define ICD_MAX_K 128
 
 typedef struct icd_index icd_index;
@@ -246,6 +246,13 @@ int icd_index_set_second_pass(icd_index *idx, int32_t enabled);
 /* Test switch, process-wide, read by icd_index_create: 0 keeps the fp16 corpus copy in row order instead of the
  * golden-ratio permutation (results are identical; only the share of certified queries changes). Default 1. */
 int icd_debug_set_permute(int32_t enabled);
+
+/* Test switch, process-wide, read by icd_index_create (default 1): 0 skips the corpus-shape probe. With it, an index whose
+ * max_nq allows large batches (>= 2 048 queries) searches 2 048 evenly spaced rows of its own corpus once at create and
+ * starts large batches on the wide partition (icd_stats.wide_mode) when most of them could not be certified from the
+ * narrow plan's lists - a corpus of tight families of near-identical rows. A performance decision only: results are
+ * identical either way, and later searches keep deciding from their own counters. */
+int icd_debug_set_create_probe(int32_t enabled);
 
 /* Diagnostic builds only (make ABLATE=1, env ICD_FLAT_VAR with bit 1024): per-wave cycle sums of the coarse kernel,
  * [work-group][wave][8] = {LDS-DMA wait, barrier, stage body, fused select, tiles, ...}. */

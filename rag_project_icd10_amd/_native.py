@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = (
     "icd_abi_version", "icd_last_error", "icd_device_count", "icd_index_create", "icd_index_destroy",
     "icd_index_search", "icd_index_search_reweighted", "icd_merge_topk", "icd_index_lookup_levels",
     "icd_index_stats", "icd_index_set_chunks", "icd_index_debug_counters", "icd_index_set_profiling",
-    "icd_index_last_profile", "icd_index_profile_summary", "icd_debug_set_permute",
+    "icd_index_last_profile", "icd_index_profile_summary", "icd_debug_set_permute", "icd_debug_set_create_probe",
     "icd_hier_rescore",
     "icd_score_stats",
     "icd_cosine_rows",
@@ -92,6 +92,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.icd_group_search.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, vp, vp]
     lib.icd_group_destroy.argtypes = [vp]
     lib.icd_debug_set_permute.argtypes = [i32]
+    lib.icd_debug_set_create_probe.argtypes = [i32]
     lib.icd_hier_rescore.argtypes = [i32, vp, vp, i64, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.icd_score_stats.argtypes = [i32, vp, vp, i64, i32, i32, vp, vp]
     lib.icd_cosine_rows.argtypes = [i32, vp, vp, i64, i64, i32, vp, vp]

@@ -635,18 +635,51 @@ def _tight_family_corpus(nfam, per, dim, spread, nq, seed):
 
 @pytest.mark.parametrize("k", [10, 20])
 def test_family_corpus_is_certified_within_the_call(oracle, k):
-    """300 families x 124 rows of mutual cosine 0.99, 10 000 queries, a FRESH index, no icd_index_set_chunks: the first
-    coarse pass gives a query 5-8 lists of 16 candidates, fewer than its family has rows inside 2 eps of each other, so it
-    certifies nothing; the second coarse pass (flagged queries only, ~20 lists each, sized on the device) must certify them
-    inside the same call: <= 1 % of the batch on the exact re-search, bit-exact results, a few ms per batch (8.9 / 18 ms
-    per batch when every query took the exact re-search). The next large batch starts with the wide partition."""
+    """300 families x 124 rows of mutual cosine 0.99, 10 000 queries, a FRESH index, no icd_index_set_chunks. The narrow plan
+    gives a query 5-8 lists of 16 candidates, fewer than its family has rows inside 2 eps of each other, so its first
+    coarse pass certifies nothing. (a) Default: icd_index_create has asked the corpus itself (2 048 of its rows searched as
+    one batch) and the FIRST user batch already runs on the wide partition: <= 2 ms, <= 1 % on the exact re-search. (b)
+    Without that probe: the second coarse pass (flagged queries only, ~20 lists each, sized on the device) certifies them
+    inside the same call (8.9 / 18 ms per batch when every query took the exact re-search), and the next large batch
+    starts wide. Bit-exact results either way."""
     import time
     import torch
+    from rag_project_icd10_amd import _native
     corpus, queries = _tight_family_corpus(300, 124, 768, 0.10, 10000, 7)
     n = corpus.shape[0]
     levels = icd_levels(n, 8)
-    idx = IcdIndex(corpus, levels, max_nq=10000, max_k=20)
     dq = torch.from_numpy(queries).cuda()
+    sample = np.arange(0, len(queries), 10)
+    os_, oi = oracle.flat_ip_topk(corpus, queries[sample], k)
+    want = oracle.reweight(os_, oi, levels)
+    # (a) the default: the corpus-shape probe at create
+    idx_a = IcdIndex(corpus, levels, max_nq=10000, max_k=20)
+    assert idx_a.stats()["wide_mode"] == 1 and idx_a.stats()["last_nq"] == 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out_a = idx_a.search_reweighted(dq, k)                            # the FIRST user batch of the index
+    torch.cuda.synchronize()
+    fresh_ms = (time.perf_counter() - t0) * 1e3
+    st = idx_a.stats()
+    assert st["last_mode"] == MODE_AUTO and st["wide_mode"] == 1 and st["last_second_pass_lists"] == 0
+    assert st["last_fallback"] <= 0.01 * len(queries), st
+    assert np.array_equal(out_a[2].cpu().numpy()[sample], want[2]) and _bits(out_a[0].cpu().numpy()[sample]) == _bits(want[0])
+    each = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        idx_a.search_reweighted(dq, k)
+        torch.cuda.synchronize()
+        each.append((time.perf_counter() - t0) * 1e3)
+    print(f"family corpus k={k}: fresh index with the create probe: first batch {fresh_ms:.2f} ms, then {' '.join('%.2f' % x for x in each)}")
+    assert sorted(each)[2] <= 2.0, each
+    idx_a.close()
+    # (b) the same without the probe: the second coarse pass inside the call
+    _native.load_library().icd_debug_set_create_probe(0)
+    try:
+        idx = IcdIndex(corpus, levels, max_nq=10000, max_k=20)
+    finally:
+        _native.load_library().icd_debug_set_create_probe(1)
+    assert idx.stats()["wide_mode"] == 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     adj, raw, ids, lv = idx.search_reweighted(dq, k)                  # the FIRST large batch of the index
@@ -656,11 +689,9 @@ def test_family_corpus_is_certified_within_the_call(oracle, k):
     assert st["last_mode"] == MODE_AUTO and st["wide_mode"] == 0
     assert st["last_second_pass"] >= 0.9 * len(queries) and st["last_second_pass_lists"] >= 16   # the first pass certified (almost) nothing
     assert st["last_fallback"] <= 0.01 * len(queries), st                                        # ... the second nearly everything
-    sample = np.arange(0, len(queries), 10)
-    os_, oi = oracle.flat_ip_topk(corpus, queries[sample], k)
-    want = oracle.reweight(os_, oi, levels)
     assert np.array_equal(ids.cpu().numpy()[sample], want[2]) and _bits(adj.cpu().numpy()[sample]) == _bits(want[0])
     assert _bits(raw.cpu().numpy()[sample]) == _bits(want[1])
+    assert all(torch.equal(x, y) for x, y in zip(out_a, (adj, raw, ids, lv)))
     # the second large batch: planned wide from the start (the counters of the first one have arrived), same results
     a2, r2, i2, l2 = idx.search_reweighted(dq, k)
     torch.cuda.synchronize()
@@ -699,7 +730,12 @@ def test_second_pass_switch_and_gaussian_batches_skip_it(oracle):
     idx.close()
     fc, fq = _tight_family_corpus(100, 124, 768, 0.10, 6000, 11)           # 6 000 queries x 97 tiles: 6-7 lists of 16 per query
     fl = icd_levels(len(fc), 12)
-    idx = IcdIndex(fc, fl, max_nq=6000, max_k=10)
+    from rag_project_icd10_amd import _native
+    _native.load_library().icd_debug_set_create_probe(0)                   # (the probe would start this corpus on the wide plan)
+    try:
+        idx = IcdIndex(fc, fl, max_nq=6000, max_k=10)
+    finally:
+        _native.load_library().icd_debug_set_create_probe(1)
     a1 = [t.cpu().numpy() for t in idx.search_reweighted(torch.from_numpy(fq).cuda(), 10)]
     st1 = idx.stats()
     idx.set_second_pass(False)
