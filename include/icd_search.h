@@ -37,7 +37,11 @@
  *     Slots beyond the number of valid hits (n < k, NaN scores) hold id = -1, score = -inf.
  *   - Row ids are `id_base + row index` (id_base != 0 for a shard of a larger corpus).
  *   - Every function returns ICD_OK (0) or a negative icd_status; icd_last_error() gives the text.
- *   - A handle is thread-compatible: one search at a time per handle.
+ *   - Threads: calls on one handle are serialised by the library (a mutex guards the handle's host-side state: plans,
+ *     adaptive counters, profiling ring), so concurrent callers cannot corrupt it. The handle's DEVICE workspace is
+ *     reused by every search: enqueue the searches of one handle on ONE stream (or order the streams yourself); two
+ *     searches of one handle executing concurrently on different streams is a data race on the device. Different
+ *     handles are independent.
  */
 #ifndef ICD_SEARCH_H
 #define ICD_SEARCH_H

@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 
@@ -160,6 +161,7 @@ struct icd_index {
     int sparse_need = SPARSE_DISARM_AFTER;
     int sparse_run_seen = 0;       // the device's run length when the host last saw a completed search
     bool sparse_disarmed = false;  // the last fast-path search went without the streaming pair
+    std::mutex mu;   // host-side state of the handle (plans, adaptive counters, profiling ring): calls on one handle are serialised; the DEVICE workspace still belongs to one stream at a time (header)
     int probe_flagged = -1, probe_left = -1;   // the corpus-shape probe of icd_index_create: queries its first finalize flagged / its second pass left (-1: not run)
     bool pass2_enabled = true;     // test hook (icd_index_set_second_pass)
     bool adapt_enabled = true;     // ... 2 = second pass without the adaptive list count
@@ -752,7 +754,12 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         g.part_scores = x->partc_s; g.part_rows = x->partc_r; g.bounds = x->partc_b; g.P = pc; g.KP = wide_lists ? CO_KP_WIDE : CO_KP; g.nq = nq;
         g.perm_mul = x->perm_mul; g.perm_mod = x->perm_mod;
         g.perm_inv = (x->perm_mod > 0 && (double)x->perm_mod * (double)x->perm_mod < 9007199254740992.0) ? 1.0 / (double)x->perm_mod : 0.0;
-        int rc = launch_finalize<true>(x, g, s);
+        // Wide mode (a corpus of tight families, decided from earlier counters): the window sized for k would certify
+        // next to nothing and its rescoring be thrown away (0.13 of 1.5 ms per 10 000 queries): the widest window takes
+        // every query at once, and the retry below has nothing to add.
+        const bool wide_fin = wide_now && k <= 32 && pc * g.KP >= 128;
+        if (wide_fin) g.wide_window = 1;
+        int rc = wide_fin ? launch_finalize_t<true, false, 4>(x, g, s) : launch_finalize<true>(x, g, s);
         if (rc) return rc;
         // Second chance before the exact re-search. A query fails the first pass when more candidates lie within 2 eps of
         // its k-th best than the window sized for k holds (32 or 64 for k <= 32): a family of near-identical rows, the
@@ -761,7 +768,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         // (profiles/r02_family_corpus_probe.log: 1 000 queries 2.7 / 5.2 ms -> see there). Only launched when the lists can
         // fill a wider window (mid-size batches; 10 000 queries have 5 lists of 16); gated on the flagged count on the device.
         x->fallback_word = 0;
-        if (k <= 32 && pc * g.KP >= 128) {
+        if (!wide_fin && k <= 32 && pc * g.KP >= 128) {
             FinArgs g2 = g;
             g2.qlist = x->flagged; g2.nq_ptr = x->nflag; g2.lists_by_query = 1; g2.wide_window = 1;
             g2.nflag = x->nflag + 1; g2.flagged = x->flagged + x->max_nq_pad;
@@ -1007,6 +1014,7 @@ int icd_index_destroy(icd_index *idx) {
 static int search_common(icd_index *x, const float *queries, int64_t nq, int32_t k, int32_t q_on_device,
                          int32_t mode, Outs user, int32_t out_on_device, void *stream) {
     if (!valid(x)) return fail(ICD_ERR_STATE, "invalid handle");
+    std::lock_guard<std::mutex> guard(x->mu);
     if (nq < 0 || nq > x->max_nq) return fail(ICD_ERR_INVALID, "nq=%lld exceeds max_nq=%d", (long long)nq, x->max_nq);
     if (k <= 0 || k > x->max_k) return fail(ICD_ERR_INVALID, "k=%d exceeds max_k=%d", k, x->max_k);
     if (mode != ICD_MODE_AUTO && mode != ICD_MODE_EXACT) return fail(ICD_ERR_INVALID, "mode=%d", mode);
@@ -1140,6 +1148,7 @@ int icd_cosine_rows(int32_t device, const float *x, const float *y, int64_t y_st
 
 int icd_index_lookup_levels(icd_index *idx, const int64_t *ids, int64_t count, int32_t *out_levels, void *stream) {
     if (!valid(idx)) return fail(ICD_ERR_STATE, "invalid handle");
+    std::lock_guard<std::mutex> guard(idx->mu);
     if (!ids || !out_levels || count < 0) return fail(ICD_ERR_INVALID, "bad arguments");
     if (count == 0) return ICD_OK;
     HIP_TRY(hipSetDevice(idx->device));
@@ -1152,6 +1161,7 @@ int icd_index_lookup_levels(icd_index *idx, const int64_t *ids, int64_t count, i
 
 int icd_index_stats(icd_index *idx, icd_stats *out) {
     if (!valid(idx)) return fail(ICD_ERR_STATE, "invalid handle");
+    std::lock_guard<std::mutex> guard(idx->mu);
     if (!out) return fail(ICD_ERR_INVALID, "out is NULL");
     memset(out, 0, sizeof *out);
     out->n = idx->n; out->dim = idx->dim; out->device = idx->device; out->id_base = idx->id_base;
@@ -1191,6 +1201,7 @@ int icd_debug_set_create_probe(int32_t enabled) {
 
 int icd_index_set_second_pass(icd_index *idx, int32_t enabled) {
     if (!valid(idx)) return fail(ICD_ERR_STATE, "invalid handle");
+    std::lock_guard<std::mutex> guard(idx->mu);
     idx->pass2_enabled = enabled != 0;
     idx->adapt_enabled = enabled == 1;
     if (!idx->pass2_enabled || !idx->adapt_enabled) { idx->wide_mode = false; idx->last_narrow_large = false; }
@@ -1202,6 +1213,7 @@ int icd_index_set_second_pass(icd_index *idx, int32_t enabled) {
 
 int icd_index_set_chunks(icd_index *idx, int32_t chunks) {
     if (!valid(idx)) return fail(ICD_ERR_STATE, "invalid handle");
+    std::lock_guard<std::mutex> guard(idx->mu);
     if (chunks < 0 || chunks > COARSE_MAX_P) return fail(ICD_ERR_INVALID, "chunks=%d (0..%d)", chunks, COARSE_MAX_P);
     idx->chunks_override = chunks;
     return ICD_OK;
@@ -1209,6 +1221,7 @@ int icd_index_set_chunks(icd_index *idx, int32_t chunks) {
 
 int icd_index_debug_counters(icd_index *idx, unsigned long long *out, int32_t count) {
     if (!valid(idx)) return fail(ICD_ERR_STATE, "invalid handle");
+    std::lock_guard<std::mutex> guard(idx->mu);
     if (!out || count <= 0 || count > 8192 * 16) return fail(ICD_ERR_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(idx->device));
     HIP_TRY(hipMemcpy(out, idx->dbg, (size_t)count * 8, hipMemcpyDeviceToHost));
@@ -1217,6 +1230,7 @@ int icd_index_debug_counters(icd_index *idx, unsigned long long *out, int32_t co
 
 int icd_index_set_profiling(icd_index *idx, int32_t enabled) {
     if (!valid(idx)) return fail(ICD_ERR_STATE, "invalid handle");
+    std::lock_guard<std::mutex> guard(idx->mu);
     if (enabled < 0) return fail(ICD_ERR_INVALID, "enabled=%d", enabled);
     idx->profiling = enabled != 0;
     idx->prof_every = enabled > 1 ? enabled : 1;
@@ -1226,6 +1240,7 @@ int icd_index_set_profiling(icd_index *idx, int32_t enabled) {
 
 int icd_index_profile_summary(icd_index *idx, icd_profile *out_mean, int32_t *out_count) {
     if (!valid(idx)) return fail(ICD_ERR_STATE, "invalid handle");
+    std::lock_guard<std::mutex> guard(idx->mu);
     if (!out_mean || !out_count) return fail(ICD_ERR_INVALID, "out is NULL");
     memset(out_mean, 0, sizeof *out_mean);
     HIP_TRY(hipSetDevice(idx->device));
@@ -1262,6 +1277,7 @@ int icd_index_profile_summary(icd_index *idx, icd_profile *out_mean, int32_t *ou
 
 int icd_index_last_profile(icd_index *idx, icd_profile *out) {
     if (!valid(idx)) return fail(ICD_ERR_STATE, "invalid handle");
+    std::lock_guard<std::mutex> guard(idx->mu);
     if (!out) return fail(ICD_ERR_INVALID, "out is NULL");
     memset(out, 0, sizeof *out);
     if (!idx->ev_valid[0] || !idx->ev_valid[NUM_EV]) return fail(ICD_ERR_STATE, "no profiled search recorded");
