@@ -137,6 +137,13 @@ class _PackedBert:
         starts = np.concatenate([[0], np.cumsum(lens_np)])
         flat = np.fromiter(itertools.chain.from_iterable(ids_sorted), dtype=np.int64, count=T)
         pos = np.arange(T, dtype=np.int64) - np.repeat(starts[:-1], lens_np)
+        dtype = self.bert.embeddings.word_embeddings.weight.dtype
+
+        # EVERY host -> device copy of the chunk happens here, before its first kernel: a copy from pageable memory holds
+        # the host until the stream has reached it - behind the encoder's kernels that is the whole forward (the caller
+        # then cannot prepare the search while the GPU encodes: 51 -> 44 ms per 1 000 strings end to end)
+        def up(a):
+            return torch.from_numpy(np.ascontiguousarray(a)).to(device, non_blocking=True)
         groups = []
         for first, count, longest in self.plan_groups(lengths):
             col = np.arange(longest, dtype=np.int64)[None, :]
@@ -144,43 +151,41 @@ class _PackedBert:
             grid = np.where(key, starts[first:first + count, None] + col, T)   # pads point at the zero row behind the tokens
             # (the key mask as the additive bias SDPA would make of a boolean one - once per group, not once per layer;
             #  a group without pads needs none)
-            bias = None if bool(key.all()) else torch.from_numpy(np.where(key, 0.0, -np.inf).astype(np.float32)).to(device, non_blocking=True)[:, None, None, :]
-            groups.append((count, longest, torch.from_numpy(grid.reshape(-1)).to(device, non_blocking=True), bias))
-        ids_t = torch.from_numpy(flat).to(device, non_blocking=True)
-        pos_t = torch.from_numpy(pos).to(device, non_blocking=True)
+            bias = None if bool(key.all()) else up(np.where(key, 0.0, -np.inf).astype(np.float32)).to(dtype)[:, None, None, :]
+            lens_t = up(np.maximum(lens_np[first:first + count], 1e-9).astype(np.float32)).to(dtype)
+            groups.append((count, longest, up(grid.reshape(-1)), bias, lens_t))
+        ids_t, pos_t, first_rows = up(flat), up(pos), up(starts[:-1])
         emb = self.bert.embeddings
         x = emb.word_embeddings(ids_t) + emb.token_type_embeddings.weight[0]
         x = x + emb.position_embeddings(pos_t)
         x = emb.LayerNorm(x)
         H, nh = self.hidden, self.heads
         dh = H // nh
-        groups = [(c, L, g, None if m is None else m.to(x.dtype)) for c, L, g, m in groups]
         qkv = torch.zeros((T + 1, 3 * H), dtype=x.dtype, device=device)   # row T: the pads' zero row
         ctx = torch.empty((T + 1, H), dtype=x.dtype, device=device)       # row T: where the pads' outputs land
         for l in self.layers:
             torch.addmm(l["bqkv"], x, l["wqkv"].t(), out=qkv[:T])
-            for count, longest, grid, key in groups:
+            for count, longest, grid, bias, _ in groups:
                 g = qkv.index_select(0, grid).view(count, longest, 3, nh, dh)
                 q, k, v = (g[:, :, i].transpose(1, 2) for i in range(3))
-                o = F.scaled_dot_product_attention(q, k, v, attn_mask=key)
+                o = F.scaled_dot_product_attention(q, k, v, attn_mask=bias)
                 ctx.index_copy_(0, grid, o.transpose(1, 2).reshape(count * longest, H))
             x = l["attn_out"].LayerNorm(l["attn_out"].dense(ctx[:T]) + x)
             x = l["out"].LayerNorm(l["out"].dense(F.gelu(l["inter"](x))) + x)
-        return x, (lengths, starts, groups)
+        return x, (lengths, starts, groups, first_rows)
 
     @torch.no_grad()
     def forward(self, ids_sorted, device, pooling: str):
         """ids_sorted: token id lists, longest first. Returns the pooled, UN-normalised [n, hidden] in that order."""
-        x, (lengths, starts, groups) = self.hidden_states(ids_sorted, device)
+        x, (lengths, starts, groups, first_rows) = self.hidden_states(ids_sorted, device)
         n, H = len(lengths), self.hidden
         if pooling == "cls":
-            return x.index_select(0, torch.from_numpy(starts[:-1].copy()).to(device))
+            return x.index_select(0, first_rows)
         xe = torch.cat([x, x.new_zeros((1, H))], 0)
         pooled = torch.empty((n, H), dtype=x.dtype, device=device)
         first = 0
-        for count, longest, grid, key in groups:
-            lens = torch.tensor(lengths[first:first + count], dtype=x.dtype, device=device).clamp(min=1e-9)
-            pooled[first:first + count] = xe.index_select(0, grid).view(count, longest, H).sum(1) / lens[:, None]
+        for count, longest, grid, _, lens_t in groups:
+            pooled[first:first + count] = xe.index_select(0, grid).view(count, longest, H).sum(1) / lens_t[:, None]
             first += count
         return pooled
 
@@ -337,8 +342,9 @@ class EmbeddingService:
                     tokens += len(ids[order[e]])
                     e += 1
                 idx = order[s:e]
+                idx_t = torch.tensor(idx, dtype=torch.long).to(self.device, non_blocking=True)   # (before the forward: see _PackedBert)
                 pooled = self._packed.forward([ids[i] for i in idx], self.device, self.pooling)
-                out[torch.tensor(idx, device=self.device)] = torch.nn.functional.normalize(pooled.float(), p=2, dim=1)
+                out.index_copy_(0, idx_t, torch.nn.functional.normalize(pooled.float(), p=2, dim=1))
                 s = e
             return out if to_device else out.cpu().numpy()
         pad = self._tokenizer.pad_token_id if self._tokenizer is not None else _CharTokenizer.pad_id

@@ -160,7 +160,7 @@ class _TokenClassifier:
                         tokens += len(encoded[rev[e]][0])
                         e += 1
                     idx = rev[s:e]
-                    hidden, (lengths, starts, _) = self._packed.hidden_states([encoded[i][0] for i in idx], self.device)
+                    hidden, (lengths, starts, _, _) = self._packed.hidden_states([encoded[i][0] for i in idx], self.device)
                     logits = self.model.classifier(hidden)
                     score, label = torch.softmax(logits.float(), dim=-1).max(dim=-1)
                     score, label = score.cpu().numpy(), label.cpu().numpy()

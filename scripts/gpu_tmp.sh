@@ -1,6 +1,8 @@
+set -e
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -x -q -m gpu > gpurun_out/pytest_full.log 2>&1
-grep -E "^(FAILED|ERROR)|^E  " gpurun_out/pytest_full.log | head -30
-tail -3 gpurun_out/pytest_full.log
-python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "family_corpus_is_certified" -s 2>&1 | grep "family corpus" > gpurun_out/family_probe.log
-cat gpurun_out/family_probe.log
+python -m pytest tests/test_encoder_gpu.py tests/test_ner_gpu.py -x -q -m gpu 2>&1 | tail -2
+python scripts/bench_e2e.py > gpurun_out/e2e_packed.json 2> gpurun_out/e2e_packed.err
+python - <<'PY'
+import json
+d=json.load(open("gpurun_out/e2e_packed.json")); print(d["stages_ms"], d["pipeline_strings_per_s"])
+PY
