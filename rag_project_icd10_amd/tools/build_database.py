@@ -119,23 +119,59 @@ class DatabaseBuilder:
     def vectorize_and_index(self, records: List[Dict], encode_batch: int = 2048) -> bool:
         try:
             insert_batch = self._calculate_optimal_batch_size(len(records))
-            # encode in large bucketed batches, insert in the reference's batch size (:183-192,:240)
+
+            def insert_chunk(start, chunk, vectors) -> bool:
+                for s in range(0, len(chunk), insert_batch):
+                    rows = chunk[s:s + insert_batch]
+                    if not self.milvus_service.insert_records(rows, list(vectors[s:s + insert_batch])):
+                        logger.error("批次 %d 插入失败", (start + s) // insert_batch + 1)
+                        return False
+                return True
+
+            # encode in large bucketed batches, insert in the reference's batch size (:183-192,:240). On the GPU the two
+            # overlap: chunk i's vectors are copied to pinned host memory behind its forward, chunk i + 1's forward is
+            # enqueued, and only then is chunk i appended to the store (fsynced inserts of 128) - the host writes while
+            # the device encodes (profiles/r03_build_full.json: 4.5 -> 3.6 s for the 40 474 rows). Same rows, same order.
+            pending = None
             for start in range(0, len(records), encode_batch):
                 chunk = records[start:start + encode_batch]
                 texts = [r.get("semantic_text", r.get("preferred_zh", "")) for r in chunk]
-                vectors = self.embedding_service.encode_query_batch(texts)
-                for s in range(0, len(chunk), insert_batch):
-                    rows = chunk[s:s + insert_batch]
-                    ok = self.milvus_service.insert_records(rows, list(vectors[s:s + insert_batch]))
-                    if not ok:
-                        logger.error("批次 %d 插入失败", (start + s) // insert_batch + 1)
-                        return False
+                vectors = self._encode_for_insert(texts)
+                if pending is not None and not insert_chunk(pending[0], pending[1], pending[2]()):
+                    return False
+                pending = (start, chunk, vectors)
+            if pending is not None and not insert_chunk(pending[0], pending[1], pending[2]()):
+                return False
             if not self.milvus_service.load_collection():
                 logger.warning("集合加载失败，但数据插入成功")
             return True
         except Exception as exc:
             logger.error("向量化和索引失败: %s", exc)
             return False
+
+    def _encode_for_insert(self, texts: List[str]):
+        """-> a callable that returns the float32 [n, dim] numpy vectors of `texts`. With a CUDA encoder that offers the
+        device path, the forward and the copy to pinned host memory are only ENQUEUED here; the callable waits for the
+        copy's event (and for nothing enqueued after it)."""
+        es = self.embedding_service
+        try:
+            import torch
+            on_gpu = str(getattr(es, "device", "cpu")).startswith("cuda") and torch.cuda.is_available()
+        except Exception:   # pragma: no cover
+            on_gpu = False
+        if not on_gpu:
+            vectors = es.encode_query_batch(texts)
+            return lambda: vectors
+        dev = es.encode_query_batch(texts, to_device=True)
+        host = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=True)
+        host.copy_(dev, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+
+        def wait():
+            done.synchronize()
+            return host.numpy()
+        return wait
 
     def verify_database(self) -> Dict[str, Any]:
         try:

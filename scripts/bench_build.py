@@ -131,24 +131,32 @@ def main():
     b.initialize_services()
     sync()
     t_init = time.perf_counter() - t0
+    # (build_full_database calls initialize_services itself: keep the instance we time)
+    b.initialize_services = lambda: None
+    sync()
+    t0 = time.perf_counter()
+    ok = b.build_full_database(csv_path, rebuild=True)      # THE measurement: nothing instrumented, encode and append overlap
+    sync()
+    t_build = time.perf_counter() - t0
+    assert ok, "build_full_database failed"
+    # the stage split comes from a SECOND build in which every stage is bracketed by device synchronisation (so a stage owns
+    # the GPU work it enqueued): the stages then run one after the other and their sum is larger than the build above
     timers = {"csv_to_records": Timer(b, "load_csv_data", sync),
               "tokenise_and_encode": Timer(b.embedding_service, "encode_query_batch", sync),
               "store_append": Timer(b.milvus_service, "insert_records", sync),
               "index_create_and_load": Timer(b.milvus_service, "load_collection", sync),
               "verify": Timer(b, "verify_database", sync)}
-    # (build_full_database calls initialize_services itself: keep the instance we instrumented)
-    b.initialize_services = lambda: None
     t0 = time.perf_counter()
     ok = b.build_full_database(csv_path, rebuild=True)
     sync()
-    t_build = time.perf_counter() - t0
-    assert ok, "build_full_database failed"
+    t_build_sync = time.perf_counter() - t0
+    assert ok, "build_full_database (synchronised run) failed"
     stats = b.milvus_service.get_collection_stats()
     recs = b.milvus_service.client.records
     st = sorted(len(r["semantic_text"]) for r in recs)
     levels = {str(l): sum(1 for r in recs if r["level"] == l) for l in (1, 2, 3)}
     stages = {k: {"s": round(v.t, 4), "calls": v.n} for k, v in timers.items()}
-    other = t_build - sum(v.t for v in timers.values())
+    other = t_build_sync - sum(v.t for v in timers.values())
     out = {
         "what": "DatabaseBuilder.build_full_database(csv, rebuild=True) on one MI355X: CSV -> records -> batched encode on ROCm -> "
                 "store -> HBM index -> verify; a synthetic CSV of the real one's shape (tests/golden/csv_shape.json)",
@@ -156,7 +164,9 @@ def main():
         "semantic_text_len": {"mean": sum(st) / len(st), "p50": st[len(st) // 2], "p90": st[int(len(st) * 0.9)], "p99": st[int(len(st) * 0.99)], "max": st[-1]},
         "semantic_text_len_real": {k: shape["semantic_text_len"][k] for k in ("mean", "p50", "p90", "p99", "max")},
         "build_s": round(t_build, 3), "rows_per_s": round(stats["num_entities"] / t_build, 1),
-        "initialize_services_s": round(t_init, 3), "stages": stages, "unattributed_s": round(other, 4),
+        "initialize_services_s": round(t_init, 3),
+        "synchronised_run": {"what": "a second build with every stage bracketed by device synchronisation (no overlap of encode and append): the stage split",
+                             "build_s": round(t_build_sync, 3), "stages": stages, "unattributed_s": round(other, 4)},
         "encoder": b.embedding_service.get_model_info(), "store_bytes": sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(os.environ["MILVUS_DB_PATH"]) for f in fs),
     }
     # the reference's shape for the same work: one batch-1 forward per record, on the host CPU and on the GPU (a sample)
