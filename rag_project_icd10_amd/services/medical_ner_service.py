@@ -138,6 +138,27 @@ class _TokenClassifier:
         tokens = [text[offsets[i][0]:offsets[i][1]] if ids[i] == unk else tokens[i] for i in range(len(ids))]
         return ids, offsets, tokens, list(enc["special_tokens_mask"])
 
+    def _encode_all(self, texts: Sequence[str]):
+        """_encode for many strings: ONE call into the fast tokenizer (its Rust side encodes the batch in parallel; one
+        Python call per string was 0.15 ms of 0.38 ms per string on the host). No padding is requested, so every string
+        gets what the single call gives it."""
+        tk = self.tokenizer
+        if isinstance(tk, _CharOffsetTokenizer) or len(texts) < 2:
+            return [self._encode(t) for t in texts]
+        limit = getattr(tk, "model_max_length", 0)
+        enc = tk(list(texts), return_offsets_mapping=True, return_special_tokens_mask=True,
+                 truncation=bool(limit and 0 < limit < 10 ** 9))
+        unk = tk.unk_token_id
+        out = []
+        for i, text in enumerate(texts):
+            ids = list(enc["input_ids"][i])
+            offsets = [tuple(o) for o in enc["offset_mapping"][i]]
+            tokens = tk.convert_ids_to_tokens(ids)
+            if unk in ids:
+                tokens = [text[offsets[t][0]:offsets[t][1]] if ids[t] == unk else tokens[t] for t in range(len(ids))]
+            out.append((ids, offsets, tokens, list(enc["special_tokens_mask"][i])))
+        return out
+
     def _join(self, tokens: Sequence[str]) -> str:
         tk = self.tokenizer
         return tk.join(tokens) if isinstance(tk, _CharOffsetTokenizer) else tk.convert_tokens_to_string(list(tokens))
@@ -205,7 +226,9 @@ class _TokenClassifier:
                 return
             run = keep[i0:i1]
             # group score: np.mean(np.nanmean([token scores])) of float32 scalars = the float32 mean of the slice
-            groups.append({"entity_group": group, "score": np.asarray([scores[t] for t in run], dtype=np.float32).mean(),
+            # (special tokens sit at the ends only: a run is a contiguous slice of the float32 score array)
+            groups.append({"entity_group": group, "score": (scores[run[0]:run[-1] + 1].mean() if run[-1] - run[0] + 1 == len(run)
+                                                            else np.asarray([scores[t] for t in run], dtype=np.float32).mean()),
                            "word": self._join([tokens[t] for t in run]),
                            "start": int(offsets[run[0]][0]), "end": int(offsets[run[-1]][1])})
         for i in range(1, len(keep)):
@@ -218,7 +241,7 @@ class _TokenClassifier:
         return groups
 
     def __call__(self, texts: Sequence[str]) -> List[List[Dict[str, Any]]]:
-        encoded = [self._encode(t) for t in texts]
+        encoded = self._encode_all(texts)
         return [self._groups(e, lab, sc) for e, (lab, sc) in zip(encoded, self._forward(encoded))]
 
 
