@@ -69,7 +69,7 @@ def test_packed_encoder_equals_the_padded_hf_forward(emb, monkeypatch):
     monkeypatch.setattr(emb.model, "pooling", "cls")
     assert np.max(np.abs(cls_packed - emb.encode_query_batch(texts, batch_size=256))) <= 2e-6
     monkeypatch.undo()
-    assert np.allclose(emb.encode_batch(["query: " + t for t in texts[:40]], show_progress=False), packed[:40], atol=2e-6)   # (/embed: sub-batches of 32, padded)
+    assert np.allclose(emb.encode_batch(["query: " + t for t in texts[:40]], show_progress=False), packed[:40], atol=2e-6)   # (/embed: the same forward for more than 32 texts)
     for lengths in ([51, 40, 39, 20, 20, 19, 3], [7], [9] * 40, list(range(128, 2, -1))):
         groups = _PackedBert.plan_groups(lengths)
         assert sum(c for _, c, _ in groups) == len(lengths) and len(groups) <= _PackedBert.MAX_GROUPS
