@@ -739,7 +739,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
 #define ICD_FV_CASE(V) else if (v == V) rc = launch_coarse_flat<768, V>(x, a, nwg, s);
             ICD_FV_CASE(0) ICD_FV_CASE(139) ICD_FV_CASE(143) ICD_FV_CASE(155) ICD_FV_CASE(171) ICD_FV_CASE(187) ICD_FV_CASE(2187) ICD_FV_CASE(2203)
             ICD_FV_CASE(2235) ICD_FV_CASE(1163) ICD_FV_CASE(4235) ICD_FV_CASE(4251)
-            ICD_FV_CASE(34971) ICD_FV_CASE(39067) ICD_FV_CASE(100507) ICD_FV_CASE(104603) ICD_FV_CASE(32923) ICD_FV_CASE(32955) ICD_FV_CASE(34843) ICD_FV_CASE(166043) ICD_FV_CASE(297115) ICD_FV_CASE(559259) ICD_FV_CASE(1083547)
+            ICD_FV_CASE(34971) ICD_FV_CASE(35995) ICD_FV_CASE(39067) ICD_FV_CASE(100507) ICD_FV_CASE(104603) ICD_FV_CASE(32923) ICD_FV_CASE(32955) ICD_FV_CASE(34843) ICD_FV_CASE(166043) ICD_FV_CASE(297115) ICD_FV_CASE(559259) ICD_FV_CASE(1083547)
 #undef ICD_FV_CASE
             else return fail(ICD_ERR_INVALID, "ICD_FLAT_VAR=%d is not built", v);
         }
