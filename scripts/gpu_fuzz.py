@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--seed", type=int, default=7)
     args = ap.parse_args()
     import oracle as orc
+    from rag_project_icd10_amd import _native
     from rag_project_icd10_amd._native import MODE_AUTO, MODE_EXACT, IcdIndex
     rng = np.random.default_rng(args.seed)
     bad = 0
@@ -84,8 +85,18 @@ def main():
             queries[rng.random(nq) < 0.5, rng.integers(0, dim)] = 3e5
         r = rng.random(n)
         levels = np.where(r < 0.1243, 1, np.where(r < 0.4234, 2, 3)).astype(np.int32)
+        probe = bool(rng.random() < 0.75)                       # the corpus-shape probe of icd_index_create, mostly on
+        _native.load_library().icd_debug_set_create_probe(1 if probe else 0)
         idx = IcdIndex(corpus, levels, max_nq=nq, max_k=k, id_base=id_base)
+        _native.load_library().icd_debug_set_create_probe(1)
+        sp = int(rng.choice([1, 1, 1, 2, 0]))                   # adaptive (default) / second pass without the adaptive parts / off
+        if sp != 1:
+            idx.set_second_pass(sp != 0, adaptive=False)
         s, i = idx.search(queries, k, mode)
+        long_run = bool(rng.random() < 0.25) and nq <= 3000 and n <= 37000
+        if long_run:              # a long history: the streaming fallback's launches are dropped after 96 clean searches
+            for _ in range(110):
+                idx.search_reweighted(queries, k, mode)
         if kind == "family":      # more searches on the same index: counters arrive, the second pass disarms / wide mode switches on
             for _ in range(int(rng.integers(0, 6))):
                 idx.search(queries, k, mode)
@@ -101,7 +112,7 @@ def main():
               and np.array_equal(lv[sample], want[3]))
         bad += 0 if ok else 1
         print(f"{'ok  ' if ok else 'FAIL'} case {case:3d}: n={n} nq={nq} dim={dim} k={k} kind={kind} mode={'auto' if mode == MODE_AUTO else 'exact'} "
-              f"id_base={id_base} -> last_mode={st['last_mode']} lists={st['last_chunks']} second_pass={st['last_second_pass']} wide={st['wide_mode']} fallback={st['last_fallback']}", flush=True)
+              f"id_base={id_base} probe={int(probe)} sp={sp} long={int(long_run)} -> sparse_armed={st['sparse_fallback_armed']} last_mode={st['last_mode']} lists={st['last_chunks']} second_pass={st['last_second_pass']} wide={st['wide_mode']} fallback={st['last_fallback']}", flush=True)
     print(f"gpu_fuzz: {args.cases - bad} ok, {bad} failed in {time.time() - t0:.1f} s")
     sys.exit(1 if bad else 0)
 
