@@ -28,6 +28,20 @@ for packed in (True, False):
         es.encode_query_batch(strings, batch_size=256, to_device=True)
     torch.cuda.synchronize()
     print(f"{'packed tokens' if packed else 'padded, batch 256'}: {(time.perf_counter() - t0) / 8 * 1e3:6.1f} ms")
+from rag_project_icd10_amd.services.embedding_service import _PackedBert
+es._packed = pk
+for ratio in (0.9, 0.75, 0.6, 0.5, 0.4, 0.3):
+    _PackedBert.GROUP_RATIO = ratio
+    groups = _PackedBert.plan_groups(sorted((int(x) for x in lens), reverse=True))
+    for _ in range(3):
+        es.encode_query_batch(strings, batch_size=256)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(8):
+        es.encode_query_batch(strings, batch_size=256, to_device=True)
+    torch.cuda.synchronize()
+    print(f"packed, attention groups within {ratio:.2f} of their longest: {len(groups)} groups, padded attention tokens {sum(c * L for _, c, L in groups)}: {(time.perf_counter() - t0) / 8 * 1e3:6.1f} ms")
+_PackedBert.GROUP_RATIO = 0.75
 es._packed = None
 for bs in (64, 128, 256, 512, 1000):
     padded = 0
