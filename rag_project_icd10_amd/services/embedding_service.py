@@ -81,8 +81,8 @@ class _PackedBert:
     chunk, Q / K / V are one fused GEMM, and only the attention itself sees a padded view: the sequences, sorted by
     length, are cut into a few groups of similar length, each gathered to [n_g, L_g] (pads read a zero row), attended
     with a key mask, and scattered back (profiles/r03_encoder_packed.log). Same weights as the module it is built from
-    (shared storage, except the fused QKV copy); post-LN BERT with absolute positions and erf-GELU only - anything else
-    keeps the padded HF forward. Arithmetic restated from transformers' BertModel (BertEmbeddings: (word + type) +
+    (shared storage, except the fused QKV copy); post-LN BERT / RoBERTa / XLM-R encoders with absolute positions and erf-GELU
+    only - anything else keeps the padded HF forward. Arithmetic restated from transformers' BertModel (BertEmbeddings: (word + type) +
     position -> LayerNorm; BertSelfAttention via scaled_dot_product_attention; BertSelfOutput / BertOutput: dense ->
     LayerNorm(x + residual)), the published architecture the reference reaches through sentence-transformers.
     """
@@ -93,7 +93,7 @@ class _PackedBert:
     @staticmethod
     def supported(bert) -> bool:
         cfg = bert.config
-        return (type(bert).__name__ == "BertModel" and getattr(cfg, "position_embedding_type", None) in (None, "absolute")
+        return (type(bert).__name__ in ("BertModel", "XLMRobertaModel", "RobertaModel") and getattr(cfg, "position_embedding_type", None) in (None, "absolute")
                 and getattr(cfg, "hidden_act", "gelu") == "gelu" and not getattr(cfg, "is_decoder", False))
 
     def __init__(self, bert):
@@ -102,6 +102,9 @@ class _PackedBert:
         self.heads = int(cfg.num_attention_heads)
         self.hidden = int(cfg.hidden_size)
         self.eps = float(cfg.layer_norm_eps)
+        # RoBERTa-family embeddings (the reference's default checkpoint, multilingual-e5, is XLM-R) number positions from
+        # padding_idx + 1 (create_position_ids_from_input_ids); BERT from 0
+        self.pos_offset = int(bert.embeddings.padding_idx) + 1 if type(bert).__name__ != "BertModel" else 0
         self.layers = []
         for l in bert.encoder.layer:
             a = l.attention.self
@@ -136,7 +139,7 @@ class _PackedBert:
         lens_np = np.asarray(lengths, dtype=np.int64)
         starts = np.concatenate([[0], np.cumsum(lens_np)])
         flat = np.fromiter(itertools.chain.from_iterable(ids_sorted), dtype=np.int64, count=T)
-        pos = np.arange(T, dtype=np.int64) - np.repeat(starts[:-1], lens_np)
+        pos = np.arange(T, dtype=np.int64) - np.repeat(starts[:-1], lens_np) + self.pos_offset
         dtype = self.bert.embeddings.word_embeddings.weight.dtype
 
         # EVERY host -> device copy of the chunk happens here, before its first kernel: a copy from pageable memory holds

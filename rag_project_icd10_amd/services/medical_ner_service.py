@@ -116,7 +116,7 @@ class _TokenClassifier:
         self._packed = None
         try:
             from .embedding_service import _PackedBert
-            bert = getattr(self.model, "bert", None)
+            bert = getattr(self.model, "bert", None) or getattr(self.model, "roberta", None)   # (BertFor... / (XLM)RobertaForTokenClassification)
             if (os.getenv("ICD_NER_PACKED", "1") == "1" and bert is not None and hasattr(self.model, "classifier")
                     and _PackedBert.supported(bert)):
                 self._packed = _PackedBert(bert)

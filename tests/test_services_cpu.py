@@ -76,6 +76,38 @@ def test_packed_encoder_equals_the_padded_hf_forward(emb, monkeypatch):
         assert all(lengths[f] == longest and f == sum(c for _, c, _ in groups[:i]) for i, (f, c, longest) in enumerate(groups))
 
 
+def test_packed_encoder_covers_the_roberta_family():
+    """the reference's default checkpoint (intfloat/multilingual-e5-large-instruct) is XLM-R: the same encoder stack with
+    positions numbered from padding_idx + 1. The packed forward's hidden states equal transformers' padded forward token for
+    token (seeded random-init XLM-R and BERT of a small shape; a decoder or relative positions are refused)"""
+    import torch
+    from transformers import BertConfig, BertModel, XLMRobertaConfig, XLMRobertaModel
+    from rag_project_icd10_amd.services.embedding_service import _PackedBert
+    rng = np.random.default_rng(0)
+    seqs = sorted([[0] + list(rng.integers(3, 500, int(L))) + [2] for L in rng.integers(1, 40, 50)], key=len, reverse=True)
+    width = len(seqs[0])
+    for make, pad in ((lambda: XLMRobertaModel(XLMRobertaConfig(vocab_size=500, hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+                                                                  intermediate_size=128, max_position_embeddings=70, pad_token_id=1,
+                                                                  type_vocab_size=1), add_pooling_layer=False), 1),
+                      (lambda: BertModel(BertConfig(vocab_size=500, hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+                                                    intermediate_size=128, max_position_embeddings=70), add_pooling_layer=False), 0)):
+        torch.manual_seed(0)
+        model = make().eval()
+        assert _PackedBert.supported(model)
+        x, (lengths, starts, _, _) = _PackedBert(model).hidden_states(seqs, "cpu")
+        ids = torch.full((len(seqs), width), pad)
+        mask = torch.zeros((len(seqs), width), dtype=torch.long)
+        for r, sq in enumerate(seqs):
+            ids[r, :len(sq)] = torch.tensor(sq)
+            mask[r, :len(sq)] = 1
+        with torch.no_grad():
+            ref = model(input_ids=ids, attention_mask=mask).last_hidden_state
+        worst = max(float((x[starts[r]:starts[r + 1]] - ref[r, :lengths[r]]).abs().max()) for r in range(len(seqs)))
+        assert worst <= 5e-6, (type(model).__name__, worst)
+    assert not _PackedBert.supported(BertModel(BertConfig(vocab_size=50, hidden_size=32, num_hidden_layers=1, num_attention_heads=2,
+                                                          intermediate_size=64, is_decoder=True)))
+
+
 def test_corpus_store_roundtrip(tmp_path):
     st = CorpusStore.open(str(tmp_path), "icd10", 8)
     assert not st.exists()
