@@ -163,6 +163,63 @@ class _TokenClassifier:
         tk = self.tokenizer
         return tk.join(tokens) if isinstance(tk, _CharOffsetTokenizer) else tk.convert_tokens_to_string(list(tokens))
 
+    # -- small batches replay a captured HIP graph (a request's one to a few strings: ~150 tiny kernels whose launch overhead,
+    # not their arithmetic, sets the latency - 3.1 ms eager for one string; the encoder does the same, embedding_service.py).
+    # Batches of <= 32 strings and <= 128 tokens are padded to a (batch, width) bucket; padded tokens carry mask 0 and their
+    # outputs are never read. Capture failure -> eager, for good.
+    _GRAPH_BATCHES = (1, 2, 4, 8, 16, 32)
+    _GRAPH_WIDTHS = (16, 32, 64, 128)
+
+    def _logits_to_scores(self, logits):
+        # (the pipeline does this softmax in numpy float32 on the host: the same formula, equal to ~1e-7)
+        return self.torch.softmax(logits.float(), dim=-1).max(dim=-1)
+
+    def _scores(self, ids, mask, pad):
+        """ids, mask: numpy int64 [b, w] -> (probability of the best label, its index) per token, device tensors [b, w]"""
+        torch = self.torch
+        b, w = ids.shape
+        graphs = getattr(self, "_graphs", None)
+        if graphs is None and not hasattr(self, "_graphs"):
+            graphs = self._graphs = {} if (str(self.device).startswith("cuda") and os.getenv("ICD_NER_GRAPHS", "1") == "1") else None
+        if graphs is None or b > self._GRAPH_BATCHES[-1] or w > self._GRAPH_WIDTHS[-1]:
+            logits = self.model(input_ids=torch.from_numpy(ids).to(self.device),
+                                attention_mask=torch.from_numpy(mask).to(self.device)).logits
+            return self._logits_to_scores(logits)
+        bb = next(x for x in self._GRAPH_BATCHES if x >= b)
+        wb = next(x for x in self._GRAPH_WIDTHS if x >= w)
+        entry = graphs.get((bb, wb))
+        if entry is None:
+            try:
+                entry = self._capture(bb, wb)
+            except Exception as exc:  # pragma: no cover - depends on the runtime
+                logger.warning("HIP graph capture failed (%s): the token classifier runs eagerly", exc)
+                self._graphs = None
+                return self._scores(ids, mask, pad)
+            graphs[(bb, wb)] = entry
+        g, sids, smask, sscore, slabel = entry
+        sids.fill_(pad)
+        smask.zero_()
+        smask[b:, 0] = 1   # (unused rows: one live token, so no row of the attention is fully masked)
+        sids[:b, :w].copy_(torch.from_numpy(ids), non_blocking=True)
+        smask[:b, :w].copy_(torch.from_numpy(mask), non_blocking=True)
+        g.replay()
+        return sscore[:b, :w].clone(), slabel[:b, :w].clone()
+
+    def _capture(self, bb: int, wb: int):
+        torch = self.torch
+        sids = torch.zeros((bb, wb), dtype=torch.long, device=self.device)
+        smask = torch.ones((bb, wb), dtype=torch.long, device=self.device)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):
+                self._logits_to_scores(self.model(input_ids=sids, attention_mask=smask).logits)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g), torch.no_grad():
+            sscore, slabel = self._logits_to_scores(self.model(input_ids=sids, attention_mask=smask).logits)
+        return g, sids, smask, sscore, slabel
+
     # -- forward: one padded batch per max_batch strings; softmax, best label and its probability per token on the device
     def _forward(self, encoded):
         """-> per string (label index per token, its float32 probability per token), as Python lists"""
@@ -200,10 +257,7 @@ class _TokenClassifier:
                     n = len(encoded[i][0])
                     ids[r, :n] = encoded[i][0]
                     mask[r, :n] = 1
-                logits = self.model(input_ids=torch.from_numpy(ids).to(self.device),
-                                    attention_mask=torch.from_numpy(mask).to(self.device)).logits
-                # (the pipeline does this softmax in numpy float32 on the host: the same formula, equal to ~1e-7)
-                score, label = torch.softmax(logits.float(), dim=-1).max(dim=-1)
+                score, label = self._scores(ids, mask, pad)
                 score, label = score.cpu().numpy(), label.cpu().numpy()
                 for r, i in enumerate(idx):
                     n = len(encoded[i][0])
