@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define ICD_ABI_VERSION 3   /* 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
+#define ICD_ABI_VERSION 3   /* 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
 #define ICD_MAX_K 128
 
 typedef struct icd_index icd_index;
@@ -233,6 +233,18 @@ int icd_score_stats(int32_t device, const double *scores, const int32_t *order, 
  */
 int icd_cosine_rows(int32_t device, const float *x, const float *y, int64_t y_stride, int64_t nq, int32_t dim,
                     double *out, void *stream);
+
+/* The self-attention of the packed BERT encoder (row a3-a5 / N1 of SURVEY.md section 8: the text -> vector forward the
+ * reference reaches through sentence-transformers; rag_project_icd10_amd/services/embedding_service.py _PackedBert runs
+ * every Linear of the encoder over packed tokens and calls this for the attention): softmax(Q K^T / sqrt(64)) V per
+ * sequence and head, fp32.
+ *   qkv      [T][ld] device fp32: Q | K | V of a token side by side (ld >= 3 * heads * 64, a multiple of 4)
+ *   starts   [nseq + 1] device int32: first packed row of every sequence (sequence s is rows starts[s] .. starts[s + 1])
+ *   max_len  the longest sequence (host-known): 1 .. 64 - longer sequences stay with the caller's padded attention
+ *   out      [T][out_ld] device fp32: heads side by side
+ * Enqueues one launch on `stream`. */
+int icd_packed_attention(int32_t device, const float *qkv, int64_t ld, const int32_t *starts, int32_t nseq, int32_t heads,
+                         int32_t head_dim, int32_t max_len, float *out, int64_t out_ld, void *stream);
 
 /* (last_fallback: every search copies its counters to pinned host memory behind itself, on its stream; this call waits
  *  for the last search of this handle - an event on that stream - and for nothing else on the device) */

@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = (
     "icd_abi_version", "icd_last_error", "icd_device_count", "icd_index_create", "icd_index_destroy",
     "icd_index_search", "icd_index_search_reweighted", "icd_merge_topk", "icd_index_lookup_levels",
     "icd_index_stats", "icd_index_set_chunks", "icd_index_debug_counters", "icd_index_set_profiling",
-    "icd_index_last_profile", "icd_index_profile_summary", "icd_debug_set_permute", "icd_debug_set_create_probe",
+    "icd_index_last_profile", "icd_index_profile_summary", "icd_debug_set_permute", "icd_debug_set_create_probe", "icd_packed_attention",
     "icd_hier_rescore",
     "icd_score_stats",
     "icd_cosine_rows",
@@ -93,6 +93,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.icd_group_destroy.argtypes = [vp]
     lib.icd_debug_set_permute.argtypes = [i32]
     lib.icd_debug_set_create_probe.argtypes = [i32]
+    lib.icd_packed_attention.argtypes = [i32, vp, i64, vp, i32, i32, i32, i32, vp, i64, vp]
     lib.icd_hier_rescore.argtypes = [i32, vp, vp, i64, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.icd_score_stats.argtypes = [i32, vp, vp, i64, i32, i32, vp, vp]
     lib.icd_cosine_rows.argtypes = [i32, vp, vp, i64, i64, i32, vp, vp]
@@ -466,6 +467,18 @@ def cosine_rows(x, y):
     out = torch.empty((nq,), dtype=torch.float64, device=dev)
     _check(lib, lib.icd_cosine_rows(dev.index, x.data_ptr(), y.data_ptr(), stride, nq, dim, out.data_ptr(),
                                     _current_stream_ptr(dev.index)))
+    return out
+
+
+def packed_attention(qkv, starts, nseq: int, heads: int, max_len: int, out):
+    """icd_packed_attention: softmax(Q K^T / 8) V per sequence and head over packed tokens. qkv f32 [T(+1), 3 * heads * 64]
+    (row-contiguous), starts int32 [nseq + 1] on the same GPU, out f32 [T(+1), heads * 64]; sequences of at most 64 tokens.
+    Enqueued on the current stream."""
+    lib = load_library()
+    dev = qkv.device
+    assert qkv.is_cuda and qkv.stride(1) == 1 and out.stride(1) == 1 and starts.is_cuda
+    _check(lib, lib.icd_packed_attention(dev.index, qkv.data_ptr(), qkv.stride(0), starts.data_ptr(), int(nseq), int(heads), 64,
+                                         int(max_len), out.data_ptr(), out.stride(0), _current_stream_ptr(dev.index)))
     return out
 
 

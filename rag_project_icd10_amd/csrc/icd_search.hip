@@ -19,6 +19,7 @@
 #include "../../experiments/r02_w8_kernel/coarse_w8_kernel.hpp"   // (A/B builds only: eight waves, two per SIMD)
 #include "../../experiments/r02_g16_kernel/coarse_g16_kernel.hpp" // (A/B builds only: the flat geometry on 16x16x32)
 #endif
+#include "attention_kernel.hpp"
 #include "exact_kernel.hpp"
 #include "finalize.hpp"
 #include "hier_kernel.hpp"
@@ -1142,6 +1143,25 @@ int icd_cosine_rows(int32_t device, const float *x, const float *y, int64_t y_st
     CosArgs a{};
     a.x = x; a.y = y; a.y_stride = y_stride; a.nq = (int)nq; a.dim = dim; a.out = out;
     hipLaunchKernelGGL(cosine_rows_kernel, dim3(((int)nq + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    HIP_TRY(hipGetLastError());
+    return ICD_OK;
+}
+
+int icd_packed_attention(int32_t device, const float *qkv, int64_t ld, const int32_t *starts, int32_t nseq, int32_t heads,
+                         int32_t head_dim, int32_t max_len, float *out, int64_t out_ld, void *stream) {
+    if (!qkv || !starts || !out) return fail(ICD_ERR_INVALID, "pointer is NULL");
+    if (head_dim != ATT_HEAD_DIM) return fail(ICD_ERR_UNSUPPORTED, "head_dim=%d (this kernel is written for %d)", head_dim, ATT_HEAD_DIM);
+    if (max_len < 1 || max_len > ATT_MAX_LEN) return fail(ICD_ERR_UNSUPPORTED, "max_len=%d (1..%d tokens per sequence)", max_len, ATT_MAX_LEN);
+    if (nseq < 0 || heads <= 0 || (int64_t)nseq * heads > 0x7FFFFFF0LL) return fail(ICD_ERR_INVALID, "nseq=%d heads=%d", nseq, heads);
+    const int64_t hidden = (int64_t)heads * head_dim;
+    if (ld < 3 * hidden || out_ld < hidden || ld % 4 != 0) return fail(ICD_ERR_INVALID, "ld=%lld out_ld=%lld for hidden=%lld", (long long)ld, (long long)out_ld, (long long)hidden);
+    if (nseq == 0) return ICD_OK;
+    HIP_TRY(hipSetDevice(device));
+    PackedAttnArgs a{};
+    a.qkv = qkv; a.out = out; a.starts = starts; a.nseq = nseq; a.heads = heads; a.ld = ld; a.out_ld = out_ld; a.hidden = (int)hidden;
+    a.scale = 0.125f;   // 1 / sqrt(64), exact
+    const int tasks = nseq * heads;
+    hipLaunchKernelGGL(packed_attention_kernel, dim3((tasks + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     HIP_TRY(hipGetLastError());
     return ICD_OK;
 }

@@ -105,6 +105,17 @@ class _PackedBert:
         # RoBERTa-family embeddings (the reference's default checkpoint, multilingual-e5, is XLM-R) number positions from
         # padding_idx + 1 (create_position_ids_from_input_ids); BERT from 0
         self.pos_offset = int(bert.embeddings.padding_idx) + 1 if type(bert).__name__ != "BertModel" else 0
+        # the attention itself over packed tokens, for sequences of up to 64 tokens: one hand-written HIP launch per layer
+        # (csrc/attention_kernel.hpp through the C ABI) instead of gather -> SDPA -> scatter per group of similar length.
+        # fp32 on a GPU with 64-wide heads only; ICD_EMBEDDING_NATIVE_ATTENTION=0 keeps SDPA everywhere.
+        self.native_attention = None
+        if os.getenv("ICD_EMBEDDING_NATIVE_ATTENTION", "1") == "1" and self.hidden // self.heads == 64:
+            try:
+                from .. import _native
+                _native.load_library()
+                self.native_attention = _native.packed_attention
+            except Exception as exc:   # (a CPU-only install: the library is not built)
+                logger.debug("native packed attention unavailable: %s", exc)
         self.layers = []
         for l in bert.encoder.layer:
             a = l.attention.self
@@ -147,16 +158,26 @@ class _PackedBert:
         # then cannot prepare the search while the GPU encodes: 51 -> 44 ms per 1 000 strings end to end)
         def up(a):
             return torch.from_numpy(np.ascontiguousarray(a)).to(device, non_blocking=True)
-        groups = []
-        for first, count, longest in self.plan_groups(lengths):
-            col = np.arange(longest, dtype=np.int64)[None, :]
-            key = col < lens_np[first:first + count, None]
-            grid = np.where(key, starts[first:first + count, None] + col, T)   # pads point at the zero row behind the tokens
-            # (the key mask as the additive bias SDPA would make of a boolean one - once per group, not once per layer;
-            #  a group without pads needs none)
-            bias = None if bool(key.all()) else up(np.where(key, 0.0, -np.inf).astype(np.float32)).to(dtype)[:, None, None, :]
-            lens_t = up(np.maximum(lens_np[first:first + count], 1e-9).astype(np.float32)).to(dtype)
-            groups.append((count, longest, up(grid.reshape(-1)), bias, lens_t))
+        # sequences of <= 64 tokens (sorted: the tail) go to the native kernel; only the longer ones form SDPA groups
+        use_native = (self.native_attention is not None and str(device).startswith("cuda") and dtype == torch.float32)
+        n_long = int(np.searchsorted(-lens_np, -64, side="left")) if use_native else n   # sequences longer than 64 tokens
+        native = None
+        if use_native and n_long < n:
+            native = (up((starts[n_long:]).astype(np.int32)), n - n_long, int(lens_np[n_long]))
+        def make_groups(upto, with_bias):
+            out = []
+            for first, count, longest in (self.plan_groups(lengths[:upto]) if upto else []):
+                col = np.arange(longest, dtype=np.int64)[None, :]
+                key = col < lens_np[first:first + count, None]
+                grid = np.where(key, starts[first:first + count, None] + col, T)   # pads point at the zero row behind the tokens
+                # (the key mask as the additive bias SDPA would make of a boolean one - once per group, not once per layer;
+                #  a group without pads needs none)
+                bias = None if (not with_bias or bool(key.all())) else up(np.where(key, 0.0, -np.inf).astype(np.float32)).to(dtype)[:, None, None, :]
+                lens_t = up(np.maximum(lens_np[first:first + count], 1e-9).astype(np.float32)).to(dtype)
+                out.append((count, longest, up(grid.reshape(-1)), bias, lens_t))
+            return out
+        groups = make_groups(n_long, True)                                  # attention through SDPA: these sequences
+        pool_groups = groups if n_long == n else make_groups(n, False)      # mean pooling: every sequence
         ids_t, pos_t, first_rows = up(flat), up(pos), up(starts[:-1])
         emb = self.bert.embeddings
         x = emb.word_embeddings(ids_t) + emb.token_type_embeddings.weight[0]
@@ -173,9 +194,11 @@ class _PackedBert:
                 q, k, v = (g[:, :, i].transpose(1, 2) for i in range(3))
                 o = F.scaled_dot_product_attention(q, k, v, attn_mask=bias)
                 ctx.index_copy_(0, grid, o.transpose(1, 2).reshape(count * longest, H))
+            if native is not None:
+                self.native_attention(qkv, native[0], native[1], nh, native[2], ctx)
             x = l["attn_out"].LayerNorm(l["attn_out"].dense(ctx[:T]) + x)
             x = l["out"].LayerNorm(l["out"].dense(F.gelu(l["inter"](x))) + x)
-        return x, (lengths, starts, groups, first_rows)
+        return x, (lengths, starts, pool_groups, first_rows)
 
     @torch.no_grad()
     def forward(self, ids_sorted, device, pooling: str):

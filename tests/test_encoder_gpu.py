@@ -96,3 +96,55 @@ def test_packed_forward_matches_the_padded_hf_forward(services, monkeypatch):
     monkeypatch.setattr(gpu.model, "pooling", "cls")
     cls_padded = gpu.encode_query_batch(texts, batch_size=256)
     assert np.max(np.abs(cls_packed - cls_padded)) <= TOL and np.max(np.abs(cls_packed - packed)) > 1e-3
+
+
+def test_native_packed_attention_kernel_matches_sdpa():
+    """icd_packed_attention alone (through the C ABI): softmax(Q K^T / 8) V per sequence and head over packed tokens against
+    torch's scaled_dot_product_attention on every sequence separately - lengths 1 .. 64, 12 heads, rows of the packed QKV
+    that do not start at row 0, an output with a wider row stride"""
+    import torch
+    from rag_project_icd10_amd import _native
+    torch.manual_seed(5)
+    rng = np.random.default_rng(6)
+    lengths = [64, 64, 63, 33, 32, 31, 17, 16, 15, 8, 2, 1] + [int(x) for x in rng.integers(1, 65, 300)]
+    heads, dh = 12, 64
+    H = heads * dh
+    T = sum(lengths)
+    qkv = torch.randn(T + 3, 3 * H, device="cuda") * 2.0
+    starts = np.concatenate([[0], np.cumsum(lengths)]) + 2                      # the packed rows start at row 2
+    out = torch.full((T + 3, H + 64), float("nan"), device="cuda")
+    _native.packed_attention(qkv, torch.from_numpy(starts.astype(np.int32)).cuda(), len(lengths), heads, max(lengths), out)
+    torch.cuda.synchronize()
+    worst, worst_sdpa = 0.0, 0.0
+    for s, L in enumerate(lengths):
+        a = int(starts[s])
+        blk = qkv[a:a + L].view(L, 3, heads, dh)
+        q, k, v = (blk[:, i].transpose(0, 1) for i in range(3))                 # [heads, L, dh]
+        # float64 reference (the inputs are scaled up: scores of +-100, outputs of a few units); SDPA in fp32 for scale
+        p64 = torch.softmax(q.double() @ k.double().transpose(1, 2) / 8.0, dim=-1) @ v.double()
+        want = p64.transpose(0, 1).reshape(L, H)
+        sdpa = torch.nn.functional.scaled_dot_product_attention(q[None], k[None], v[None])[0].transpose(0, 1).reshape(L, H)
+        got = out[a:a + L, :H]
+        worst = max(worst, float((got.double() - want).abs().max()))
+        worst_sdpa = max(worst_sdpa, float((sdpa.double() - want).abs().max()))
+    assert worst <= 5e-5 and worst <= 1.5 * worst_sdpa + 1e-6, (worst, worst_sdpa)   # as close to float64 as SDPA's own fp32 (1.46e-5 / 1.45e-5)
+    assert bool(torch.isnan(out[:2]).all()) and bool(torch.isnan(out[:, H:]).all())   # nothing written outside its rows / columns
+    with pytest.raises(_native.IcdError):
+        _native.packed_attention(qkv, torch.zeros(2, dtype=torch.int32, device="cuda"), 1, heads, 65, out)
+
+
+def test_packed_forward_with_native_attention_matches_sdpa_groups(services, monkeypatch):
+    """the encoder with the hand-written attention kernel (sequences of <= 64 tokens) against the same packed forward with
+    SDPA groups everywhere, on strings on both sides of 64 tokens"""
+    gpu, _ = services
+    texts = _strings() + ["肺" * n for n in (54, 55, 56, 57, 58, 90)]             # "query: " + CLS/SEP: 62 .. 66 and 98 tokens
+    assert gpu._packed.native_attention is not None
+    native = gpu.encode_query_batch(texts, batch_size=256)
+    monkeypatch.setattr(gpu._packed, "native_attention", None)
+    sdpa = gpu.encode_query_batch(texts, batch_size=256)
+    assert np.max(np.abs(native - sdpa)) <= 2e-6
+    monkeypatch.setattr(gpu, "pooling", "cls")
+    cls_sdpa = gpu.encode_query_batch(texts, batch_size=256)
+    monkeypatch.undo()
+    monkeypatch.setattr(gpu, "pooling", "cls")
+    assert np.max(np.abs(gpu.encode_query_batch(texts, batch_size=256) - cls_sdpa)) <= 2e-6
