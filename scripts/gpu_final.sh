@@ -11,5 +11,10 @@ mkdir -p gpurun_out
 # two ranks on this box's ONE device: RCCL refuses duplicate devices; the gloo control flow with the HIP index on one device is what can run
 (ICD_BENCH_BACKEND=gloo ICD_BENCH_ONE_DEVICE=1 timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --rows-per-gpu 400000 --rowshard-queries 20000 2>&1 | tail -2) > gpurun_out/bench_2rank_one_device.log
 bash scripts/gpu_pmc.sh $TAG > gpurun_out/pmc_$TAG.log 2>&1
+# one-off logs of the round, reproducible in the same call (copied to profiles/ by hand: see profiles/README.md)
+(timeout 300 python scripts/probe/encoder_batch_probe.py 2>&1 | grep -v amdgpu.ids) > gpurun_out/encoder_batch.log
+(timeout 300 python scripts/probe/query_latency.py 2>&1 | grep "NER o") > gpurun_out/query_latency.log
+(timeout 300 python scripts/probe/sparse_incident.py 2>&1 | grep -v amdgpu.ids) > gpurun_out/sparse_incident.log
+(timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -k family_corpus_is_certified -s 2>&1 | grep "family corpus") > gpurun_out/family_probe.log
 for f in bench_kernel_stats.csv bench_with_extras_kernel_stats.csv bench_exact_mode_kernel_stats.csv rowshard_kernel_stats.csv pmc_counters.json pmc_counters_exact_mode.json pmc_traffic.json pmc_traffic_rowshard.json; do cp gpurun_out/${TAG}_$f gpurun_out/final_${TAG}_$f 2>/dev/null; done
 cat gpurun_out/pytest_gpu.log gpurun_out/smoke.log; cut -c1-700 gpurun_out/bench.log; cut -c1-400 gpurun_out/bench_rowshard.log; grep -A14 stages_ms gpurun_out/e2e.json; cut -c1-600 gpurun_out/bench_2rank_one_device.log; tail -30 gpurun_out/pmc_$TAG.log | cut -c1-400
