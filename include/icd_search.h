@@ -240,7 +240,7 @@ int icd_cosine_rows(int32_t device, const float *x, const float *y, int64_t y_st
  * sequence and head, fp32.
  *   qkv      [T][ld] device fp32: Q | K | V of a token side by side (ld >= 3 * heads * 64, a multiple of 4)
  *   starts   [nseq + 1] device int32: first packed row of every sequence (sequence s is rows starts[s] .. starts[s + 1])
- *   max_len  the longest sequence (host-known): 1 .. 64 - longer sequences stay with the caller's padded attention
+ *   max_len  the longest sequence (host-known): 1 .. 512 (up to 64 tokens one pass; longer ones in chunks of 64 keys)
  *   out      [T][out_ld] device fp32: heads side by side
  * Enqueues one launch on `stream`. */
 int icd_packed_attention(int32_t device, const float *qkv, int64_t ld, const int32_t *starts, int32_t nseq, int32_t heads,

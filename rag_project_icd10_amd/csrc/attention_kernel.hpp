@@ -5,10 +5,9 @@
 // XLMRobertaSelfAttention (softmax(Q K^T / sqrt(d_head)) V per sequence and head, no dropout in eval), restated for
 //   qkv  [T][3 * hidden] fp32, one row per token, Q | K | V of a token side by side (the fused QKV GEMM's output)
 //   out  [T][hidden]     fp32, heads side by side (what the attention-output Linear reads)
-// over sequences given by their first rows, `starts[s] .. starts[s + 1]`, each at most 64 tokens long (longer ones keep
-// the padded scaled_dot_product_attention path of the caller). Without it a layer gathers the packed QKV to a padded
-// [n, L] view, runs SDPA, and scatters the result back: 585 MB of traffic and 18 launches per layer for the 1 000 golden
-// diagnosis strings, against 224 MB and one launch here.
+// over sequences given by their first rows, `starts[s] .. starts[s + 1]`, each at most 512 tokens long. Without it a layer
+// gathers the packed QKV to a padded [n, L] view per group of similar length, runs SDPA, and scatters the result back: 585
+// MB of traffic and 18 launches per layer for the 1 000 golden diagnosis strings, against 224 MB and one launch here.
 //
 // One wave per (sequence, head), head dimension 64:
 //   K   lane j keeps row j of the head's K in 64 registers (rows >= L are zero),
@@ -16,13 +15,16 @@
 //   per query i: the 64-term dot products q_i . k_j of ALL keys at once - the query sits four registers deep, sixteen lanes
 //   wide, and v_fmac_f32_dpp row_newbcast hands element d to every lane of its row (no LDS, no scalar traffic) -, a wave-wide
 //   max and sum for the softmax, then sum_j p_j v_j[d] with p_j read across lanes (v_readlane) eight keys per branch.
+// A sequence longer than 64 tokens takes its keys in chunks of 64 with the flash-attention recurrence (running max / sum per
+// query in LDS, the unnormalised output in `out`); up to 64 tokens - every diagnosis string - it is the single pass above.
 // fp32 throughout; the summation order differs from SDPA's, the results agree to ~1e-7 (tests/test_encoder_gpu.py).
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace icd {
 
-constexpr int ATT_MAX_LEN = 64;   // keys per sequence this kernel takes (one per lane)
+constexpr int ATT_MAX_LEN = 64;   // keys per chunk (one per lane)
+constexpr int ATT_MAX_SEQ = 512;  // tokens per sequence (the running softmax state of a wave lives in LDS: 4 KB)
 constexpr int ATT_HEAD_DIM = 64;
 
 struct PackedAttnArgs {
@@ -71,62 +73,86 @@ __device__ __forceinline__ float att_wave_sum(float v) {
 }
 
 __global__ __launch_bounds__(256) void packed_attention_kernel(PackedAttnArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (task >= a.nseq * a.heads) return;   // wave-uniform
+    // running softmax state of the queries of a sequence longer than one chunk of 64 keys: max and sum per query, per wave
+    __shared__ float run_m[4][ATT_MAX_SEQ], run_l[4][ATT_MAX_SEQ];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int task = blockIdx.x * 4 + wave;
+    if (task >= a.nseq * a.heads) return;   // wave-uniform (no work-group barriers below)
     const int s = task / a.heads, h = task - s * a.heads;
     const int r0 = a.starts[s];
-    const int L = a.starts[s + 1] - r0;     // 1 .. 64 (checked by the host)
+    const int L = a.starts[s + 1] - r0;     // 1 .. ATT_MAX_SEQ (checked by the host)
     const float *base = a.qkv + (size_t)r0 * a.ld + (size_t)h * ATT_HEAD_DIM;
-
-    float kreg[ATT_HEAD_DIM];               // row `lane` of K
-    {
-        const float4 *kp = reinterpret_cast<const float4 *>(base + (size_t)min(lane, L - 1) * a.ld + a.hidden);
-        const bool live = lane < L;
-#pragma unroll
-        for (int c = 0; c < ATT_HEAD_DIM / 4; ++c) {
-            const float4 v = kp[c];
-            kreg[4 * c + 0] = live ? v.x : 0.f; kreg[4 * c + 1] = live ? v.y : 0.f;
-            kreg[4 * c + 2] = live ? v.z : 0.f; kreg[4 * c + 3] = live ? v.w : 0.f;
-        }
-    }
-    float vreg[ATT_MAX_LEN];                // column `lane` of V, one register per key
-    {
-        const float *vp = base + 2 * (size_t)a.hidden + lane;
-#pragma unroll
-        for (int jb = 0; jb < ATT_MAX_LEN; jb += 8) {
-            if (jb < L) {                   // wave-uniform
-#pragma unroll
-                for (int j = jb; j < jb + 8; ++j) vreg[j] = (j < L) ? vp[(size_t)j * a.ld] : 0.f;
-            } else {
-#pragma unroll
-                for (int j = jb; j < jb + 8; ++j) vreg[j] = 0.f;
-            }
-        }
-    }
     float *op = a.out + (size_t)r0 * a.out_ld + (size_t)h * ATT_HEAD_DIM + lane;
     const float *qp = base + (lane & 15);
-    for (int i = 0; i < L; ++i) {
-        const float *qi = qp + (size_t)i * a.ld;
-        const float q0 = qi[0] * a.scale, q1 = qi[16] * a.scale, q2 = qi[32] * a.scale, q3 = qi[48] * a.scale;
-        float acc = 0.f;
-        att_dot16(acc, q0, kreg);
-        att_dot16(acc, q1, kreg + 16);
-        att_dot16(acc, q2, kreg + 32);
-        att_dot16(acc, q3, kreg + 48);
-        const float sc = lane < L ? acc : -INFINITY;
-        const float m = att_wave_max(sc);
-        const float e = lane < L ? expf(sc - m) : 0.f;
-        const float p = e / att_wave_sum(e);
-        float o = 0.f;
+    float *wm = run_m[wave], *wl = run_l[wave];
+
+    // keys in chunks of 64 (one per lane); a sequence of up to 64 tokens - every diagnosis string - is ONE chunk and never
+    // touches the running state. Longer ones keep, per query, the running max / sum in LDS and the unnormalised output in
+    // `out` itself (the flash-attention recurrence: o <- o * exp(m_old - m_new) + sum_j exp(s_j - m_new) v_j).
+    for (int k0 = 0; k0 < L; k0 += ATT_MAX_LEN) {
+        const int Lc = min(ATT_MAX_LEN, L - k0);   // keys of this chunk
+        const bool first = k0 == 0, last = k0 + ATT_MAX_LEN >= L;
+        const float *kbase = base + (size_t)k0 * a.ld;
+        float kreg[ATT_HEAD_DIM];               // row `lane` of the chunk's K
+        {
+            const float4 *kp = reinterpret_cast<const float4 *>(kbase + (size_t)min(lane, Lc - 1) * a.ld + a.hidden);
+            const bool live = lane < Lc;
 #pragma unroll
-        for (int jb = 0; jb < ATT_MAX_LEN; jb += 8) {
-            if (jb < L) {                   // wave-uniform: eight keys per branch (keys beyond L carry p = 0 and v = 0)
-#pragma unroll
-                for (int j = jb; j < jb + 8; ++j) o = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), j)), vreg[j], o);
+            for (int c = 0; c < ATT_HEAD_DIM / 4; ++c) {
+                const float4 v = kp[c];
+                kreg[4 * c + 0] = live ? v.x : 0.f; kreg[4 * c + 1] = live ? v.y : 0.f;
+                kreg[4 * c + 2] = live ? v.z : 0.f; kreg[4 * c + 3] = live ? v.w : 0.f;
             }
         }
-        op[(size_t)i * a.out_ld] = o;
+        float vreg[ATT_MAX_LEN];                // column `lane` of the chunk's V, one register per key
+        {
+            const float *vp = kbase + 2 * (size_t)a.hidden + lane;
+#pragma unroll
+            for (int jb = 0; jb < ATT_MAX_LEN; jb += 8) {
+                if (jb < Lc) {                  // wave-uniform
+#pragma unroll
+                    for (int j = jb; j < jb + 8; ++j) vreg[j] = (j < Lc) ? vp[(size_t)j * a.ld] : 0.f;
+                } else {
+#pragma unroll
+                    for (int j = jb; j < jb + 8; ++j) vreg[j] = 0.f;
+                }
+            }
+        }
+        for (int i = 0; i < L; ++i) {
+            const float *qi = qp + (size_t)i * a.ld;
+            const float q0 = qi[0] * a.scale, q1 = qi[16] * a.scale, q2 = qi[32] * a.scale, q3 = qi[48] * a.scale;
+            float acc = 0.f;
+            att_dot16(acc, q0, kreg);
+            att_dot16(acc, q1, kreg + 16);
+            att_dot16(acc, q2, kreg + 32);
+            att_dot16(acc, q3, kreg + 48);
+            const float sc = lane < Lc ? acc : -INFINITY;
+            float m = att_wave_max(sc);
+            float carry = 0.f, l_old = 0.f;     // exp(m_old - m_new) and the running sum so far
+            if (!first) {                       // wave-uniform
+                const float m_old = wm[i];
+                l_old = wl[i];
+                const float m_new = fmaxf(m_old, m);
+                carry = expf(m_old - m_new);
+                m = m_new;
+            }
+            const float e = lane < Lc ? expf(sc - m) : 0.f;
+            const float l = l_old * carry + att_wave_sum(e);
+            float o = first ? 0.f : op[(size_t)i * a.out_ld] * carry;
+#pragma unroll
+            for (int jb = 0; jb < ATT_MAX_LEN; jb += 8) {
+                if (jb < Lc) {                  // wave-uniform: eight keys per branch (keys beyond Lc carry e = 0 and v = 0)
+#pragma unroll
+                    for (int j = jb; j < jb + 8; ++j) o = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e), j)), vreg[j], o);
+                }
+            }
+            if (last) {
+                op[(size_t)i * a.out_ld] = o / l;
+            } else {
+                op[(size_t)i * a.out_ld] = o;
+                if (lane == 0) { wm[i] = m; wl[i] = l; }
+            }
+        }
     }
 }
 

@@ -1151,7 +1151,7 @@ int icd_packed_attention(int32_t device, const float *qkv, int64_t ld, const int
                          int32_t head_dim, int32_t max_len, float *out, int64_t out_ld, void *stream) {
     if (!qkv || !starts || !out) return fail(ICD_ERR_INVALID, "pointer is NULL");
     if (head_dim != ATT_HEAD_DIM) return fail(ICD_ERR_UNSUPPORTED, "head_dim=%d (this kernel is written for %d)", head_dim, ATT_HEAD_DIM);
-    if (max_len < 1 || max_len > ATT_MAX_LEN) return fail(ICD_ERR_UNSUPPORTED, "max_len=%d (1..%d tokens per sequence)", max_len, ATT_MAX_LEN);
+    if (max_len < 1 || max_len > ATT_MAX_SEQ) return fail(ICD_ERR_UNSUPPORTED, "max_len=%d (1..%d tokens per sequence)", max_len, ATT_MAX_SEQ);
     if (nseq < 0 || heads <= 0 || (int64_t)nseq * heads > 0x7FFFFFF0LL) return fail(ICD_ERR_INVALID, "nseq=%d heads=%d", nseq, heads);
     const int64_t hidden = (int64_t)heads * head_dim;
     if (ld < 3 * hidden || out_ld < hidden || ld % 4 != 0) return fail(ICD_ERR_INVALID, "ld=%lld out_ld=%lld for hidden=%lld", (long long)ld, (long long)out_ld, (long long)hidden);

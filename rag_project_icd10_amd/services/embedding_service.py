@@ -88,6 +88,7 @@ class _PackedBert:
     """
 
     GROUP_RATIO = 0.75   # a group of sequences for the attention: lengths within this factor of its longest
+    NATIVE_MAX_LEN = 512  # tokens per sequence icd_packed_attention takes (csrc/attention_kernel.hpp ATT_MAX_SEQ)
     MAX_GROUPS = 12
 
     @staticmethod
@@ -105,7 +106,7 @@ class _PackedBert:
         # RoBERTa-family embeddings (the reference's default checkpoint, multilingual-e5, is XLM-R) number positions from
         # padding_idx + 1 (create_position_ids_from_input_ids); BERT from 0
         self.pos_offset = int(bert.embeddings.padding_idx) + 1 if type(bert).__name__ != "BertModel" else 0
-        # the attention itself over packed tokens, for sequences of up to 64 tokens: one hand-written HIP launch per layer
+        # the attention itself over packed tokens (sequences of up to 512 tokens): one hand-written HIP launch per layer
         # (csrc/attention_kernel.hpp through the C ABI) instead of gather -> SDPA -> scatter per group of similar length.
         # fp32 on a GPU with 64-wide heads only; ICD_EMBEDDING_NATIVE_ATTENTION=0 keeps SDPA everywhere.
         self.native_attention = None
@@ -158,9 +159,9 @@ class _PackedBert:
         # then cannot prepare the search while the GPU encodes: 51 -> 44 ms per 1 000 strings end to end)
         def up(a):
             return torch.from_numpy(np.ascontiguousarray(a)).to(device, non_blocking=True)
-        # sequences of <= 64 tokens (sorted: the tail) go to the native kernel; only the longer ones form SDPA groups
+        # sequences of <= NATIVE_MAX_LEN tokens (sorted: the tail) go to the native kernel; only longer ones form SDPA groups
         use_native = (self.native_attention is not None and str(device).startswith("cuda") and dtype == torch.float32)
-        n_long = int(np.searchsorted(-lens_np, -64, side="left")) if use_native else n   # sequences longer than 64 tokens
+        n_long = int(np.searchsorted(-lens_np, -self.NATIVE_MAX_LEN, side="left")) if use_native else n   # sequences beyond the kernel's reach
         native = None
         if use_native and n_long < n:
             native = (up((starts[n_long:]).astype(np.int32)), n - n_long, int(lens_np[n_long]))

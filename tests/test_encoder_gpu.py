@@ -100,13 +100,14 @@ def test_packed_forward_matches_the_padded_hf_forward(services, monkeypatch):
 
 def test_native_packed_attention_kernel_matches_sdpa():
     """icd_packed_attention alone (through the C ABI): softmax(Q K^T / 8) V per sequence and head over packed tokens against
-    torch's scaled_dot_product_attention on every sequence separately - lengths 1 .. 64, 12 heads, rows of the packed QKV
+    a float64 softmax attention (and torch's fp32 scaled_dot_product_attention for scale) on every sequence separately - lengths 1 .. 512
+    (one pass up to 64 keys, the chunked recurrence beyond), 12 heads, rows of the packed QKV
     that do not start at row 0, an output with a wider row stride"""
     import torch
     from rag_project_icd10_amd import _native
     torch.manual_seed(5)
     rng = np.random.default_rng(6)
-    lengths = [64, 64, 63, 33, 32, 31, 17, 16, 15, 8, 2, 1] + [int(x) for x in rng.integers(1, 65, 300)]
+    lengths = [512, 511, 200, 129, 128, 127, 65, 64, 64, 63, 33, 32, 31, 17, 16, 15, 8, 2, 1] + [int(x) for x in rng.integers(1, 65, 300)] + [int(x) for x in rng.integers(65, 260, 12)]
     heads, dh = 12, 64
     H = heads * dh
     T = sum(lengths)
@@ -130,14 +131,14 @@ def test_native_packed_attention_kernel_matches_sdpa():
     assert worst <= 5e-5 and worst <= 1.5 * worst_sdpa + 1e-6, (worst, worst_sdpa)   # as close to float64 as SDPA's own fp32 (1.46e-5 / 1.45e-5)
     assert bool(torch.isnan(out[:2]).all()) and bool(torch.isnan(out[:, H:]).all())   # nothing written outside its rows / columns
     with pytest.raises(_native.IcdError):
-        _native.packed_attention(qkv, torch.zeros(2, dtype=torch.int32, device="cuda"), 1, heads, 65, out)
+        _native.packed_attention(qkv, torch.zeros(2, dtype=torch.int32, device="cuda"), 1, heads, 513, out)
 
 
 def test_packed_forward_with_native_attention_matches_sdpa_groups(services, monkeypatch):
-    """the encoder with the hand-written attention kernel (sequences of <= 64 tokens) against the same packed forward with
-    SDPA groups everywhere, on strings on both sides of 64 tokens"""
+    """the encoder with the hand-written attention kernel against the same packed forward with SDPA groups, on strings on
+    both sides of the kernel's 64-key chunk and up to max_seq_length"""
     gpu, _ = services
-    texts = _strings() + ["肺" * n for n in (54, 55, 56, 57, 58, 90)]             # "query: " + CLS/SEP: 62 .. 66 and 98 tokens
+    texts = _strings() + ["肺" * n for n in (54, 55, 56, 57, 58, 90, 119, 120, 121)]   # "query: " + CLS/SEP: 62 .. 66, 98, 127, 128 (and truncated to 128) tokens
     assert gpu._packed.native_attention is not None
     native = gpu.encode_query_batch(texts, batch_size=256)
     monkeypatch.setattr(gpu._packed, "native_attention", None)
