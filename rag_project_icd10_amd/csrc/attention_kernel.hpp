@@ -61,16 +61,29 @@ __device__ __forceinline__ void att_dot16(float &acc, float q, const float *k) {
                    "v"(k[9]), "v"(k[10]), "v"(k[11]), "v"(k[12]), "v"(k[13]), "v"(k[14]), "v"(k[15]));
 }
 
+// wave-wide max / sum on the DPP network (row_shr 1, 2, 4, 8, then row_bcast 15 and 31: lane 63 ends up with the result) -
+// six VALU instructions each; a __shfl_xor butterfly is six ds_bpermute round trips through the LDS, and with two
+// reductions per query row that was 6 % of this kernel (116 -> 110 us per layer on the 1 000 golden strings; the next query row fetched one iteration ahead: 104 us. What remains is instruction issue: ~250 VALU instructions per query row).
+#define ICD_ATT_DPP(v, ctrl, rmask, ident) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(ident)), __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
 __device__ __forceinline__ float att_wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
+    v = fmaxf(v, ICD_ATT_DPP(v, 0x111, 0xf, -INFINITY));   // row_shr:1
+    v = fmaxf(v, ICD_ATT_DPP(v, 0x112, 0xf, -INFINITY));   // row_shr:2
+    v = fmaxf(v, ICD_ATT_DPP(v, 0x114, 0xf, -INFINITY));   // row_shr:4
+    v = fmaxf(v, ICD_ATT_DPP(v, 0x118, 0xf, -INFINITY));   // row_shr:8
+    v = fmaxf(v, ICD_ATT_DPP(v, 0x142, 0xa, -INFINITY));   // row_bcast:15
+    v = fmaxf(v, ICD_ATT_DPP(v, 0x143, 0xc, -INFINITY));   // row_bcast:31
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float att_wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += ICD_ATT_DPP(v, 0x111, 0xf, 0.f);
+    v += ICD_ATT_DPP(v, 0x112, 0xf, 0.f);
+    v += ICD_ATT_DPP(v, 0x114, 0xf, 0.f);
+    v += ICD_ATT_DPP(v, 0x118, 0xf, 0.f);
+    v += ICD_ATT_DPP(v, 0x142, 0xa, 0.f);
+    v += ICD_ATT_DPP(v, 0x143, 0xc, 0.f);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+#undef ICD_ATT_DPP
 
 __global__ __launch_bounds__(256) void packed_attention_kernel(PackedAttnArgs a) {
     // running softmax state of the queries of a sequence longer than one chunk of 64 keys: max and sum per query, per wave
@@ -118,9 +131,15 @@ __global__ __launch_bounds__(256) void packed_attention_kernel(PackedAttnArgs a)
                 }
             }
         }
+        // (the next query's four values are fetched while this one is worked on: a row's arithmetic is ~150 instructions,
+        //  a global load's round trip several times that)
+        float n0 = qp[0], n1 = qp[16], n2 = qp[32], n3 = qp[48];
         for (int i = 0; i < L; ++i) {
-            const float *qi = qp + (size_t)i * a.ld;
-            const float q0 = qi[0] * a.scale, q1 = qi[16] * a.scale, q2 = qi[32] * a.scale, q3 = qi[48] * a.scale;
+            const float q0 = n0 * a.scale, q1 = n1 * a.scale, q2 = n2 * a.scale, q3 = n3 * a.scale;
+            {
+                const float *qn = qp + (size_t)min(i + 1, L - 1) * a.ld;
+                n0 = qn[0]; n1 = qn[16]; n2 = qn[32]; n3 = qn[48];
+            }
             float acc = 0.f;
             att_dot16(acc, q0, kreg);
             att_dot16(acc, q1, kreg + 16);
