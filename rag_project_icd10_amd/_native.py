@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Optional, Tuple
+from typing import Optional
 
 import numpy as np
 
