@@ -9,7 +9,7 @@
 touches the GPU) runs the second command line above as a child process, relays rank 0's JSON line and exits with the
 child's status (spawn_ranks). Under torchrun (WORLD_SIZE set) the process is a rank and runs the workload.
 
-Workload `replicated` (default; BASELINE.json configs[1] at N = 1, configs[3] at N > 1), per GPU:
+Workload `replicated` (default; BASELINE.json configs[1]), per GPU:
     corpus  37 000 x 768 fp32, iid N(0,1) rows L2-normalised, default_rng(1234); levels default_rng(1235)
             from the real CSV histogram;
     queries 10 000 x 768, default_rng(4321 + rank), resident in HBM before the timed region;
@@ -17,7 +17,10 @@ Workload `replicated` (default; BASELINE.json configs[1] at N = 1, configs[3] at
     fp16-MFMA coarse top-k', certification + exact fp32 rescoring, level reweight + stable re-sort,
     exact fallback for uncertified queries), k = 10. Results are bit-identical to the exact kernel.
 With N > 1 every rank holds a corpus replica and its own query batch (data-parallel, no collective on
-the data path: weak scaling); `value` is the whole-job rate = N * nq * K / max-over-ranks time.
+the data path: weak scaling); `value` is the whole-job rate = N * nq * K / max-over-ranks time: the HEADLINE workload
+replicated, labelled so. BASELINE configs[3] proper - 1 M queries over the node, 125 000 per GPU - is measured next to it
+and reported under "config3" (run_config3: the per-GPU share in slices of the index's batch size, every 100th query
+checked against the oracle).
 
 Workload `rowshard` (BASELINE.json configs[4]; SURVEY.md 8d "Config 5"): every rank generates a shard of
 1 250 000 x 768 rows ON THE DEVICE (seed 1234 + rank; N = 8 -> the 10 M-row corpus), the query batch (100 000 x 768,
@@ -28,8 +31,11 @@ With N > 1 the default run also measures this workload and reports it under "row
 driver's scaling run (bench.py --gpus 1/2/4/8) yields both curves.
 
 At N = 1 the default line also carries, under "extra" (never the headline): the same step on the real CSV's size
-(40 474 rows) and on SURVEY 8d's clustered data (512 centroids, x = normalise(c_j + 0.5 eps)), each with ms_per_step,
-fallback_queries and ids_exact against the oracle from the same run; "exact_mode" = the fp32-MFMA kernel alone on the
+(40 474 rows), on SURVEY 8d's clustered data (512 centroids, x = normalise(c_j + 0.5 eps)), on the headline data at the
+serving path's k = 20 (/query searches top_k * 2, services/multi_diagnosis_service.py:153) and on an ICD-SHAPED corpus
+("family": 300 families x 124 near-identical rows in code order, mutual cosine 0.99 - the reference's semantic_text repeats
+the ancestors' names, tools/build_database.py:156-171 - a fresh index, its first batch and the steady state), each with
+ms_per_step, fallback_queries, last_second_pass and ids_exact against the oracle on every query, from the same run; "exact_mode" = the fp32-MFMA kernel alone on the
 headline workload against its own 157.3 TFLOP/s peak; "windows" = the K-step window repeated (min / median / max) and
 the first window of the process, before the clock has settled.
 
@@ -73,6 +79,18 @@ def clustered_rows(n, dim, seed, centroid_seed=77, ncent=512, spread=0.5):
     x = cent[rng.integers(0, ncent, n)] + (spread / np.sqrt(dim)) * rng.standard_normal((n, dim), dtype=np.float32)
     x /= np.linalg.norm(x, axis=1, keepdims=True)
     return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def family_rows(nfam, per, dim, spread, nq, seed):
+    """an ICD-shaped corpus: `nfam` families of `per` near-identical rows IN CODE ORDER (a family's rows are neighbours),
+    x = normalise(c_f + spread eps); the queries are noisy members of random families. spread 0.10 -> mutual cosine 0.99"""
+    rng = np.random.default_rng(seed)
+    cent = rng.standard_normal((nfam, dim)).astype(np.float32)
+    x = np.repeat(cent, per, axis=0) + spread * rng.standard_normal((nfam * per, dim)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    q = cent[rng.integers(0, nfam, nq)] + spread * rng.standard_normal((nq, dim)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return np.ascontiguousarray(x, dtype=np.float32), np.ascontiguousarray(q, dtype=np.float32)
 
 
 def icd_levels(n, seed):
@@ -278,14 +296,23 @@ def oracle_check(corpus, levels, queries, k, out, world=1):
             "parity_checked_queries": int(len(queries)), "parity_check_s": round(time.perf_counter() - t0, 2)}
 
 
-def side_workload(ctx, args, index_factory, name, corpus, levels, queries, k, mode, steps):
+def side_workload(ctx, args, index_factory, name, corpus, levels, queries, k, mode, steps, first_batch=False):
     """one of the line's `extra` objects: the same step on other data / another size / the exact kernel alone, timed
-    over `steps` steps after a short warm-up and checked against the oracle on every query, in this run"""
+    over `steps` steps after a short warm-up and checked against the oracle on every query, in this run.
+    first_batch: also time the FIRST search of the fresh index on its own (what a new index costs its first user batch)"""
     from rag_project_icd10_amd._native import MODE_AUTO
     torch = ctx.torch
     index = index_factory(corpus, levels, ctx.local_rank, len(queries), max(k, 10))
     dq = torch.from_numpy(queries).to(ctx.dev)
     fn = lambda: index.search_reweighted(dq, k, mode)
+    first_ms = first_stats = None
+    if first_batch:
+        ctx.sync()
+        t0 = time.perf_counter()
+        fn()
+        ctx.sync()
+        first_ms = (time.perf_counter() - t0) * 1e3
+        first_stats = index.stats()
     # the same untimed settle + warm-up the headline gets (a fresh index and a fresh clock ramp otherwise cost these
     # lines ~15 %: 40 474 rows measured 0.81 ms per step without it, 0.69 as a main workload)
     t_end = time.perf_counter() + args.settle_ms / 1e3
@@ -310,10 +337,15 @@ def side_workload(ctx, args, index_factory, name, corpus, levels, queries, k, mo
     obj = {"workload": name, "corpus_rows": int(corpus.shape[0]), "nq": int(len(queries)), "top_k": k, "steps": steps,
            "ms_per_step": elapsed / steps * 1e3, "queries_per_sec": len(queries) * steps / elapsed,
            "fallback_queries": int(stats["last_fallback"]), "coarse_chunks": int(stats["last_chunks"]),
+           "last_second_pass": int(stats.get("last_second_pass", 0)), "wide_mode": int(stats.get("wide_mode", 0)),
            "kernel_ms": {kname: round(v, 5) for kname, v in prof.items() if kname != "count"},
            "roofline": {"bound": "mfma", "kernel": "coarse_flat_kernel" if fast else "exact_topk_kernel", "achieved": achieved,
                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "launch_ms": dom_ms,
                         "launches_averaged": prof["count"]}}
+    if first_batch:
+        obj["first_batch_ms"] = first_ms
+        obj["first_batch"] = {"ms": first_ms, "fallback_queries": int(first_stats["last_fallback"]),
+                              "last_second_pass": int(first_stats.get("last_second_pass", 0)), "wide_mode": int(first_stats.get("wide_mode", 0))}
     obj.update(oracle_check(corpus, levels, queries, k, out, ctx.world))
     index.close()
     return obj
@@ -363,8 +395,10 @@ def run_replicated(ctx, args, index_factory=hip_index_factory):
             "vs_baseline": None,
             "dtype": "f16" if fast else "f32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{1 if ctx.world == 1 else 3}]: {nq} random fp32 768-d queries per GPU x {n}x768 corpus, "
-                                   f"top_k={k}, search only (pre-embedded, HBM-resident inputs), level reweight fused",
+            "config": {"workload": (f"BASELINE configs[1]: {nq} random fp32 768-d queries x {n}x768 corpus, " if ctx.world == 1 else
+                                    f"BASELINE configs[1] replicated on every GPU (the headline workload, {nq} random fp32 768-d queries per GPU x {n}x768 corpus; "
+                                    f"configs[3] at its stated size is the `config3` object), ")
+                                   + f"top_k={k}, search only (pre-embedded, HBM-resident inputs), level reweight fused",
                        "nq_per_gpu": nq, "corpus_rows": n, "dim": dim, "top_k": k, "mode": args.mode,
                        "parallelism": f"query-sharded x{ctx.world}, corpus replicated" if ctx.world > 1 else "single GPU",
                        "collective_ranks": ctx.dist.get_world_size() if ctx.world > 1 else 1,
@@ -394,12 +428,105 @@ def run_replicated(ctx, args, index_factory=hip_index_factory):
                                         unit_rows(n_real, dim, 1234), icd_levels(n_real, 1235), queries, k, mode, steps_x)
         ex["clustered"] = side_workload(ctx, args, index_factory, f"SURVEY 8d clustered: 512 centroids, x = normalise(c_j + 0.5 eps), {nq} queries x {n}x768",
                                         clustered_rows(n, dim, 2234), levels, clustered_rows(nq, dim, 5321), k, mode, steps_x)
+        if mode == MODE_AUTO and not args.no_family:
+            ex["k20"] = side_workload(ctx, args, index_factory, f"the headline data at the serving path's k = 20 (/query searches top_k * 2): {nq} x {n}x768",
+                                      corpus, levels, queries, 20, mode, steps_x)
+            fam_c, fam_q = family_rows(args.family_families, args.family_rows, dim, 0.10, nq, 7)
+            ex["family"] = side_workload(ctx, args, index_factory, f"ICD-shaped corpus: {args.family_families} families x {args.family_rows} near-identical rows in code order "
+                                         f"(mutual cosine 0.99), {nq} queries, k = {k}; a fresh index: first batch, then the steady state",
+                                         fam_c, icd_levels(len(fam_c), 8), fam_q, k, mode, steps_x, first_batch=True)
         if mode == MODE_AUTO:
             ex["exact_mode"] = side_workload(ctx, args, index_factory, f"--mode exact: the fp32-MFMA kernel alone, {nq} x {n}x768",
                                              corpus, levels, queries, k, MODE_EXACT, max(3, steps_x // 4))
     if line is not None and ctx.world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(corpus, levels, queries, k)
     return line
+
+
+def run_config3(ctx, args, index_factory=hip_index_factory):
+    """BASELINE configs[3] at its stated size: the 37k corpus replicated, 1 M queries over an 8-GPU node = 125 000 per GPU
+    (args.config3_queries), every rank its own batch (seed 9000 + rank), searched in slices of the index's batch size with no
+    collective on the data path. One STEP = one pass over the rank's whole share; every 100th query is checked against the
+    oracle after the timed region."""
+    from rag_project_icd10_amd._native import MODE_AUTO
+    torch = ctx.torch
+    dim, n, k = 768, args.n, args.k
+    nq = int(args.config3_queries)
+    sl = min(nq, max(1, int(args.rowshard_slice)))
+    corpus, levels = unit_rows(n, dim, 1234), icd_levels(n, 1235)
+    queries = unit_rows(nq, dim, 9000 + ctx.rank)
+    index = index_factory(corpus, levels, ctx.local_rank, sl, max(k, 10))
+    dq = torch.from_numpy(queries).to(ctx.dev)
+    ctx.sync()
+
+    def one_pass():
+        return [index.search_reweighted(dq[s:s + sl], k, MODE_AUTO) for s in range(0, nq, sl)]
+
+    steps = max(1, min(args.steps, args.config3_steps))
+    elapsed, outs, _ = ctx.timed(one_pass, steps, 1)
+    stats = index.stats()
+    line = None
+    if ctx.rank == 0:
+        sel = np.arange(0, nq, 100 if nq >= 1000 else 1)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as orc
+        adj, raw, ids, lv = (torch.cat([o[j] for o in outs]).cpu().numpy()[sel] for j in range(4))
+        t0 = time.perf_counter()
+        os_, oi = orc.flat_ip_topk(corpus, queries[sel], k, nthreads=max(1, (os.cpu_count() or 1) // max(1, ctx.world)))
+        want = orc.reweight(os_, oi, levels)
+        line = {"metric": "queries_per_sec", "value": ctx.world * nq * steps / elapsed, "unit": "queries/s", "n_gpus": ctx.world,
+                "steps": steps, "warmup": 1, "ms_per_step": elapsed / steps * 1e3, "scaling": "weak", "dtype": "f16", "data": "synthetic",
+                "config": {"workload": f"BASELINE configs[3]: {n}x{dim} corpus replicated, {ctx.world * nq} synthetic 768-d queries sharded per GPU "
+                                       f"({nq} per GPU, slices of {sl}), top_k={k}, search + level reweight, no data-path collective",
+                           "nq_per_gpu": nq, "queries_total": ctx.world * nq, "corpus_rows": n, "slice": sl, "top_k": k,
+                           "parallelism": f"query-sharded x{ctx.world}, corpus replicated"},
+                "ids_exact": bool(np.array_equal(ids, want[2])), "adjusted_scores_exact": bool(adj.tobytes() == want[0].tobytes()),
+                "max_abs_dscore": float(np.max(np.abs(raw.astype(np.float64) - want[1].astype(np.float64)))),
+                "parity_checked_queries": int(len(sel)), "parity_check_s": round(time.perf_counter() - t0, 2),
+                "fallback_queries_last_slice": int(stats.get("last_fallback", 0))}
+    index.close()
+    return line
+
+
+def native_group_trial(ctx, index, queries, sl, k, ref_out, limit_s):
+    """N > 1 only, AFTER the row-sharded measurement (which runs on the torch.distributed engine): the same slice through the
+    C-ABI group (icd_group_*: RCCL opened by the library, ncclCommInitRank + one grouped ncclAllGather + merge on one
+    stream). It has never run on more than one GPU, so it runs in a side thread under a time limit: the ranks agree on
+    prepare / connect (ShardedSearch._open_native), the first slice must equal the torch engine's output bit for bit, three
+    passes of the slice are timed. A hang costs `limit_s` seconds and is reported; the measurement above is untouched."""
+    import threading
+    from rag_project_icd10_amd.sharded import ROW_SHARD, ShardedSearch
+    torch = ctx.torch
+    res = {"status": "started"}
+
+    def body():
+        try:
+            sh = ShardedSearch.from_index(index, ROW_SHARD, native=True)
+            if sh.native_group is None:
+                res["status"] = "not opened: the ranks agreed on the torch.distributed engine (see the warning on stderr)"
+                return
+            qs = queries[:sl]
+            out = sh.search_reweighted(qs, k)
+            ctx.sync()
+            res["equals_torch_engine"] = bool(all(torch.equal(a, b) for a, b in zip(out, ref_out)))
+            t0 = time.perf_counter()
+            for _ in range(3):
+                sh.search_reweighted(qs, k)
+            ctx.sync()
+            res["ms_per_slice"] = (time.perf_counter() - t0) / 3 * 1e3
+            res["slice"] = int(qs.shape[0])
+            sh.close()
+            res["status"] = "ok"
+        except Exception as exc:   # reported, never fatal: the line's numbers do not depend on this engine
+            res["status"] = f"error: {exc}"
+
+    th = threading.Thread(target=body, daemon=True)
+    th.start()
+    th.join(limit_s)
+    if th.is_alive():
+        res["status"] = f"timed out after {limit_s:.0f} s (a rank stuck in the C-ABI collective)"
+        ctx.native_hung = True
+    return res
 
 
 def device_shard(torch, dev, n, dim, seed):
@@ -466,8 +593,13 @@ def run_rowshard(ctx, args, index_factory=hip_index_factory, sharded_factory=Non
     # the row-sharded HIP path returned must equal that merge bit for bit
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
-    m = min(64 if ctx.world <= 2 else 32, sl, nq)
-    sample = queries[:m].contiguous()
+    # eight queries of EVERY slice, spread by stride - the short last slice (another launch geometry) included
+    starts = list(range(0, nq, sl))
+    per = 8 if ctx.world <= 2 else 4
+    pick = [(j, (i * min(sl, nq - s0)) // per) for j, s0 in enumerate(starts) for i in range(min(per, min(sl, nq - s0)))]
+    sel = torch.tensor([starts[j] + o for j, o in pick], device=queries.device, dtype=torch.long)
+    m = int(len(sel))
+    sample = queries[sel].contiguous()
     t0 = time.perf_counter()
     os_, oi_ = orc.flat_ip_topk(shard_host, sample.cpu().numpy(), k, id_base=ctx.rank * n,
                                 nthreads=max(1, (os.cpu_count() or 1) // max(1, ctx.world)))
@@ -482,23 +614,26 @@ def run_rowshard(ctx, args, index_factory=hip_index_factory, sharded_factory=Non
     else:
         es, ei = es.unsqueeze(0), ei.unsqueeze(0)
     ws, wi = exact_merge_torch(torch, es, ei, k)
-    adj0, raw0, ids0, lv0 = outs[0]
+    adj0, raw0, ids0, lv0 = (torch.stack([outs[j][c][o] for j, o in pick]) for c in range(4))   # the sampled rows of every slice
     # the path's output is in reweighted order: compare as sets of (id, raw score) per query, and its adjusted order
-    got = torch.argsort(ids0[:m], dim=1)
+    got = torch.argsort(ids0, dim=1)
     want = torch.argsort(wi, dim=1)
-    ids_ok = bool(torch.equal(torch.gather(ids0[:m], 1, got), torch.gather(wi, 1, want)))
-    raw_ok = bool(torch.equal(torch.gather(raw0[:m], 1, got).view(torch.int32), torch.gather(ws, 1, want).view(torch.int32)))
-    sorted_ok = bool((adj0[:, 1:] <= adj0[:, :-1]).all())
+    ids_ok = bool(torch.equal(torch.gather(ids0, 1, got), torch.gather(wi, 1, want)))
+    raw_ok = bool(torch.equal(torch.gather(raw0, 1, got).view(torch.int32), torch.gather(ws, 1, want).view(torch.int32)))
+    sorted_ok = all(bool((o[0][:, 1:] <= o[0][:, :-1]).all()) for o in outs)
     # rank 0 also checks the reweighted ORDER of the sample: adjusted score = raw x weight of the level the hit carries
     # (levels of its own shard from the host copy; hits of other shards carry their level in the payload)
     adj_ok = True
     if ctx.rank == 0:
-        a0, r0, i0, l0 = (x[:m].cpu().numpy() for x in (adj0, raw0, ids0, lv0))
+        a0, r0, i0, l0 = (x.cpu().numpy() for x in (adj0, raw0, ids0, lv0))
         w = np.where(l0 == 1, 1.2, np.where(l0 == 3, 0.8, 1.0))
         adj_ok = bool(np.array_equal(a0, r0.astype(np.float64) * w))
         mine = (i0 >= 0) & (i0 < n)
         adj_ok = adj_ok and bool(np.array_equal(l0[mine], levels_host[i0[mine]]))
     stats = index.stats() if hasattr(index, "stats") else {}
+    trial = None
+    if ctx.world > 1 and sharded_factory is None and getattr(sharded, "native_group", None) is None and not args.no_native_trial:
+        trial = native_group_trial(ctx, index, queries, sl, k, outs[0], args.native_trial_limit)
     line = None
     if ctx.rank == 0:
         flops_gpu = 2.0 * nq * n * dim
@@ -519,15 +654,20 @@ def run_rowshard(ctx, args, index_factory=hip_index_factory, sharded_factory=Non
                        "collective_ranks": dist.get_world_size() if ctx.world > 1 else 1},
             "whole_job_tflops": ctx.world * flops_gpu * steps / elapsed / 1e12,
             "ids_exact_on_sample": ids_ok, "raw_scores_exact_on_sample": raw_ok, "adjusted_sorted": sorted_ok,
-            "adjusted_scores_exact_on_sample": adj_ok, "sample_queries": int(m),
+            "adjusted_scores_exact_on_sample": adj_ok, "sample_queries": int(m), "sample_slices": int(len(starts)),
+            "sample_rule": f"{per} queries of every slice of {sl} (the last slice has {nq - starts[-1]}), spread by stride",
             "sample_checked_against": "oracle/icd_oracle.c over every rank's shard (host copy), merged by plain torch", "parity_check_s": round(check_s, 2),
             "fallback_queries_last_slice": int(stats.get("last_fallback", 0)),
             "index_build_s": round(t_build, 3),
+            "native_group_trial": trial,
             "roofline": {"bound": "mfma", "kernel": "coarse_flat_kernel", "achieved": achieved, "peak": PEAK_TFLOPS_F16,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS_F16, "traffic": traffic, "traffic_source": traffic_src,
                          "flops_per_launch": flops_gpu / launches, "launch_ms": dom_ms, "launches_averaged": int(prof.get("count", 0))},
         }
-    index.close()
+    if not getattr(ctx, "native_hung", False):   # (a rank stuck inside the C-ABI collective still owns the group: leave it to process exit)
+        if hasattr(sharded, "close"):
+            sharded.close()
+        index.close()
     return line
 
 
@@ -552,14 +692,41 @@ def free_port():
         return sk.getsockname()[1]
 
 
+def visible_gpus():
+    """GPUs this process may use, counted WITHOUT touching the HIP runtime (torch.cuda.device_count() falls through to
+    hipGetDeviceCount when amdsmi is absent, which opens /dev/kfd): the visibility variables when set, else the KFD topology
+    nodes that have SIMDs (CPU nodes have none). None when neither source exists."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        count = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as fh:
+                for ln in fh:
+                    if ln.startswith("simd_count"):
+                        count += 1 if int(ln.split()[1]) > 0 else 0
+        return count
+    except OSError:
+        return None
+
+
 def spawn_ranks(args, argv):
     """`python bench.py --gpus N` outside torchrun: start the N ranks as ONE child (python -m torch.distributed.run, one
-    rank per GPU) BEFORE anything in this process has touched the GPU, relay rank 0's JSON line, exit with the child's
-    status. The parent never initialises HIP (a process that has must not exec or fork GPU work)."""
+    rank per GPU), relay rank 0's JSON line, exit with the child's status. The parent never initialises HIP (a process that
+    has must not exec or fork GPU work): it counts the devices from the environment / sysfs (visible_gpus). The child runs in
+    its own process group under a wall-clock limit (--rank-timeout): a rank that hangs - one stuck in a collective the others
+    never entered - gets the whole group killed and the parent exits 124, instead of hanging until the caller's own limit."""
+    import signal
     import subprocess
-    import torch   # (importing torch and counting devices does not initialise the runtime)
+    import threading
     one_device = os.environ.get("ICD_BENCH_ONE_DEVICE") == "1" or os.environ.get("ICD_BENCH_DEVICE") == "cpu"
-    have = torch.cuda.device_count()
+    have = visible_gpus()
+    if have is None:   # no sysfs topology (not a ROCm box): ask torch, which may initialise the runtime - nothing is started after a refusal
+        import torch
+        have = torch.cuda.device_count()
     if not one_device and have < args.gpus:
         print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible", file=sys.stderr)
         return 2
@@ -567,7 +734,46 @@ def spawn_ranks(args, argv):
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), "--", os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (dmabuf IPC: RCCL between processes needs it on this driver)
-    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    timed_out = []
+
+    def descendants(root):
+        """every live process below `root` (torchrun starts each rank in a session of its own, so the launcher's process group
+        does not contain them): the /proc parent links, followed from the child this function started - exact PIDs, never a
+        name pattern"""
+        kids = {}
+        for ent in os.listdir("/proc"):
+            if ent.isdigit():
+                try:
+                    with open(f"/proc/{ent}/stat") as fh:
+                        st = fh.read()
+                    ppid = int(st[st.rindex(")") + 2:].split()[1])
+                    kids.setdefault(ppid, []).append(int(ent))
+                except (OSError, ValueError):
+                    pass
+        out, todo = [], [root]
+        while todo:
+            for c in kids.get(todo.pop(), []):
+                out.append(c)
+                todo.append(c)
+        return out
+
+    def kill_group():
+        timed_out.append(True)
+        victims = descendants(p.pid)   # (listed BEFORE the launcher dies: its orphans would be re-parented to init)
+        for pid in [p.pid] + victims:
+            try:
+                os.kill(pid, signal.SIGKILL)
+            except OSError:
+                pass
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except OSError:
+            pass
+
+    watchdog = threading.Timer(max(1.0, float(args.rank_timeout)), kill_group)
+    watchdog.daemon = True
+    watchdog.start()
     line = None
     for raw in p.stdout:
         t = raw.strip()
@@ -576,6 +782,10 @@ def spawn_ranks(args, argv):
         elif t:
             print(t, file=sys.stderr)   # anything else a rank printed
     rc = p.wait()
+    watchdog.cancel()
+    if timed_out:
+        print(f"bench.py: the {args.gpus}-rank child did not finish within --rank-timeout {args.rank_timeout:.0f} s: the ranks (its process tree) were killed", file=sys.stderr)
+        return 124
     if rc != 0 or line is None:
         print(f"bench.py: the {args.gpus}-rank child exited with status {rc}" + ("" if line else " and printed no result line"), file=sys.stderr)
         return rc if rc != 0 else 3
@@ -604,7 +814,16 @@ def main(argv=None):
     ap.add_argument("--rowshard-steps", type=int, default=3, help="passes of the row-sharded workload (each ~0.2 s per GPU)")
     ap.add_argument("--no-rowshard", action="store_true", help="N > 1: skip the row-sharded leg of the default run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the real-size / clustered / exact-mode side workloads")
+    ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the real-size / clustered / k = 20 / family / exact-mode side workloads")
+    ap.add_argument("--no-family", action="store_true", help="N = 1: skip the k = 20 and ICD-shaped (family) side workloads")
+    ap.add_argument("--family-families", type=int, default=300)
+    ap.add_argument("--family-rows", type=int, default=124)
+    ap.add_argument("--config3-queries", type=int, default=125_000, help="N > 1: queries per GPU of the BASELINE configs[3] leg (1 M over 8 GPUs)")
+    ap.add_argument("--config3-steps", type=int, default=3)
+    ap.add_argument("--no-config3", action="store_true", help="N > 1: skip the configs[3] leg of the default run")
+    ap.add_argument("--no-native-trial", action="store_true", help="N > 1: skip the time-limited trial of the C-ABI RCCL group behind the row-sharded leg")
+    ap.add_argument("--native-trial-limit", type=float, default=90.0)
+    ap.add_argument("--rank-timeout", type=float, default=1500.0, help="--gpus N > 1 started by this process: wall-clock limit of the ranks in seconds")
     args = ap.parse_args(argv)
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -618,17 +837,28 @@ def main(argv=None):
     ctx = Ctx()
     if os.environ.get("ICD_BENCH_TEST_FAIL_RANK") == str(ctx.rank):   # test hook: a rank that dies must fail the whole run
         raise RuntimeError(f"rank {ctx.rank}: forced failure (ICD_BENCH_TEST_FAIL_RANK)")
+    if os.environ.get("ICD_BENCH_TEST_HANG_RANK") == str(ctx.rank):   # test hook: a rank that never returns must not hang the parent
+        time.sleep(10 ** 6)
     eng = test_engine()
     if args.workload == "rowshard":
         line = run_rowshard(ctx, args, **eng)
     else:
         line = run_replicated(ctx, args, **({"index_factory": eng["index_factory"]} if eng else {}))
+        if ctx.world > 1 and not args.no_config3:
+            c3 = run_config3(ctx, args, **({"index_factory": eng["index_factory"]} if eng else {}))
+            if line is not None:
+                line["config3"] = c3
         if ctx.world > 1 and not args.no_rowshard:
             rs = run_rowshard(ctx, args, **eng)
             if line is not None:
                 line["rowshard"] = rs
     if ctx.rank == 0:
         print(json.dumps(line), flush=True)
+    if getattr(ctx, "native_hung", False):
+        # the trial's thread is stuck in a collective of the C-ABI group: the line is out, nothing else of value can happen
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
     if ctx.world > 1:
         ctx.dist.barrier()
         ctx.dist.destroy_process_group()

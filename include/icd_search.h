@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define ICD_ABI_VERSION 3   /* 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
+#define ICD_ABI_VERSION 4   /* 4: icd_debug_set_family_order, icd_group_prepare / icd_group_connect (round 4). 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
 #define ICD_MAX_K 128
 
 typedef struct icd_index icd_index;
@@ -174,6 +174,11 @@ int icd_merge_topk(int32_t device, const float *scores, const int64_t *ids, cons
  * this rank's slice. Everything is enqueued on `stream`; nothing synchronises. world = 1 needs no id and no RCCL (given
  * an id all the same, a one-rank communicator is created and the collective path runs end to end: tests).
  * librccl.so.1 is opened (dlopen) by the first call that needs it.
+ * icd_group_create = icd_group_prepare (everything that can fail on ONE rank alone: argument checks, the device buffers,
+ * opening librccl) + icd_group_connect (ncclCommInitRank: COLLECTIVE - a rank that fails before it leaves the others
+ * waiting inside it). A host whose ranks can fail locally calls the two itself and lets the ranks agree on the outcome of
+ * prepare (any side channel) before any of them connects; rag_project_icd10_amd/sharded.py does exactly that over the
+ * torch.distributed group that already exists. Errors of a group call name the rank and the world size.
  */
 #define ICD_GROUP_ID_BYTES 128
 typedef struct icd_group icd_group;
@@ -181,6 +186,10 @@ typedef enum icd_group_mode { ICD_GROUP_ROW_SHARD = 0, ICD_GROUP_QUERY_SHARD = 1
 int icd_group_unique_id(uint8_t *out_id /* [ICD_GROUP_ID_BYTES] */);
 int icd_group_create(icd_index *local, const uint8_t *id, int32_t rank, int32_t world, int32_t mode, int32_t max_nq,
                      int32_t max_k, icd_group **out);
+/* with_comm: 1 = a communicator will follow (always the case for world > 1; a one-rank group may ask for one: tests) */
+int icd_group_prepare(icd_index *local, int32_t with_comm, int32_t rank, int32_t world, int32_t mode, int32_t max_nq,
+                      int32_t max_k, icd_group **out);
+int icd_group_connect(icd_group *group, const uint8_t *id);
 int icd_group_search(icd_group *group, const float *queries, int64_t nq, int32_t k, int32_t gather, double *out_adj,
                      float *out_raw, int64_t *out_ids, int32_t *out_levels, void *stream);
 int icd_group_destroy(icd_group *group);   /* (the index stays with the caller) */
@@ -269,6 +278,11 @@ int icd_debug_set_permute(int32_t enabled);
  * narrow plan's lists - a corpus of tight families of near-identical rows. A performance decision only: results are
  * identical either way, and later searches keep deciding from their own counters. */
 int icd_debug_set_create_probe(int32_t enabled);
+
+/* Test switch, process-wide, read by every search (default 1): 0 keeps the wide-window finalize of a family-shaped corpus
+ * (icd_stats.wide_mode) in batch order instead of visiting the queries family by family, XCD by XCD (finalize.hpp,
+ * order_keys_kernel / order_scatter_kernel). A performance decision only: results are identical either way. */
+int icd_debug_set_family_order(int32_t enabled);
 
 /* Diagnostic builds only (make ABLATE=1, env ICD_FLAT_VAR with bit 1024): per-wave cycle sums of the coarse kernel,
  * [work-group][wave][8] = {LDS-DMA wait, barrier, stage body, fused select, tiles, ...}. */

@@ -20,18 +20,18 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libicdsearch.so")
 MODE_AUTO = 0   # fp16-MFMA coarse pass + certified exact rescoring (+ exact fallback); same results as EXACT
 MODE_EXACT = 1  # fp32-MFMA kernel only
 MAX_K = 128
-ABI_VERSION = 3   # include/icd_search.h ICD_ABI_VERSION: a stale libicdsearch.so is refused with a clear message
+ABI_VERSION = 4   # include/icd_search.h ICD_ABI_VERSION: a stale libicdsearch.so is refused with a clear message
 
 EXPORTED_SYMBOLS = (
     "icd_abi_version", "icd_last_error", "icd_device_count", "icd_index_create", "icd_index_destroy",
     "icd_index_search", "icd_index_search_reweighted", "icd_merge_topk", "icd_index_lookup_levels",
     "icd_index_stats", "icd_index_set_chunks", "icd_index_debug_counters", "icd_index_set_profiling",
-    "icd_index_last_profile", "icd_index_profile_summary", "icd_debug_set_permute", "icd_debug_set_create_probe", "icd_packed_attention",
+    "icd_index_last_profile", "icd_index_profile_summary", "icd_debug_set_permute", "icd_debug_set_create_probe", "icd_debug_set_family_order", "icd_packed_attention",
     "icd_hier_rescore",
     "icd_score_stats",
     "icd_cosine_rows",
     "icd_index_set_second_pass",
-    "icd_group_unique_id", "icd_group_create", "icd_group_search", "icd_group_destroy",
+    "icd_group_unique_id", "icd_group_create", "icd_group_prepare", "icd_group_connect", "icd_group_search", "icd_group_destroy",
 )
 GROUP_ROW_SHARD = 0
 GROUP_QUERY_SHARD = 1
@@ -89,10 +89,13 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.icd_index_set_second_pass.argtypes = [vp, i32]
     lib.icd_group_unique_id.argtypes = [vp]
     lib.icd_group_create.argtypes = [vp, vp, i32, i32, i32, i32, i32, C.POINTER(vp)]
+    lib.icd_group_prepare.argtypes = [vp, i32, i32, i32, i32, i32, i32, C.POINTER(vp)]
+    lib.icd_group_connect.argtypes = [vp, vp]
     lib.icd_group_search.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, vp, vp]
     lib.icd_group_destroy.argtypes = [vp]
     lib.icd_debug_set_permute.argtypes = [i32]
     lib.icd_debug_set_create_probe.argtypes = [i32]
+    lib.icd_debug_set_family_order.argtypes = [i32]
     lib.icd_packed_attention.argtypes = [i32, vp, i64, vp, i32, i32, i32, i32, vp, i64, vp]
     lib.icd_hier_rescore.argtypes = [i32, vp, vp, i64, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.icd_score_stats.argtypes = [i32, vp, vp, i64, i32, i32, vp, vp]
@@ -184,6 +187,10 @@ class IcdIndex:
     # -- lifecycle -----------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
+            for ref in list(getattr(self, "_group_refs", [])):   # (an IcdGroup borrows this handle: it goes first, never dangles)
+                grp = ref()
+                if grp is not None:
+                    grp.close()
             self._lib.icd_index_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -340,7 +347,10 @@ class IcdGroup:
     of rank 0 (None for a single rank). search() takes the FULL query batch as a CUDA tensor on every rank."""
 
     def __init__(self, index: "IcdIndex", mode: int, rank: int = 0, world: int = 1, unique_id: Optional[bytes] = None,
-                 max_nq: Optional[int] = None, max_k: Optional[int] = None):
+                 max_nq: Optional[int] = None, max_k: Optional[int] = None, connect: bool = True, with_comm: Optional[bool] = None):
+        """connect=True (default): prepare + connect in one go (`unique_id` required for world > 1). connect=False: only the
+        LOCAL half (icd_group_prepare: argument checks, buffers, librccl) - the caller lets the ranks agree that every one of
+        them got this far and then calls connect(unique_id) on all of them (collective) or close() on all of them."""
         self._lib = load_library()
         self._h = C.c_void_p()
         self.index, self.mode, self.rank, self.world = index, int(mode), int(rank), int(world)
@@ -348,25 +358,53 @@ class IcdGroup:
         #  slice of world x max_nq queries gives every rank max_nq of them)
         self.max_nq = int(max_nq or (index.max_nq if mode == GROUP_ROW_SHARD else index.max_nq * max(1, world)))
         self.max_k = int(max_k or min(index.max_k, 1024 // max(1, world) if mode == GROUP_ROW_SHARD else index.max_k))
-        idbuf = None
-        if world > 1 and unique_id is None:
+        if connect and world > 1 and unique_id is None:
             raise ValueError(f"a group of {world} ranks needs rank 0's {GROUP_ID_BYTES}-byte unique id")
-        if unique_id is not None:   # (world = 1 with an id: a one-rank communicator, the collective path end to end)
-            if len(unique_id) != GROUP_ID_BYTES:
-                raise ValueError(f"unique id must be {GROUP_ID_BYTES} bytes")
-            idbuf = (C.c_uint8 * GROUP_ID_BYTES).from_buffer_copy(unique_id)
-        _check(self._lib, self._lib.icd_group_create(index._h, C.cast(idbuf, C.c_void_p) if idbuf is not None else None, self.rank,
-                                                      self.world, self.mode, self.max_nq, self.max_k, C.byref(self._h)))
+        if with_comm is None:   # (world = 1 with an id: a one-rank communicator, the collective path end to end)
+            with_comm = world > 1 or unique_id is not None
+        if index.closed:
+            raise IcdError(-5, "index is closed")
+        _check(self._lib, self._lib.icd_group_prepare(index._h, 1 if with_comm else 0, self.rank, self.world, self.mode, self.max_nq,
+                                                       self.max_k, C.byref(self._h)))
+        self.connected = not with_comm
+        import weakref
+        if not hasattr(index, "_group_refs"):
+            index._group_refs = []
+        index._group_refs.append(weakref.ref(self))   # the group borrows the index's handle: IcdIndex.close() closes it first
+        if connect and with_comm:
+            try:
+                self.connect(unique_id)
+            except Exception:
+                self.close()
+                raise
+
+    def connect(self, unique_id: bytes):
+        """COLLECTIVE (ncclCommInitRank): every rank of the group calls it, or none does"""
+        if self.connected:
+            return
+        if unique_id is None or len(unique_id) != GROUP_ID_BYTES:
+            raise ValueError(f"unique id must be {GROUP_ID_BYTES} bytes")
+        idbuf = (C.c_uint8 * GROUP_ID_BYTES).from_buffer_copy(unique_id)
+        _check(self._lib, self._lib.icd_group_connect(self._h, C.cast(idbuf, C.c_void_p)))
+        self.connected = True
 
     def search(self, queries, k: int = 10, gather: bool = True):
         """-> (adj f64, raw f32, ids i64, levels i32), each [nq, k] CUDA tensors (query-sharded with gather=False: only
         this rank's rows). Batches larger than the group's max_nq go through in slices of that many queries."""
         import torch
+        if not getattr(self, "_h", None) or not self._h.value:
+            raise IcdError(-5, "group is closed")
         q, on_dev = self.index._prep_queries(queries)
+        self.index._validate(q, k)   # (icd_group_search has no dim argument: a wrong width would be an out-of-bounds device read)
+        if k > self.max_k:
+            raise ValueError(f"k={k} outside 1..{self.max_k} (group)")
         if not on_dev:
             q = torch.from_numpy(q).to(torch.device("cuda", self.index.device))
         nq, dev = int(q.shape[0]), q.device
         local_only = self.mode == GROUP_QUERY_SHARD and not gather
+        if local_only and nq > self.max_nq:
+            # (slices of max_nq would each be split over the ranks: another set of rows than shard_bounds(nq) of the whole batch)
+            raise ValueError(f"query-sharded search without gather takes at most the group's max_nq = {self.max_nq} queries per call (got {nq})")
         parts = []
         for s0 in range(0, max(nq, 1), self.max_nq):
             qs = q[s0:s0 + self.max_nq]

@@ -49,7 +49,7 @@ class Candidate(BaseModel):
 
 
 _CAND_FIELDS = frozenset(("code", "title", "score", "level", "parent_code", "enhanced_score", "original_score", "similarity_factors"))
-_CAND_FIELDS_SET = set(_CAND_FIELDS)   # shared by every trusted Candidate of trusted_candidates (assigning a field adds a name it already holds)
+_CAND_FIELDS_SET = frozenset(_CAND_FIELDS)   # copied into every trusted Candidate of trusted_candidates (its own mutable set, like a validated object's)
 _trusted_ok: Optional[bool] = None
 
 
@@ -104,7 +104,7 @@ def trusted_candidates(recs, ids, scores, originals, factors) -> List["Candidate
         c = new(Candidate)
         setattr_(c, "__dict__", {"code": rec.get("code", ""), "title": rec.get("preferred_zh", ""), "score": s, "level": 1,
                                  "parent_code": "", "enhanced_score": s, "original_score": o, "similarity_factors": f})
-        setattr_(c, "__pydantic_fields_set__", fields_set)
+        setattr_(c, "__pydantic_fields_set__", set(fields_set))   # (its own set: model_fields_set is mutable per object)
         setattr_(c, "__pydantic_extra__", None)
         setattr_(c, "__pydantic_private__", None)
         out.append(c)

@@ -37,6 +37,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // operand: 8 instead of 5 instructions per score in the threshold bootstrap); MFMA results need no quieting
 __device__ __forceinline__ float raw_min_f32(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float raw_max_f32(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float raw_max3_f32(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
 #ifndef ICD_CO_KP
 #define ICD_CO_KP 16

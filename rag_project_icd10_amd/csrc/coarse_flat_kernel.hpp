@@ -31,6 +31,7 @@ struct CoarseFlatArgs {
     int pos_period;          // ctiles / gcd(U, ctiles): work-groups l and l + pos_period start on the same corpus tile
     int list_tiles;          // a list covers at most this many tiles
     int boot_tiles;          // threshold bootstrap over at most this many first tiles of a list (less for larger k)
+    int sparse_from;         // (VAR & 16777216) from this tile of a list on, 8-register groups are pre-filtered by their maximum
     int P;                   // list slots per query (>= the largest number of lists of any query tile)
     float *part_scores;      // [nq][P][KP] (KP = the instantiation's candidates per list)
     int *part_rows;
@@ -48,6 +49,7 @@ struct CoarseFlatArgs {
 constexpr int CO_BOOT_MIN_TILES = 6;   // lists at least this long bootstrap their threshold ...
 constexpr int CO_KP_WIDE = 24;         // candidates per list of the instantiation for larger k (see icd_search.hip)
 constexpr int CO_BOOT_TILES = 8;       // ... over their first tiles
+constexpr int CO_SPARSE_FROM = 40;     // (VAR & 16777216) tiles of a list before its 8-register groups are pre-filtered by their maximum
 
 // End of a list, all 32 queries of the wave at once (lane = half a query; the one-query-at-a-time compaction of
 // Sel2Ops costs ~1 400 cycles per query: 45 000 per list and wave, 7 % of a 90-tile sweep). Every lane loads the 32
@@ -273,6 +275,19 @@ __device__ __forceinline__ void compact_all_parallel(char *smem, Sel2 &st, uint3
 //   1048576  ONE barrier per TWO stages: ring of six 16-KB slots (no compaction scratch: the rare tie-ranking path ranks with
 //        v_readlane), the mid-stage wait + barrier of the even stages publishes the next two stages and is followed by
 //        the LDS-DMA pieces of two stages (eight, two behind each MFMA group); odd stages run without wait or barrier
+//   2097152  the four LDS-DMA pieces of a stage spread over a WHOLE stage interval, one per eight MFMAs (pieces 0, 1 in the half
+//        stage behind the barrier, pieces 2, 3 in the next stage's half in front of its barrier) instead of one behind each of
+//        the first four MFMA pairs: the CU's one address unit takes 16 cycles per piece and the four waves issue in step, so
+//        four pieces per 32 cycles queue (a piece stalls its wave ~45 cycles); at one per 128 cycles they do not
+//   4194304  threshold bootstrap with three INDEPENDENT instructions per score (b1' = max(b1, v), b2' = med3(b1, b2, v),
+//        b3' = med3(b2, b3, v): with b1 >= b2 >= b3 these are the three largest of {b1, b2, b3, v}) on two register chains
+//        (even / odd registers, merged once per tile) instead of the five-instruction min / max ladder on one chain
+//   8388608  the overflow guard of the select (every 8 registers) only when some lane has appended since the last one: a
+//        wave-uniform flag set by the append path; a warm list passes most 8-register groups without an append
+//   16777216  from tile `sparse_from` of a list on, the select first reduces every 8 registers (two quads) to their lane
+//        maximum (three v_max3 + one v_max) and tests THAT against the threshold: one compare and one scalar branch per 8
+//        registers while nothing passes, the two quads' own tests only behind it. A warm list passes most groups untouched
+//        (a 1.25 M-row shard's lists are 4 900 tiles long and append a handful of rows per hundred tiles)
 //   TIMING ONLY (the results are not the scores; they size the parts of the kernel, profiles/r02_coarse_loop_decomposition.log):
 //   256 no s_barrier   512 no wait for the LDS-DMA pieces   4096 thresholds at +inf (nothing passes)
 //   8192 no select at all   16384 no LDS-DMA inside the tile loop   65536 (with 32768) no lane swaps
@@ -308,10 +323,16 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     constexpr bool NOBAR = (VAR & 256) != 0, NOVM = (VAR & 512) != 0, STAMPS = (VAR & 1024) != 0;
     constexpr bool NOPASS = (VAR & 4096) != 0, NOSEL = (VAR & 8192) != 0, NODMA = (VAR & 16384) != 0;
     constexpr bool PAIRBAR = (VAR & 1048576) != 0;
+    constexpr bool DMA_WIDE = (VAR & 2097152) != 0;
+    constexpr bool BOOT_MED3 = (VAR & 4194304) != 0;
+    constexpr bool DIRTY_GUARD = (VAR & 8388608) != 0;
+    constexpr bool SPARSE_PRE = (VAR & 16777216) != 0;
+    static_assert(!SPARSE_PRE || (QUAD && X16), "the group pre-filter is built on the quad select of the 16x16x32 form");
+    static_assert(!DMA_WIDE || (DMA_SPREAD && PF2 && !NODMA), "the wide spread is built on the product's stage");
     constexpr int S = cf_ring_stages(VAR);            // ring slots
     constexpr int VM_MID = NOVM ? 63 : (PAIRBAR ? 4 : 4 * (S - 3));   // LDS-DMA pieces that may stay in flight at the mid-stage wait
     constexpr int PRO = PAIRBAR ? 4 : S - 1;          // stages issued by a list's prologue
-    constexpr int VM_TILE_END = NOVM ? 0 : (PAIRBAR ? 8 : 4 * (S - 2));   // pieces younger than the early threshold load at the tile end
+    constexpr int VM_TILE_END = NOVM ? 0 : (PAIRBAR ? (DMA_WIDE ? 6 : 8) : (DMA_WIDE ? 4 * (S - 2) - 2 : 4 * (S - 2)));   // pieces younger than the early threshold load at the tile end
     constexpr int KS = D / CO_BK;      // stages per tile
     constexpr int NF = D / 16;         // query fragments per lane
     static_assert(KS % S == 0, "ring slot must be a compile-time function of the stage");
@@ -420,17 +441,21 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
         const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<_Float16 *>(a.c16) + (size_t)t0 * CO_BN * D, 0,
             (int)min((size_t)(a.ctiles - t0) * CO_BN * (size_t)(D * 2), (size_t)0x7FFFFFFF), 0x00020000);
-        auto issue_stage = [&](int g_tile, int g_ks, int ring_slot) {
+        auto issue_pieces = [&](int g_tile, int g_ks, int ring_slot, auto LO, auto HI) {   // pieces [LO, HI) of a stage
             const int trow = min(g_tile, last_tile - t0);   // stages past the sweep re-read valid memory, never consumed
             char *dst = smem + ring_slot * CO_STAGE_BYTES + wave * 4096;
             const uint32_t soff = (uint32_t)trow * (uint32_t)(CO_BN * D * 2) + (uint32_t)g_ks * (CO_BK * 2);
             // The instruction offset is added to the LDS address AND the buffer address: piece i lands at dst + 1024 i
             // with ONE M0 for the four pieces; src_off[i] was reduced by 1024 i to compensate on the buffer side.
             __attribute__((address_space(3))) void *ldst = (__attribute__((address_space(3))) void *)dst;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, ldst, 16, src_off[0], soff, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, ldst, 16, src_off[1], soff, 1024, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, ldst, 16, src_off[2], soff, 2048, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, ldst, 16, src_off[3], soff, 3072, 0);
+            constexpr int lo = decltype(LO)::value, hi = decltype(HI)::value;
+            if constexpr (lo <= 0 && 0 < hi) __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, ldst, 16, src_off[0], soff, 0, 0);
+            if constexpr (lo <= 1 && 1 < hi) __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, ldst, 16, src_off[1], soff, 1024, 0);
+            if constexpr (lo <= 2 && 2 < hi) __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, ldst, 16, src_off[2], soff, 2048, 0);
+            if constexpr (lo <= 3 && 3 < hi) __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, ldst, 16, src_off[3], soff, 3072, 0);
+        };
+        auto issue_stage = [&](int g_tile, int g_ks, int ring_slot) {
+            issue_pieces(g_tile, g_ks, ring_slot, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
         };
 
         Sel2 st;
@@ -441,6 +466,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
         unsigned int *my_shared = a.shared_thr + (slot0 + wave * 32 + c);
         const bool publish = (slot0 + wave * 32 + c) < nq_act;   // (padding queries sit at +inf and never publish)
         uint32_t published = 0u;
+        int dirty = 0;   // (DIRTY_GUARD; wave-uniform) some lane has appended since the last overflow check
         auto filter_reg = [&](const f32x16 (&pa)[4], auto F, uint32_t rowbase, auto GUARD) {
             constexpr int f = decltype(F)::value;
             constexpr int t = f >> 4, r = f & 15;
@@ -507,20 +533,44 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                              : "+v"(st.aw), "=&v"(r1), "=&v"(r2), "=&v"(r3)
                              : "s"(m0), "s"(m1), "s"(m2), "s"(m3), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(rowq), "v"(st.inc)
                              : "memory");
+                if constexpr (DIRTY_GUARD) dirty = 1;
             }
             if constexpr (q % 2 == 1) {   // every 8 registers: the overflow guard of filter_reg
+                if constexpr (DIRTY_GUARD) {
+                    if (dirty) {
+                        dirty = 0;
+                        if (__builtin_amdgcn_ballot_w64(Ops::used(st, h) > CO_QUOTA) != 0ull)
+                            Ops::template check<PAIRBAR>(st, lane, smem, wave_qbase, wave_scratch, false, CO_LIMIT, STAMPS ? st_comp : nullptr, CO_QUOTA);
+                    }
+                } else
                 if (__builtin_amdgcn_ballot_w64(Ops::used(st, h) > CO_QUOTA) != 0ull)
                     Ops::template check<PAIRBAR>(st, lane, smem, wave_qbase, wave_scratch, false, CO_LIMIT, STAMPS ? st_comp : nullptr, CO_QUOTA);
             }
         };
         static_assert(!QUAD || Ops::ROW_OFF == 256, "ds_write2st64_b32 offset1:1 = the row array of the query's buffer");
+        // SPARSE_PRE: quads 2 G and 2 G + 1 (registers xs[2 G], xs[2 G + 1]) behind one test of their lane maximum. Rows past
+        // the corpus are only masked inside filter_quad: a zero pad row above the threshold costs the detour, nothing else.
+        auto filter_group = [&](const f32x16 (&pa)[X16 ? 1 : 4], const f32x4 (&px)[X16 ? 16 : 1], auto G, uint32_t rowbase, auto GUARD) {
+            constexpr int g = decltype(G)::value;
+            const f32x4 &x0 = px[X16 ? 2 * g : 0], &x1 = px[X16 ? 2 * g + 1 : 0];
+            float m = raw_max3_f32(x0[0], x0[1], x0[2]);
+            m = raw_max3_f32(m, x0[3], x1[0]);
+            m = raw_max3_f32(m, x1[1], x1[2]);
+            m = raw_max_f32(m, x1[3]);
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(m > st.thr) != 0ull, 0)) {
+                filter_quad(pa, px, std::integral_constant<int, 2 * g>{}, rowbase, GUARD);
+                filter_quad(pa, px, std::integral_constant<int, 2 * g + 1>{}, rowbase, GUARD);
+            }
+        };
 
         // prologue: stages 0..S-2 in flight, stage 0 published, its first fragments read
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (query fragment loads: the vmcnt accounting starts from zero)
 #pragma unroll
-        for (int p = 0; p < PRO; ++p) issue_stage(p / KS, p % KS, p % S);
+        for (int p = 0; p < PRO - (DMA_WIDE ? 1 : 0); ++p) issue_stage(p / KS, p % KS, p % S);
+        // (DMA_WIDE: the last prologue stage's pieces 2, 3 go out in the first stage's front half, like every later stage's)
+        if constexpr (DMA_WIDE) issue_pieces((PRO - 1) / KS, (PRO - 1) % KS, (PRO - 1) % S, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
         half8 afn[4], bfn[4];
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(4 * (PRO - 1)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(4 * (PRO - 1) - (DMA_WIDE ? 2 : 0)) : "memory");
         read_frags(afn, 0, 0);
         if constexpr (PF2) read_frags(bfn, 0, 1);
         if constexpr (STAMPS) ICD_CF_STAMP(st_prev);
@@ -542,13 +592,14 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             static_for<0, KS>([&](auto KSI) {
                 constexpr int ks = decltype(KSI)::value;
                 constexpr int slot = ks % S, nslot = (ks + 1) % S;
-                auto mfma4 = [&](const half8 (&f)[4], int qi) {
+                auto mfma4 = [&](const half8 (&f)[4], int qi, int t_lo = 0, int t_hi = 4) {
                     // (REV_WAIT: the four MFMAs of a k-step in the reverse of the order their fragments were read - the first one
                     //  waits for the youngest read, the other three need no s_waitcnt at all)
                     if constexpr (X16) {   // qi = 4 ks + quad: k-step 2 ks + (quad >> 1), row groups 4 (quad & 1) + t, both query groups
                         const int quad = qi & 3, kq = (qi >> 2) * 2 + (quad >> 1);
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
+                            if (t < t_lo || t >= t_hi) continue;
                             const int rg = 4 * (quad & 1) + t;
 #pragma unroll
                             for (int gr = 0; gr < 2; ++gr)
@@ -565,7 +616,21 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                 constexpr int M4 = X16 ? 8 : 4;   // MFMAs per k-step group
                 // stage g = (tile, ks) was published by the previous mid-stage barrier; afn holds its k-step 0 (PF2: bfn its k-step 1)
                 half8 f1[4], f2[4], f3[4];
-                if constexpr (PF2) {
+                if constexpr (DMA_WIDE) {   // pieces 2, 3 of the stage whose pieces 0, 1 went out behind the previous barrier
+                    constexpr int pks = PAIRBAR ? ks + 3 : ks + S - 2;   // (PAIRBAR: the eight pieces of two stages over two stage intervals)
+                    read_frags(f2, slot, 2);
+                    mfma4(afn, ks * 4 + 0, 0, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_pieces(tile + pks / KS, pks % KS, pks % S, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma4(afn, ks * 4 + 0, 2, 4);
+                    read_frags(f3, slot, 3);
+                    mfma4(bfn, ks * 4 + 1, 0, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_pieces(tile + pks / KS, pks % KS, pks % S, std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma4(bfn, ks * 4 + 1, 2, 4);
+                } else if constexpr (PF2) {
                     read_frags(f2, slot, 2);
                     mfma4(afn, ks * 4 + 0);
                     read_frags(f3, slot, 3);
@@ -577,10 +642,13 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                     mfma4(f1, ks * 4 + 1);
                 }
                 // pin: the reads go out before the MFMAs of the k-step in front of them
+                if constexpr (DMA_WIDE) {
+                } else {
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, M4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, M4, 0);
+                }
                 // publish stage g+1: this wave's pieces of g+1 have landed when only the stages behind it are outstanding
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (STAMPS) {
@@ -611,14 +679,28 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                 }
                 if constexpr (!NODMA && !PAIRBAR) {   // every wave is past stage g-1: its slot takes stage g+S-1
                     constexpr int nks = ks + S - 1;
-                    issue_stage(tile + nks / KS, nks % KS, nks % S);
+                    if constexpr (!DMA_WIDE) issue_stage(tile + nks / KS, nks % KS, nks % S);
                 }
-                if constexpr (!NODMA && PAIRBAR && (ks & 1) == 0) {   // every wave is past stages g-2, g-1: their slots take g+4, g+5
+                if constexpr (!NODMA && PAIRBAR && !DMA_WIDE && (ks & 1) == 0) {   // every wave is past stages g-2, g-1: their slots take g+4, g+5
                     constexpr int n4 = ks + 4, n5 = ks + 5;
                     issue_stage(tile + n4 / KS, n4 % KS, n4 % S);
                     issue_stage(tile + n5 / KS, n5 % KS, n5 % S);
                 }
-                if constexpr (PF2) {
+                if constexpr (DMA_WIDE) {
+                    constexpr int nks = PAIRBAR ? ks + 4 : ks + S - 1;
+                    read_frags(afn, nslot, 0);
+                    mfma4(f2, ks * 4 + 2, 0, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_pieces(tile + nks / KS, nks % KS, nks % S, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma4(f2, ks * 4 + 2, 2, 4);
+                    read_frags(bfn, nslot, 1);
+                    mfma4(f3, ks * 4 + 3, 0, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_pieces(tile + nks / KS, nks % KS, nks % S, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma4(f3, ks * 4 + 3, 2, 4);
+                } else if constexpr (PF2) {
                     read_frags(afn, nslot, 0);
                     mfma4(f2, ks * 4 + 2);
                     read_frags(bfn, nslot, 1);
@@ -635,6 +717,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                     __builtin_amdgcn_sched_group_barrier(0x008, M4, 1);
                     __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
                     __builtin_amdgcn_sched_group_barrier(0x008, M4, 1);
+                } else if constexpr (DMA_WIDE) {      // (one piece in the middle of each k-step group: pinned by source order above)
                 } else {                               // one piece behind each of the next four MFMAs
                     __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
 #pragma unroll
@@ -700,6 +783,29 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                 // reaches (0.6 % of the rows), so the list still fills and ends on its own KP-th best. Third best,
                 // not second: with the second best a list whose first rows happen to hold four of the query's
                 // global top hits ends on a bound inside the top-k and fails the certificate (measured 4 of 10 000).
+                if constexpr (BOOT_MED3) {
+                    // chain A = (boot1, boot2, boot3) takes the even registers, chain B the odd ones; every step is three
+                    // independent instructions on the chain's previous state
+                    float c1 = -INFINITY, c2 = -INFINITY, c3 = -INFINITY;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) {
+                            const float va = X16 ? xs[X16 ? 4 * t + (r >> 2) : 0][r & 3] : acc[X16 ? 0 : t][r];
+                            const float vb = X16 ? xs[X16 ? 4 * t + ((r + 1) >> 2) : 0][(r + 1) & 3] : acc[X16 ? 0 : t][r + 1];
+                            const float a3 = __builtin_amdgcn_fmed3f(boot2, boot3, va), a2 = __builtin_amdgcn_fmed3f(boot1, boot2, va);
+                            boot1 = raw_max_f32(boot1, va); boot2 = a2; boot3 = a3;
+                            const float b3 = __builtin_amdgcn_fmed3f(c2, c3, vb), b2 = __builtin_amdgcn_fmed3f(c1, c2, vb);
+                            c1 = raw_max_f32(c1, vb); c2 = b2; c3 = b3;
+                        }
+                    // merge: the three largest of the six (insert chain B's three into chain A)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const float v = i == 0 ? c1 : (i == 1 ? c2 : c3);
+                        const float a3 = __builtin_amdgcn_fmed3f(boot2, boot3, v), a2 = __builtin_amdgcn_fmed3f(boot1, boot2, v);
+                        boot1 = raw_max_f32(boot1, v); boot2 = a2; boot3 = a3;
+                    }
+                } else {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -711,6 +817,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                         boot2 = raw_max_f32(boot2, lo1);
                         boot3 = raw_max_f32(boot3, lo2);
                     }
+                }
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(boot3), __float_as_uint(boot3), false, false);
                 const float thr0 = fminf(boot3, __uint_as_float(h ? sw[0] : sw[1]));
                 if (thr0 > st.thr) st.thr = thr0;   // (padding queries keep +inf)
@@ -727,6 +834,7 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                 }
             } else if constexpr (QUAD) {
                 if (tile_row0 + CO_BN > a.n) static_for<0, 16>([&](auto Q) { filter_quad(acc, xs, Q, rowbase, std::true_type{}); });
+                else if (SPARSE_PRE && tile >= a.sparse_from) static_for<0, 8>([&](auto G) { filter_group(acc, xs, G, rowbase, std::false_type{}); });
                 else static_for<0, 16>([&](auto Q) { filter_quad(acc, xs, Q, rowbase, std::false_type{}); });
             } else if (tile_row0 + CO_BN > a.n) static_for<0, 64>([&](auto F) { filter_reg(acc, F, rowbase, std::true_type{}); });
             else static_for<0, 64>([&](auto F) { filter_reg(acc, F, rowbase, std::false_type{}); });

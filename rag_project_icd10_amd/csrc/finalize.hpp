@@ -242,6 +242,7 @@ __global__ __launch_bounds__(256, EWM == 1 ? ICD_FIN_OCC : 1) void finalize_kern
     const int slot = blockIdx.x * 4 + wave;
     if (slot >= nq) return;  // wave-uniform; no work-group barriers below
     const int qidx = a.qlist ? a.qlist[slot] : slot;
+    if (qidx < 0) return;   // (a padding entry of the family order, order_scatter_kernel)
 
     // the fallback's two producers leave different numbers of lists per slot (stream_topk: P, exact_topk: P_dense)
     int P = a.P;
@@ -428,6 +429,99 @@ __global__ __launch_bounds__(256, EWM == 1 ? ICD_FIN_OCC : 1) void finalize_kern
     }
     // 6-7. outputs (raw order + level reweight / stable re-sort)
     emit_outputs(a, qidx, sorted, nres, adjbuf, lane);
+}
+
+// ---- query order of the wide-window finalize on a family-shaped corpus --------------------------------------------
+// The reference's corpus rows repeat their ancestors' names (tools/build_database.py:156-171): sibling codes are near-
+// identical rows that sit next to each other in code order, and a query's rescoring window is its whole family - 124
+// rows x 3 KB = 381 KB per query, the SAME rows for every query of that family. In batch order those windows are fetched
+// from the fabric once per query (3.7 GB per 10 000 queries); with the queries ordered by the original row of their best
+// coarse candidate, and consecutive positions of that order mapped to ONE XCD (blockIdx is dealt round-robin over the
+// eight), a family's rows are served to its later queries by that XCD's L2.
+// Two launches: (1) one wave per query - best candidate, its original row, a histogram of row buckets; (2) one block -
+// prefix sum over the buckets, counting-sort scatter into `order` (slot of finalize -> query; -1 = padding). Order within a
+// bucket is whatever the atomics give: it decides which wave rescales which query first, never a result.
+constexpr int ORDER_BUCKETS = 1024;
+
+struct OrderArgs {
+    const float *part_scores;  // [query][P][KP]
+    const int *part_rows;      // positions of the permuted fp16 corpus
+    int P, KP, nq;
+    long long perm_mul; int perm_mod; double perm_inv;
+    int shift;                 // bucket = original row >> shift (< ORDER_BUCKETS)
+    int *key;                  // [nq] out of (1): the query's bucket
+    unsigned int *hist;        // [ORDER_BUCKETS] zero on entry of (1); (2) leaves it zero again
+    int *order;                // [4 * ceil(nq / 4)] out of (2)
+};
+
+__global__ __launch_bounds__(256) void order_keys_kernel(OrderArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wave;
+    if (q >= a.nq) return;
+    const int ncand = a.P * a.KP;
+    const size_t pbase = (size_t)q * ncand;
+    u64 best = 0ull;
+    for (int i = lane; i < ncand; i += 64) {
+        const int r = a.part_rows[pbase + i];
+        const float sc = a.part_scores[pbase + i];
+        if (r >= 0 && sc == sc) {
+            const u64 kx = make_key(sc, (uint32_t)r);
+            best = kx > best ? kx : best;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const u64 o = ((u64)(uint32_t)__shfl_xor((int)(best >> 32), off) << 32) | (uint32_t)__shfl_xor((int)best, off);
+        best = o > best ? o : best;
+    }
+    if (lane == 0) {
+        int b = 0;
+        if (best != 0ull) {
+            int row = (int)key_row(best);
+            if (a.perm_mod > 0) row = perm_row(row, a.perm_mul, a.perm_mod, a.perm_inv);
+            b = min(row >> a.shift, ORDER_BUCKETS - 1);
+        }
+        a.key[q] = b;
+        atomicAdd(&a.hist[b], 1u);
+    }
+}
+
+// slot of finalize (block b = slot / 4 runs on XCD b % 8) for position p of the sorted order: consecutive chunks of four
+// positions go to blocks of ONE XCD (the bijective form of cdna_hip_programming.md T1)
+__device__ __forceinline__ int order_slot(int p, int nblk) {
+    const int c = p >> 2, w = p & 3;
+    const int qn = nblk >> 3, rn = nblk & 7;
+    int xcd, j;
+    if (c < rn * (qn + 1)) { xcd = c / (qn + 1); j = c - xcd * (qn + 1); }
+    else { const int c2 = c - rn * (qn + 1); xcd = rn + c2 / max(qn, 1); j = c2 - (xcd - rn) * max(qn, 1); }
+    return (j * 8 + xcd) * 4 + w;
+}
+
+__global__ __launch_bounds__(1024) void order_scatter_kernel(OrderArgs a) {
+    __shared__ unsigned int offs[ORDER_BUCKETS];
+    __shared__ unsigned int wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int nblk = (a.nq + 3) >> 2;
+    for (int i = t; i < 4 * nblk; i += 1024) a.order[i] = -1;
+    // exclusive prefix over the buckets (one bucket per thread)
+    const unsigned int h = a.hist[t];
+    a.hist[t] = 0u;   // (ready for the next search)
+    unsigned int v = h;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int o = (unsigned int)__shfl_up((int)v, off);
+        if (lane >= off) v += o;
+    }
+    if (lane == 63) wsum[wave] = v;
+    __syncthreads();
+    unsigned int base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    offs[t] = base + v - h;
+    __syncthreads();
+    for (int q = t; q < a.nq; q += 1024) {
+        const int p = (int)atomicAdd(&offs[a.key[q]], 1u);
+        a.order[order_slot(p, nblk)] = q;
+    }
 }
 
 // ---- row-sharded merge: G gathered best-first lists per query -> global top-k + reweight ---------

@@ -84,6 +84,17 @@ int load_rccl() {
                                      hipGetErrorString(e_), __FILE__, __LINE__);                              \
     } while (0)
 
+// inside icd_group_search: an error between ncclGroupStart and ncclGroupEnd must not leave the RCCL group open (every later
+// collective of the process would be queued into it), and the message names the rank: on N ranks the first question is which
+#define NCCL_TRY_G(g, open, expr)                                                                             \
+    do {                                                                                                      \
+        ncclResult_t r_ = (expr);                                                                             \
+        if (r_ != ncclSuccess) {                                                                              \
+            if (open) g_rccl.GroupEnd();                                                                      \
+            return icd_internal_fail(ICD_ERR_HIP, "rank %d of %d: %s: %s (%s:%d)", (g)->rank, (g)->world, #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
+        }                                                                                                     \
+    } while (0)
+
 // contiguous split of n items over `world` ranks: the first n % world ranks get one more (rag_project_icd10_amd/sharded.py
 // shard_bounds - the two must agree)
 void shard_bounds(int64_t n, int world, int rank, int64_t *lo, int64_t *hi) {
@@ -138,14 +149,15 @@ int icd_group_unique_id(uint8_t *out_id) {
     return ICD_OK;
 }
 
-int icd_group_create(icd_index *local, const uint8_t *id, int32_t rank, int32_t world, int32_t mode, int32_t max_nq,
-                     int32_t max_k, icd_group **out) {
+// Everything of a group that can fail on ONE rank alone - argument checks, the buffers, opening librccl - without the
+// communicator: a host lets its ranks agree on the outcome (any side channel) BEFORE icd_group_connect, which is collective.
+int icd_group_prepare(icd_index *local, int32_t with_comm, int32_t rank, int32_t world, int32_t mode, int32_t max_nq,
+                      int32_t max_k, icd_group **out) {
     if (!out) return icd_internal_fail(ICD_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (!local) return icd_internal_fail(ICD_ERR_INVALID, "local index is NULL");
     if (world < 1 || rank < 0 || rank >= world) return icd_internal_fail(ICD_ERR_INVALID, "rank %d of %d", rank, world);
     if (mode != ICD_GROUP_ROW_SHARD && mode != ICD_GROUP_QUERY_SHARD) return icd_internal_fail(ICD_ERR_INVALID, "mode=%d", mode);
-    if (world > 1 && !id) return icd_internal_fail(ICD_ERR_INVALID, "a group of %d ranks needs the unique id of rank 0 (icd_group_unique_id)", world);
     icd_stats st;
     int rc = icd_index_stats(local, &st);
     if (rc) return rc;
@@ -156,7 +168,7 @@ int icd_group_create(icd_index *local, const uint8_t *id, int32_t rank, int32_t 
     icd_group *g = new (std::nothrow) icd_group();
     if (!g) return icd_internal_fail(ICD_ERR_NOMEM, "host allocation failed");
     g->idx = local; g->device = st.device; g->rank = rank; g->world = world; g->mode = mode; g->max_nq = max_nq; g->max_k = max_k; g->dim = st.dim; g->idx_max_nq = st.max_nq;
-    g->use_comm = world > 1 || id != nullptr;
+    g->use_comm = world > 1 || with_comm != 0;
 #define GR_TRY(expr)                                                                                          \
     do {                                                                                                      \
         hipError_t e_ = (expr);                                                                               \
@@ -186,14 +198,41 @@ int icd_group_create(icd_index *local, const uint8_t *id, int32_t rank, int32_t 
     if (g->use_comm) {
         rc = load_rccl();
         if (rc) { free_group(g); return rc; }
-        ncclUniqueId uid;
-        memcpy(&uid, id, sizeof uid);
-        ncclResult_t r = g_rccl.CommInitRank(&g->comm, world, uid, rank);
-        if (r != ncclSuccess) {
-            g->comm = nullptr;
-            free_group(g);
-            return icd_internal_fail(ICD_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", rank, world, g_rccl.GetErrorString(r));
-        }
+    }
+    *out = g;
+    return ICD_OK;
+}
+
+// COLLECTIVE over the group's ranks (ncclCommInitRank): call it on every rank or on none. A group prepared without a
+// communicator (one rank, with_comm = 0) needs no connect. On failure the group stays prepared (destroy it).
+int icd_group_connect(icd_group *g, const uint8_t *id) {
+    if (!valid(g)) return icd_internal_fail(ICD_ERR_STATE, "invalid group handle");
+    if (!g->use_comm) return ICD_OK;
+    if (g->comm) return icd_internal_fail(ICD_ERR_STATE, "rank %d of %d: the group is connected already", g->rank, g->world);
+    if (!id) return icd_internal_fail(ICD_ERR_INVALID, "rank %d of %d: the unique id of rank 0 is NULL (icd_group_unique_id)", g->rank, g->world);
+    HIPG_TRY(hipSetDevice(g->device));
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    ncclResult_t r = g_rccl.CommInitRank(&g->comm, g->world, uid, g->rank);
+    if (r != ncclSuccess) {
+        g->comm = nullptr;
+        return icd_internal_fail(ICD_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", g->rank, g->world, g_rccl.GetErrorString(r));
+    }
+    return ICD_OK;
+}
+
+// prepare + connect in one call: for a host whose ranks need no agreement step (a failure of one rank's local part leaves
+// the others waiting in ncclCommInitRank: hosts that can fail locally use the two calls above)
+int icd_group_create(icd_index *local, const uint8_t *id, int32_t rank, int32_t world, int32_t mode, int32_t max_nq,
+                     int32_t max_k, icd_group **out) {
+    if (out) *out = nullptr;
+    if (world > 1 && !id) return icd_internal_fail(ICD_ERR_INVALID, "a group of %d ranks needs the unique id of rank 0 (icd_group_unique_id)", world);
+    icd_group *g = nullptr;
+    int rc = icd_group_prepare(local, id != nullptr, rank, world, mode, max_nq, max_k, &g);
+    if (rc) return rc;
+    if (id) {
+        rc = icd_group_connect(g, id);
+        if (rc) { free_group(g); return rc; }
     }
     *out = g;
     return ICD_OK;
@@ -214,6 +253,7 @@ int icd_group_search(icd_group *g, const float *queries, int64_t nq, int32_t k, 
     if (nq < 0 || nq > g->max_nq || k <= 0 || k > g->max_k) return icd_internal_fail(ICD_ERR_INVALID, "nq=%lld k=%d (group max %d / %d)", (long long)nq, k, g->max_nq, g->max_k);
     if (nq == 0) return ICD_OK;
     if (!queries) return icd_internal_fail(ICD_ERR_INVALID, "queries is NULL");
+    if (g->use_comm && !g->comm) return icd_internal_fail(ICD_ERR_STATE, "rank %d of %d: the group was prepared but never connected (icd_group_connect)", g->rank, g->world);
     HIPG_TRY(hipSetDevice(g->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc;
@@ -226,11 +266,11 @@ int icd_group_search(icd_group *g, const float *queries, int64_t nq, int32_t k, 
         const float *ms = g->send_s; const long long *mi = g->send_i; const int *ml = g->send_l;
         if (g->use_comm) {
             const size_t cnt = (size_t)nq * k;
-            NCCL_TRY(g_rccl.GroupStart());   // the three arrays travel as ONE fused collective launch
-            NCCL_TRY(g_rccl.AllGather(g->send_s, g->recv_s, cnt, ncclFloat32, g->comm, s));
-            NCCL_TRY(g_rccl.AllGather(g->send_i, g->recv_i, cnt, ncclInt64, g->comm, s));
-            NCCL_TRY(g_rccl.AllGather(g->send_l, g->recv_l, cnt, ncclInt32, g->comm, s));
-            NCCL_TRY(g_rccl.GroupEnd());
+            NCCL_TRY_G(g, false, g_rccl.GroupStart());   // the three arrays travel as ONE fused collective launch
+            NCCL_TRY_G(g, true, g_rccl.AllGather(g->send_s, g->recv_s, cnt, ncclFloat32, g->comm, s));
+            NCCL_TRY_G(g, true, g_rccl.AllGather(g->send_i, g->recv_i, cnt, ncclInt64, g->comm, s));
+            NCCL_TRY_G(g, true, g_rccl.AllGather(g->send_l, g->recv_l, cnt, ncclInt32, g->comm, s));
+            NCCL_TRY_G(g, false, g_rccl.GroupEnd());
             ms = g->recv_s; mi = g->recv_i; ml = g->recv_l;   // [world][nq][k]
         }
         return icd_merge_topk(g->device, ms, reinterpret_cast<const int64_t *>(mi), ml, g->world, nq, k, out_adj, out_raw, out_ids, out_levels, stream);
@@ -265,12 +305,12 @@ int icd_group_search(icd_group *g, const float *queries, int64_t nq, int32_t k, 
     long long *r_ids = reinterpret_cast<long long *>(rb + per * g->world * 8);
     float *r_raw = reinterpret_cast<float *>(rb + per * g->world * 16);
     int *r_lv = reinterpret_cast<int *>(rb + per * g->world * 20);
-    NCCL_TRY(g_rccl.GroupStart());
-    NCCL_TRY(g_rccl.AllGather(s_adj, r_adj, per, ncclFloat64, g->comm, s));
-    NCCL_TRY(g_rccl.AllGather(s_ids, r_ids, per, ncclInt64, g->comm, s));
-    NCCL_TRY(g_rccl.AllGather(s_raw, r_raw, per, ncclFloat32, g->comm, s));
-    NCCL_TRY(g_rccl.AllGather(s_lv, r_lv, per, ncclInt32, g->comm, s));
-    NCCL_TRY(g_rccl.GroupEnd());
+    NCCL_TRY_G(g, false, g_rccl.GroupStart());
+    NCCL_TRY_G(g, true, g_rccl.AllGather(s_adj, r_adj, per, ncclFloat64, g->comm, s));
+    NCCL_TRY_G(g, true, g_rccl.AllGather(s_ids, r_ids, per, ncclInt64, g->comm, s));
+    NCCL_TRY_G(g, true, g_rccl.AllGather(s_raw, r_raw, per, ncclFloat32, g->comm, s));
+    NCCL_TRY_G(g, true, g_rccl.AllGather(s_lv, r_lv, per, ncclInt32, g->comm, s));
+    NCCL_TRY_G(g, false, g_rccl.GroupEnd());
     for (int r = 0; r < g->world; ++r) {   // padded slices -> the contiguous [nq][k] outputs
         int64_t a, b;
         shard_bounds(nq, g->world, r, &a, &b);

@@ -14,7 +14,10 @@
 
 #include "../../include/icd_search.h"
 #include "coarse_flat_kernel.hpp"
-#ifdef ICD_ABLATE
+#if defined(ICD_ABLATE) && !defined(ICD_FV_LIST)
+#define ICD_ABLATE_EXPERIMENTS 1
+#endif
+#ifdef ICD_ABLATE_EXPERIMENTS
 #include "../../experiments/r02_rg_kernel/coarse_rg_kernel.hpp"   // (A/B builds only: the row-group experiment)
 #include "../../experiments/r02_w8_kernel/coarse_w8_kernel.hpp"   // (A/B builds only: eight waves, two per SIMD)
 #include "../../experiments/r02_g16_kernel/coarse_g16_kernel.hpp" // (A/B builds only: the flat geometry on 16x16x32)
@@ -33,6 +36,7 @@ namespace {
 thread_local std::string g_err = "";
 bool g_permute = true;   // test switch (icd_debug_set_permute): row order of the fp16 corpus copy
 bool g_probe = true;     // test switch (icd_debug_set_create_probe): the corpus-shape probe of icd_index_create
+bool g_family_order = true;   // test switch (icd_debug_set_family_order): the wide-window finalize visits the queries in family order
 
 int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -134,6 +138,7 @@ struct icd_index {
     int *h_nflag_dev = nullptr;                      // its device-side address
     hipEvent_t ev_nflag = nullptr;                   // recorded behind that copy: icd_index_stats waits for it and nothing else
     unsigned int *scratch_u32 = nullptr;  // [0]=rmax bits, [1]=any_bad
+    int *order = nullptr, *order_key = nullptr; unsigned int *order_hist = nullptr;   // wide-window finalize in family order (finalize.hpp, order_*_kernel)
     // output staging (used when the caller's buffers are host memory)
     float *o_scores = nullptr; long long *o_ids = nullptr;
     double *o_adj = nullptr; float *o_adj_raw = nullptr; long long *o_adj_ids = nullptr; int *o_adj_lv = nullptr;
@@ -145,6 +150,7 @@ struct icd_index {
     bool wide_mode = false;        // plan the first pass with PASS2_CHUNKS lists per query
     int wide_runs = 0;             // large searches since wide_mode was entered (every WIDE_REPROBE-th runs narrow again)
     bool last_narrow_large = false; // the last search was a large batch with the narrow plan and the second pass behind it
+    int64_t last_narrow_nq = 0;     // ... and its size: the flagged counters read at the NEXT search are fractions of THIS batch
     // The second pass costs a search that flags nothing two launches that read a counter and leave (~9 us per 10 000-query
     // step). They are armed while nothing is known about the corpus (the first searches of an index) and whenever a recent
     // search flagged more queries than the streaming kernel takes cheaply; after PASS2_DISARM_AFTER consecutive searches
@@ -191,6 +197,7 @@ void free_all(icd_index *x) {
     hipFree(x->qnorm); hipFree(x->qexp); hipFree(x->qbad); hipFree(x->shared_thr); hipFree(x->partc_s); hipFree(x->partc_r); hipFree(x->partc_b); hipFree(x->partx_s);
     hipFree(x->part2_s); hipFree(x->part2_r); hipFree(x->part2_b);
     hipFree(x->partx_r); hipFree(x->lists_s); hipFree(x->lists_r); hipFree(x->nflag); hipFree(x->flagged); hipFree(x->scratch_u32);
+    hipFree(x->order); hipFree(x->order_key); hipFree(x->order_hist);
     hipFree(x->o_scores); hipFree(x->o_ids); hipFree(x->o_adj); hipFree(x->o_adj_raw);
     hipFree(x->o_adj_ids); hipFree(x->o_adj_lv);
     hipFree(x->dbg);
@@ -249,7 +256,7 @@ int launch_coarse_flat(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream
     return ICD_OK;
 }
 
-#ifdef ICD_ABLATE
+#ifdef ICD_ABLATE_EXPERIMENTS
 template <int D, int KP = CO_KP, int VAR = 0>
 int launch_coarse_rg(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream_t s) {
     auto kern = coarse_rg_kernel<D, KP, VAR>;
@@ -577,7 +584,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     }
     if (x->last_narrow_large && counters_in) {
         const int f0 = x->h_nflag[0], f2 = x->h_nflag[2];
-        const long long n_prev = x->last_nq;
+        const long long n_prev = x->last_narrow_nq;   // (x->last_nq already holds the CURRENT batch's size: ADVICE r3)
         if (n_prev > 0) {
             if (!x->wide_mode && (long long)f0 * 4 > n_prev && (long long)f2 * 2 < f0) { x->wide_mode = true; x->wide_runs = 0; }
             else if (x->wide_mode && (long long)f0 * 20 <= n_prev) x->wide_mode = false;   // (a narrow re-probe that certified 95 %)
@@ -611,11 +618,13 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         // of the whole corpus or the list's bound lands inside the window: fewer tiles for larger k (measured at
         // k = 48 with 8 tiles: 1.6 % of the queries uncertified).
         a.boot_tiles = std::max(1, std::min(CO_BOOT_TILES, 96 / std::max(1, k)));
+        a.sparse_from = CO_SPARSE_FROM;
         int U = plan.U;
 #ifdef ICD_ABLATE
         if (const char *e = getenv("ICD_FLAT_U")) U = std::max(U, atoi(e));   // A/B: tiles per work-group
         if (const char *e = getenv("ICD_FLAT_LIST")) a.list_tiles = std::max(1, atoi(e));   // A/B: tiles per list
         if (const char *e = getenv("ICD_FLAT_BOOT")) a.boot_tiles = std::max(0, atoi(e));   // A/B: bootstrap tiles
+        if (const char *e = getenv("ICD_FLAT_SPARSE")) a.sparse_from = std::max(0, atoi(e));   // A/B: first tile of a list with the group pre-filter
 #endif
         if (x->chunks_override > 0 || wide_now) {   // test hook / wide mode: about `chunks` lists per query
             const int chunks = x->chunks_override > 0 ? x->chunks_override : PASS2_CHUNKS;
@@ -706,7 +715,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         else
 #endif
         if (x->dim == 1024) rc = launch_coarse_flat<1024, (CF_PRODUCT_VAR & (3 | 16 | 2048))>(x, a, nwg, s);
-#ifdef ICD_ABLATE
+#ifdef ICD_ABLATE_EXPERIMENTS
         else if (const char *wv = getenv("ICD_W8_VAR")) {   // A/B builds: the eight-wave kernel
             const int v = atoi(wv);
             if (v == 0 && !wide_lists) rc = launch_coarse_w8<768>(x, a, nwg, s);
@@ -734,13 +743,19 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             else if (v == 100) rc = launch_coarse_rg<768, CO_KP, 100>(x, a, nwg, s);
             else return fail(ICD_ERR_INVALID, "ICD_RG_VAR=%d is not built", v);
         }
+#endif
+#ifdef ICD_ABLATE
         else if (const char *fv = getenv("ICD_FLAT_VAR")) {   // A/B builds: stage / select variants of the flat kernel
             const int v = atoi(fv);
             if (false) {}
 #define ICD_FV_CASE(V) else if (v == V) rc = launch_coarse_flat<768, V>(x, a, nwg, s);
+#ifdef ICD_FV_LIST
+            ICD_FV_LIST
+#else
             ICD_FV_CASE(0) ICD_FV_CASE(139) ICD_FV_CASE(143) ICD_FV_CASE(155) ICD_FV_CASE(171) ICD_FV_CASE(187) ICD_FV_CASE(2187) ICD_FV_CASE(2203)
             ICD_FV_CASE(2235) ICD_FV_CASE(1163) ICD_FV_CASE(4235) ICD_FV_CASE(4251)
             ICD_FV_CASE(34971) ICD_FV_CASE(35995) ICD_FV_CASE(39067) ICD_FV_CASE(100507) ICD_FV_CASE(104603) ICD_FV_CASE(32923) ICD_FV_CASE(32955) ICD_FV_CASE(34843) ICD_FV_CASE(166043) ICD_FV_CASE(297115) ICD_FV_CASE(559259) ICD_FV_CASE(1083547)
+#endif
 #undef ICD_FV_CASE
             else return fail(ICD_ERR_INVALID, "ICD_FLAT_VAR=%d is not built", v);
         }
@@ -760,8 +775,22 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         // every query at once, and the retry below has nothing to add.
         const bool wide_fin = wide_now && k <= 32 && pc * g.KP >= 128;
         if (wide_fin) g.wide_window = 1;
+        if (wide_fin && g_family_order && nq >= 1024) {
+            // every query's window is its family (the corpus is in code order): visit the queries family by family, XCD by XCD
+            OrderArgs o{};
+            o.part_scores = g.part_scores; o.part_rows = g.part_rows; o.P = g.P; o.KP = g.KP; o.nq = nq;
+            o.perm_mul = g.perm_mul; o.perm_mod = g.perm_mod; o.perm_inv = g.perm_inv;
+            o.shift = 6;
+            while (((long long)x->n >> o.shift) >= ORDER_BUCKETS) ++o.shift;
+            o.key = x->order_key; o.hist = x->order_hist; o.order = x->order;
+            hipLaunchKernelGGL(order_keys_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, o);
+            hipLaunchKernelGGL(order_scatter_kernel, dim3(1), dim3(1024), 0, s, o);
+            HIP_TRY(hipGetLastError());
+            g.qlist = x->order; g.lists_by_query = 1; g.nq = 4 * ((nq + 3) / 4);
+        }
         int rc = wide_fin ? launch_finalize_t<true, false, 4>(x, g, s) : launch_finalize<true>(x, g, s);
         if (rc) return rc;
+        g.qlist = nullptr; g.lists_by_query = 0; g.nq = nq;
         // Second chance before the exact re-search. A query fails the first pass when more candidates lie within 2 eps of
         // its k-th best than the window sized for k holds (32 or 64 for k <= 32): a family of near-identical rows, the
         // shape ICD sibling codes have. Its lists may hold 128-512 candidates: the same kernel with the widest window
@@ -803,6 +832,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             x->last_p2 = p2; x->last_p2_word = w_in;
         }
         x->last_narrow_large = x->adapt_enabled && large && p2 > 0 && !wide_now && x->chunks_override == 0;
+        if (x->last_narrow_large) x->last_narrow_nq = nq;
         x->p2_eval_pending = x->pass2_enabled && pc * kp_c < PASS2_BELOW;   // (a search the second pass applies to, armed or not)
     }
     rec(x, 3, s);
@@ -966,6 +996,10 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     CR_TRY(wsalloc(&x->dbg, (size_t)8192 * 16));
     CR_TRY(hipMemset(x->dbg, 0, (size_t)8192 * 16 * 8));
     CR_TRY(wsalloc(&x->flagged, (size_t)3 * x->max_nq_pad));
+    CR_TRY(wsalloc(&x->order, (size_t)x->max_nq_pad + 8));
+    CR_TRY(wsalloc(&x->order_key, (size_t)x->max_nq_pad));
+    CR_TRY(wsalloc(&x->order_hist, (size_t)ORDER_BUCKETS));
+    CR_TRY(hipMemset(x->order_hist, 0, ORDER_BUCKETS * sizeof(unsigned int)));
     const size_t no = (size_t)max_nq * max_k;
     CR_TRY(wsalloc(&x->o_scores, no)); CR_TRY(wsalloc(&x->o_ids, no)); CR_TRY(wsalloc(&x->o_adj, no));
     CR_TRY(wsalloc(&x->o_adj_raw, no)); CR_TRY(wsalloc(&x->o_adj_ids, no)); CR_TRY(wsalloc(&x->o_adj_lv, no));
@@ -1216,6 +1250,11 @@ int icd_debug_set_permute(int32_t enabled) {
 
 int icd_debug_set_create_probe(int32_t enabled) {
     g_probe = enabled != 0;
+    return ICD_OK;
+}
+
+int icd_debug_set_family_order(int32_t enabled) {
+    g_family_order = enabled != 0;
     return ICD_OK;
 }
 

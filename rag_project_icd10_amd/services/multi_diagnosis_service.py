@@ -11,7 +11,9 @@ request are embedded in ONE encoder batch and searched in ONE search_batch call.
 """
 from __future__ import annotations
 
+import gc
 import logging
+import threading
 from typing import Any, Dict, List
 
 import numpy as np
@@ -23,6 +25,33 @@ from .multidimensional_confidence_service import MultiDimensionalConfidenceServi
 
 logger = logging.getLogger(__name__)
 
+
+
+# The collector is a PROCESS-WIDE switch: under a threaded server two requests must not toggle it for each other (one
+# re-enabling it in the middle of the other's build, or leaving it off for good). A lock-protected depth counter: the
+# first request in switches it off (if it was on), the last one out switches it back on.
+_gc_lock = threading.Lock()
+_gc_depth = 0
+_gc_was_on = False
+
+
+class _gc_paused:
+    def __enter__(self):
+        global _gc_depth, _gc_was_on
+        with _gc_lock:
+            if _gc_depth == 0:
+                _gc_was_on = gc.isenabled()
+                if _gc_was_on:
+                    gc.disable()
+            _gc_depth += 1
+
+    def __exit__(self, *exc):
+        global _gc_depth
+        with _gc_lock:
+            _gc_depth -= 1
+            if _gc_depth == 0 and _gc_was_on:
+                gc.enable()
+        return False
 
 class MultiDiagnosisService:
     def __init__(self, embedding_service, milvus_service, ner_service=None):
@@ -130,14 +159,9 @@ class MultiDiagnosisService:
             conf = [{"semantic_coherence": coh[q], "model_uncertainty": stats[q][4], "prediction_variance": stats[q][5]}
                     for q in range(len(diagnoses))]
         out = []
-        import gc
-        gc_was_on = gc.isenabled()
-        gc.disable()   # (tens of thousands of acyclic objects are born here: the collector's generation-0 passes over them are pure cost)
-        try:
+        # (tens of thousands of acyclic objects are born here: the collector's generation-0 passes over them are pure cost)
+        with _gc_paused():
             self._build_matches(out, diagnoses, kk, h_ord, h_enh, h_adj, h_raw, h_boost, h_ids, h_vs, h_hb, recs, sc, qps, conf, trusted_factors_row)
-        finally:
-            if gc_was_on:
-                gc.enable()
         return out
 
     def _build_matches(self, out, diagnoses, kk, h_ord, h_enh, h_adj, h_raw, h_boost, h_ids, h_vs, h_hb, recs, sc, qps, conf, trusted_factors_row):

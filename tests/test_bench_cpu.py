@@ -32,9 +32,13 @@ def _worker_body(rank, world, port, q):
     ctx = bench.Ctx()
     assert ctx.world == world and ctx.dist.get_world_size() == world
     args = argparse.Namespace(steps=2, warmup=1, settle_ms=0.0, repeats=1, profile_every=1, nq=40, n=900, k=5, mode="auto", rows_per_gpu=700, rowshard_queries=50,
-                              rowshard_slice=32, rowshard_steps=2, no_cpu_baseline=True, no_extras=True)
+                              rowshard_slice=32, rowshard_steps=2, no_cpu_baseline=True, no_extras=True, no_family=True,
+                              config3_queries=70, config3_steps=1)
     rs = bench.run_rowshard(ctx, args, index_factory=eng.index_factory, sharded_factory=eng.sharded_factory)
     rp = bench.run_replicated(ctx, args, index_factory=eng.index_factory)
+    c3 = bench.run_config3(ctx, args, index_factory=eng.index_factory)
+    if rp is not None:
+        rp["config3"] = c3
     q.put((rank, json.dumps(rs) if rs else None, json.dumps(rp) if rp else None))
     ctx.dist.barrier()
     ctx.dist.destroy_process_group()
@@ -60,7 +64,15 @@ def test_bench_two_ranks_on_cpu():
     assert rs["scaling"] == "weak" and rs["metric"] == "queries_per_sec" and rs["value"] > 0 and "roofline" in rs
     assert "configs[4]" in rs["config"]["workload"]
     assert rp["n_gpus"] == 2 and rp["ids_exact"] and rp["recall_at_10"] == 1.0 and rp["adjusted_scores_exact"]
-    assert rp["parity_checked_queries"] == 20 and "configs[3]" in rp["config"]["workload"]   # (every 2nd query at N = 2)
+    assert rp["parity_checked_queries"] == 20   # (every 2nd query at N = 2)
+    # the N > 1 `value` is the HEADLINE workload replicated and says so; configs[3] is its own object at its own size
+    assert "configs[1] replicated on every GPU" in rp["config"]["workload"] and rp["config"]["nq_per_gpu"] == 40
+    c3 = rp["config3"]
+    assert c3["config"]["workload"].startswith("BASELINE configs[3]") and c3["config"]["nq_per_gpu"] == 70 and c3["config"]["queries_total"] == 140
+    assert c3["config"]["slice"] == 32 and c3["ids_exact"] and c3["adjusted_scores_exact"] and c3["parity_checked_queries"] == 70
+    assert abs(c3["value"] - 2 * 70 * c3["steps"] / (c3["ms_per_step"] * c3["steps"] / 1e3)) / c3["value"] < 1e-6
+    # the row-shard sample covers EVERY slice of the pass, the short last one included (50 queries in slices of 32: 32 + 18)
+    assert rs["sample_slices"] == 2 and rs["sample_queries"] == 16
     assert abs(rp["value"] - 2 * 40 * 2 / (rp["ms_per_step"] * 2 / 1e3)) / rp["value"] < 1e-6
     for line in (rs, rp):
         for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -70,7 +82,8 @@ def test_bench_two_ranks_on_cpu():
 
 # ---- `python bench.py --gpus N` as the driver runs it: the parent starts the ranks itself -------------------------------
 SMALL = ["--steps", "2", "--warmup", "1", "--settle-ms", "0", "--repeats", "1", "--nq", "40", "--n", "900", "--k", "5",
-         "--rows-per-gpu", "700", "--rowshard-queries", "50", "--rowshard-slice", "32", "--rowshard-steps", "2", "--no-cpu-baseline"]
+         "--rows-per-gpu", "700", "--rowshard-queries", "50", "--rowshard-slice", "32", "--rowshard-steps", "2", "--no-cpu-baseline",
+         "--config3-queries", "70", "--config3-steps", "1", "--family-families", "6", "--family-rows", "20"]
 
 
 def _run_bench(extra_args, extra_env=None, timeout=420):
@@ -91,12 +104,15 @@ def test_bench_gpus_2_starts_two_ranks_itself():
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, p.stdout     # ONE JSON line on stdout
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["config"]["collective_ranks"] == 2 and "configs[3]" in line["config"]["workload"]
+    assert line["n_gpus"] == 2 and line["config"]["collective_ranks"] == 2 and "configs[1] replicated on every GPU" in line["config"]["workload"]
     assert line["ids_exact"] and line["adjusted_scores_exact"]
+    c3 = line["config3"]
+    assert c3["n_gpus"] == 2 and c3["config"]["workload"].startswith("BASELINE configs[3]") and c3["config"]["nq_per_gpu"] == 70
+    assert c3["ids_exact"] and c3["adjusted_scores_exact"] and c3["value"] > 0
     rs = line["rowshard"]
     assert rs["n_gpus"] == 2 and rs["config"]["collective_ranks"] == 2 and rs["config"]["corpus_rows_total"] == 1400
     assert rs["ids_exact_on_sample"] and rs["raw_scores_exact_on_sample"] and rs["adjusted_scores_exact_on_sample"]
-    assert "oracle" in rs["sample_checked_against"]
+    assert "oracle" in rs["sample_checked_against"] and rs["sample_slices"] == 2 and rs["sample_queries"] == 16
 
 
 def test_bench_gpus_1_is_a_single_process_line_with_the_extras():
@@ -107,14 +123,26 @@ def test_bench_gpus_1_is_a_single_process_line_with_the_extras():
     assert "configs[1]" in line["config"]["workload"]
     ex = line["extra"]
     assert ex["windows"]["min"] <= ex["windows"]["median"] <= ex["windows"]["max"]
-    for key, rows in (("real_size", 40474), ("clustered", 900), ("exact_mode", 900)):
+    for key, rows in (("real_size", 40474), ("clustered", 900), ("exact_mode", 900), ("k20", 900), ("family", 120)):
         assert ex[key]["corpus_rows"] == rows and ex[key]["ids_exact"] and ex[key]["ms_per_step"] > 0 and "fallback_queries" in ex[key]
+        assert "last_second_pass" in ex[key]
+    assert ex["k20"]["top_k"] == 20 and ex["family"]["first_batch"]["ms"] > 0 and "config3" not in line
 
 
 def test_bench_child_failure_fails_the_parent():
     p = _run_bench(["--gpus", "2", "--no-rowshard"], {"ICD_BENCH_TEST_FAIL_RANK": "1"})
     assert p.returncode != 0
     assert not [l for l in p.stdout.splitlines() if l.strip().startswith("{")]   # no result line from a failed run
+
+
+def test_bench_hung_rank_fails_the_parent_within_the_limit():
+    """a rank that never returns (stuck in a collective the others left, a hung device): the parent kills the child's process
+    group at --rank-timeout and exits non-zero instead of waiting for the caller's own limit"""
+    import time
+    t0 = time.time()
+    p = _run_bench(["--gpus", "2", "--no-rowshard", "--no-config3", "--rank-timeout", "25"], {"ICD_BENCH_TEST_HANG_RANK": "1"}, timeout=200)
+    assert p.returncode == 124 and "rank-timeout" in p.stderr and time.time() - t0 < 150
+    assert not [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
 
 
 def test_bench_refuses_more_ranks_than_gpus():

@@ -89,3 +89,86 @@ def test_two_ranks_match_single_process(mode):
     results = [q.get(timeout=10) for _ in range(2)]
     assert all(p.exitcode == 0 for p in procs)
     assert sorted(results) == [(0, True), (1, True)]
+
+
+# ---- the ranks agree on the engine: all native (C-ABI group) or all torch.distributed, never a mix --------------------------
+class _FakeGroup:
+    """stands in for _native.IcdGroup (the C-ABI engine needs a GPU): prepared without a communicator, connect() is the
+    collective step, search() answers through the oracle index and says so"""
+    log = []
+
+    def __init__(self, index, rank, fail_connect=False):
+        self.index, self.rank, self.connected, self.closed, self.fail_connect = index, rank, False, False, fail_connect
+
+    def unique_id(self):
+        return bytes(range(1, 129))
+
+    def connect(self, uid):
+        assert uid == bytes(range(1, 129))          # rank 0's id reached this rank through the process group
+        if self.fail_connect:
+            raise RuntimeError("forced failure of icd_group_connect")
+        self.connected = True
+
+    def search(self, queries, k, gather=True):
+        raise AssertionError("the test never searches through the fake group")
+
+    def close(self):
+        self.closed = True
+
+
+def _agree_worker(rank, world, port, case, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    import bench_cpu_engine as eng
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    if case == "prepare_fails_on_rank_1":
+        os.environ["ICD_SHARDED_TEST_FAIL_PREPARE"] = "1"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, dim, nq, k = 803, 64, 19, 5
+        corpus, levels, queries = unit_rows(n, dim, 11), icd_levels(n, 12), unit_rows(nq, dim, 13)
+        fs, fi = orc.flat_ip_topk(corpus, queries, k)
+        want = orc.reweight(fs, fi, levels)
+        lo, hi = shard_bounds(n, world, rank)
+        index = eng.OracleIndex(corpus[lo:hi], levels[lo:hi], id_base=lo)
+        index.device = 0
+        made = []
+
+        def factory():
+            g = _FakeGroup(index, rank, fail_connect=(case == "connect_fails_on_rank_0" and rank == 0))
+            made.append(g)
+            return g
+
+        sh = ShardedSearch.from_index(index, ROW_SHARD, native=True, native_factory=factory)
+        sh.merge_fn = eng.merge_cpu
+        if case == "all_fine":
+            ok = sh.native_group is not None and sh.native_group.connected and not sh.native_group.closed
+        else:
+            # EVERY rank is on the torch engine: no group left open, none connected on the ranks that could have
+            ok = sh.native_group is None and all(g.closed for g in made)
+            if case == "prepare_fails_on_rank_1":
+                ok = ok and not any(g.connected for g in made) and len(made) == (1 if rank == 0 else 0)
+            adj, raw, ids, lv = sh.search_reweighted(torch.from_numpy(queries), k)   # ... and its results are exact
+            ok = ok and np.array_equal(ids.numpy(), want[2]) and adj.numpy().tobytes() == want[0].tobytes() \
+                and raw.numpy().tobytes() == want[1].tobytes()
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["prepare_fails_on_rank_1", "connect_fails_on_rank_0", "all_fine"])
+def test_ranks_agree_on_the_engine(case):
+    """ShardedSearch.from_index: a rank whose icd_group_prepare fails must not leave the others waiting in the collective
+    ncclCommInitRank, nor run another engine than they do: one all_reduce(MIN) decides for all of them"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29100 + (os.getpid() % 300) + ["prepare_fails_on_rank_1", "connect_fails_on_rank_0", "all_fine"].index(case)
+    procs = [ctx.Process(target=_agree_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+    assert all(p.exitcode == 0 for p in procs)   # (nobody hung, nobody died)
+    assert sorted(q.get(timeout=10) for _ in range(2)) == [(0, True), (1, True)]
