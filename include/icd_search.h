@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define ICD_ABI_VERSION 4   /* 4: icd_debug_set_family_order, icd_group_prepare / icd_group_connect (round 4). 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
+#define ICD_ABI_VERSION 4   /* 4: icd_debug_set_family_order, icd_debug_set_center, icd_stats.centered / mean_share appended, icd_group_prepare / icd_group_connect (round 4). 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
 #define ICD_MAX_K 128
 
 typedef struct icd_index icd_index;
@@ -100,6 +100,10 @@ typedef struct icd_stats {
                                    launches (few flagged queries: ~0.05 ms); 0: they were left out after a long run of
                                    searches with nothing flagged, and the fp32-MFMA kernel takes any count (~0.4 ms, once:
                                    the run restarts and the required length doubles). Results are exact either way. */
+    int32_t centered;           /* 1: the fp16 image of the corpus holds the rows minus their column mean (the rows share a large
+                                   common component, as sentence embeddings do: the coarse pass ranks by q.(c - mu), the same
+                                   order as q.c, with an fp16 error relative to the centred rows). Results are exact either way. */
+    float   mean_share;         /* |mu|^2 / mean |row|^2: the mean pairwise cosine of unit rows (centred when >= 0.25) */
 } icd_stats;
 
 /* per-kernel device time of the most recent search, measured with hipEvents on the search stream.
@@ -279,10 +283,15 @@ int icd_debug_set_permute(int32_t enabled);
  * identical either way, and later searches keep deciding from their own counters. */
 int icd_debug_set_create_probe(int32_t enabled);
 
-/* Test switch, process-wide, read by every search (default 1): 0 keeps the wide-window finalize of a family-shaped corpus
- * (icd_stats.wide_mode) in batch order instead of visiting the queries family by family, XCD by XCD (finalize.hpp,
- * order_keys_kernel / order_scatter_kernel). A performance decision only: results are identical either way. */
+/* Test switch, process-wide, read by every search (default 3 = both bits): bit 0 clear keeps the wide-window finalize of a
+ * family-shaped corpus (icd_stats.wide_mode) in batch order instead of visiting the queries family by family, XCD by XCD
+ * (finalize.hpp, order_keys_kernel / order_scatter_kernel); bit 1 clear walks wide rescoring windows four lanes per row
+ * instead of two. Performance decisions only: results are identical either way. */
 int icd_debug_set_family_order(int32_t enabled);
+
+/* Test switch, process-wide, read by icd_index_create (default 1): 0 keeps the fp16 corpus image uncentred whatever the
+ * rows look like (icd_stats.centered). A performance decision only: results are identical either way. */
+int icd_debug_set_center(int32_t enabled);
 
 /* Diagnostic builds only (make ABLATE=1, env ICD_FLAT_VAR with bit 1024): per-wave cycle sums of the coarse kernel,
  * [work-group][wave][8] = {LDS-DMA wait, barrier, stage body, fused select, tiles, ...}. */

@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = (
     "icd_abi_version", "icd_last_error", "icd_device_count", "icd_index_create", "icd_index_destroy",
     "icd_index_search", "icd_index_search_reweighted", "icd_merge_topk", "icd_index_lookup_levels",
     "icd_index_stats", "icd_index_set_chunks", "icd_index_debug_counters", "icd_index_set_profiling",
-    "icd_index_last_profile", "icd_index_profile_summary", "icd_debug_set_permute", "icd_debug_set_create_probe", "icd_debug_set_family_order", "icd_packed_attention",
+    "icd_index_last_profile", "icd_index_profile_summary", "icd_debug_set_permute", "icd_debug_set_create_probe", "icd_debug_set_family_order", "icd_debug_set_center", "icd_packed_attention",
     "icd_hier_rescore",
     "icd_score_stats",
     "icd_cosine_rows",
@@ -52,7 +52,8 @@ class _Stats(C.Structure):
                 ("max_nq", C.c_int32), ("max_k", C.c_int32), ("fast_path", C.c_int32), ("rmax", C.c_float),
                 ("last_nq", C.c_int64), ("last_fallback", C.c_int64), ("last_chunks", C.c_int32),
                 ("last_mode", C.c_int32), ("last_second_pass", C.c_int64), ("last_second_pass_lists", C.c_int32),
-                ("second_pass_armed", C.c_int32), ("wide_mode", C.c_int32), ("sparse_fallback_armed", C.c_int32)]
+                ("second_pass_armed", C.c_int32), ("wide_mode", C.c_int32), ("sparse_fallback_armed", C.c_int32),
+                ("centered", C.c_int32), ("mean_share", C.c_float)]
 
 
 class _Profile(C.Structure):
@@ -96,6 +97,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.icd_debug_set_permute.argtypes = [i32]
     lib.icd_debug_set_create_probe.argtypes = [i32]
     lib.icd_debug_set_family_order.argtypes = [i32]
+    lib.icd_debug_set_center.argtypes = [i32]
     lib.icd_packed_attention.argtypes = [i32, vp, i64, vp, i32, i32, i32, i32, vp, i64, vp]
     lib.icd_hier_rescore.argtypes = [i32, vp, vp, i64, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.icd_score_stats.argtypes = [i32, vp, vp, i64, i32, i32, vp, vp]

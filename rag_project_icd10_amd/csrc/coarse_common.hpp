@@ -80,7 +80,58 @@ struct ConvertArgs {
     int *zero_i32;           // nullable: four words cleared by the launch (the fallback counters of the search it starts)
     long long perm_mul;      // with perm_mod > 0: dst row p holds src row (p * perm_mul) mod perm_mod (an affine permutation)
     int perm_mod;
+    const float *mu;         // nullable [dim]: subtracted from every row before anything else (the corpus's column mean, see below)
+    float *norm_raw_max;     // nullable: atomicMax (as bits) of the L2 norm of the UNcentred, unscaled row (rounded up)
 };
+
+// ---- the corpus's fp16 image is CENTRED when its rows share a large common component ------------------------------------------
+// Sentence embeddings are anisotropic: every row has a large common component (mean pairwise cosine 0.3 - 0.9; the synthetic
+// encoder of this repo 0.98). q.c_r = q.(c_r - mu) + q.mu and q.mu is the same for every row of one query, so the ORDER of a
+// query's hits - all the coarse pass decides - is that of q.(c_r - mu). The fp16 rounding error of the coarse score is
+// relative to the norm of what is rounded: on centred rows it shrinks by |c - mu| / |c| (8 x at cosine 0.98), and with it
+// the certificate's window. icd_index_create computes mu (two deterministic reduction launches), centres when
+// |mu|^2 >= CENTER_MIN_SHARE of the mean squared row norm (Gaussian or family-shaped test corpora have mu ~ 0 and stay as
+// they are, bit for bit), and finalize adds the one error term that does NOT shrink: the fp32 chain of the canonical score
+// runs on the uncentred rows (finalize.hpp, eps).
+constexpr float CENTER_MIN_SHARE = 0.25f;
+
+// column sums of a row-major [rows][dim] matrix: block b sums rows b, b + grid, ... into part[b][dim] (fixed order), then
+// ONE block adds the partials in order: the same bits on every run
+__global__ __launch_bounds__(256) void column_sum_partial_kernel(const float *src, int rows, int dim, float *part, float *sq_part) {
+    float sq = 0.0f;
+    for (int d0 = threadIdx.x; d0 < dim; d0 += 256) {
+        float acc = 0.0f;
+        for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+            const float v = src[(size_t)r * dim + d0];
+            acc += v;
+            sq = __builtin_fmaf(v, v, sq);
+        }
+        part[(size_t)blockIdx.x * dim + d0] = acc;
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+        for (int i = 0; i < 256; ++i) t += red[i];
+        sq_part[blockIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(256) void column_sum_final_kernel(const float *part, const float *sq_part, int nblocks, int rows, int dim, float *mu, float *out2) {
+    for (int d0 = threadIdx.x; d0 < dim; d0 += 256) {
+        float acc = 0.0f;
+        for (int b = 0; b < nblocks; ++b) acc += part[(size_t)b * dim + d0];
+        mu[d0] = acc / (float)rows;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {   // out2[0] = |mu|^2, out2[1] = mean squared row norm
+        float m2 = 0.0f, sq = 0.0f;
+        for (int d = 0; d < dim; ++d) m2 = __builtin_fmaf(mu[d], mu[d], m2);
+        for (int b = 0; b < nblocks; ++b) sq += sq_part[b];
+        out2[0] = m2;
+        out2[1] = sq / (float)rows;
+    }
+}
 
 // e with m * 2^e in [1, 2) for finite m > 0 (subnormals included); 0 otherwise
 __host__ __device__ inline int scale_exp_for(float m) {
@@ -111,12 +162,17 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(ConvertArgs a) {
     // lane); the second pass over it used to be a second round trip
     constexpr int NV = 4;
     float4 v[NV];
-    float m = 0.0f;
+    float m = 0.0f, raw_ss = 0.0f;
     bool bad = false;
 #pragma unroll
     for (int t = 0; t < NV; ++t) {
         const int i = lane * 4 + 256 * t;
         v[t] = i < a.dim ? *reinterpret_cast<const float4 *>(s + i) : float4{0.f, 0.f, 0.f, 0.f};
+        if (a.norm_raw_max) raw_ss = __builtin_fmaf(v[t].x, v[t].x, __builtin_fmaf(v[t].y, v[t].y, __builtin_fmaf(v[t].z, v[t].z, __builtin_fmaf(v[t].w, v[t].w, raw_ss))));
+        if (a.mu && i < a.dim) {
+            const float4 m4 = *reinterpret_cast<const float4 *>(a.mu + i);
+            v[t].x -= m4.x; v[t].y -= m4.y; v[t].z -= m4.z; v[t].w -= m4.w;
+        }
         const float f[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -127,6 +183,11 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(ConvertArgs a) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
     const bool anybad = __any(bad);
+    if (a.norm_raw_max) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) raw_ss += __shfl_xor(raw_ss, off);
+        if (lane == 0 && !anybad) atomicMax(reinterpret_cast<unsigned int *>(a.norm_raw_max), __float_as_uint(sqrtf(raw_ss) * 1.000001f));
+    }
     if (a.mode == 2) {
         if (lane == 0) {
             if (!anybad && a.amax_bits) atomicMax(a.amax_bits, __float_as_uint(m));

@@ -295,6 +295,12 @@ __device__ __forceinline__ void compact_all_parallel(char *smem, Sel2 &st, uint3
 // the next tile's MFMA gaps, the first two selects built for the 16x16x32 shape before the lane swap let it keep this
 // one - bit 32768 IS that shape and is part of the product) live in experiments/r02_flat_variants/ with their logs.
 constexpr int CF_PRODUCT_VAR = 1 + 2 + 8 + 128 + 16 + 2048 + 32768;   // measured: profiles/r02_ab_flat_variants.log, profiles/r02_coarse_variants_rg_w8_all.log (+ 16 + 2048: -2 %; + 32768: -2 % at 37 000 rows, -4 % on 1.25 M-row shards)
+// The first pass over a corpus whose fp16 image stays in the Infinity Cache (the 37k - 40k-row ICD corpus: 57 - 62 MB): the
+// LDS-DMA pieces spread over a whole stage interval and the three-instruction bootstrap. Interleaved A/Bs on four boxes
+// (profiles/r04_ab_coarse_variants.log): 10 000 x 37 000 -0.9 ... -2.6 %, the family corpus in wide mode (a third of a
+// list's tiles are bootstrap tiles) -3 %; on a 1.25 M-row shard streamed from HBM the later issue of half the pieces costs
+// +6 % (less run-ahead for a longer latency), so shards keep CF_PRODUCT_VAR (icd_search.hip picks by the image's size).
+constexpr int CF_CACHED_VAR = CF_PRODUCT_VAR + 2097152 + 4194304;
 __host__ __device__ constexpr int cf_ring_stages(int var) { return (var & 1048576) ? 6 : CO_S; }
 __host__ __device__ constexpr int cf_lds_bytes(int var) { return cf_ring_stages(var) * CO_STAGE_BYTES + CO_BM * CO_CAP * 8 + ((var & 1048576) ? 0 : 4 * 256); }
 #define ICD_CF_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); \

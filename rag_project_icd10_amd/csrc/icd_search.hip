@@ -36,7 +36,9 @@ namespace {
 thread_local std::string g_err = "";
 bool g_permute = true;   // test switch (icd_debug_set_permute): row order of the fp16 corpus copy
 bool g_probe = true;     // test switch (icd_debug_set_create_probe): the corpus-shape probe of icd_index_create
-bool g_family_order = true;   // test switch (icd_debug_set_family_order): the wide-window finalize visits the queries in family order
+bool g_center = true;         // test switch (icd_debug_set_center): the fp16 corpus image is centred when the rows share a large common component
+bool g_family_order = true;
+bool g_pair_walk = true;      // test switch (icd_debug_set_family_order, bit 1): wide windows walked two lanes per row   // test switch (icd_debug_set_family_order): the wide-window finalize visits the queries in family order
 
 int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -72,6 +74,7 @@ namespace {
     } while (0)
 
 constexpr float EPS_REL = 1.2e-3f;
+constexpr size_t COARSE_CACHED_IMAGE_BYTES = (size_t)96 << 20;   // fp16 images up to this size take CF_CACHED_VAR (both corpus copies then fit the 256 MiB Infinity Cache)
 constexpr int FAST_MAX_K = 100;      // the rescoring window holds up to 256 candidates (four per lane): k + the rows inside 2 eps of the k-th
 constexpr int COARSE_MAX_P = 32;     // P * KP <= FIN_MAX_CAND
 constexpr int PASS2_CHUNKS = 20;     // second coarse pass (and wide_mode): about this many candidate lists per query
@@ -115,6 +118,9 @@ struct icd_index {
     float rmax = 0.f;        // largest row norm (unscaled; reported by icd_index_stats)
     float rmax_scaled = 0.f; // largest norm of the scaled fp16 rows
     int cexp = 0;            // fp16 corpus = fp32 corpus * 2^cexp
+    float *cmean = nullptr;  // [dim] column mean subtracted from the fp16 image (nullptr: not centred; coarse_common.hpp)
+    float rmax_unc_scaled = 0.f;   // centred image: largest norm of the UNcentred rows, in the image's scale
+    float mean_share = 0.f;  // |mu|^2 / mean |row|^2 (the mean pairwise cosine of unit rows): reported by icd_index_stats
     int num_cu = 256;
     // corpus
     float *corpus = nullptr;
@@ -197,7 +203,7 @@ void free_all(icd_index *x) {
     hipFree(x->qnorm); hipFree(x->qexp); hipFree(x->qbad); hipFree(x->shared_thr); hipFree(x->partc_s); hipFree(x->partc_r); hipFree(x->partc_b); hipFree(x->partx_s);
     hipFree(x->part2_s); hipFree(x->part2_r); hipFree(x->part2_b);
     hipFree(x->partx_r); hipFree(x->lists_s); hipFree(x->lists_r); hipFree(x->nflag); hipFree(x->flagged); hipFree(x->scratch_u32);
-    hipFree(x->order); hipFree(x->order_key); hipFree(x->order_hist);
+    hipFree(x->order); hipFree(x->order_key); hipFree(x->order_hist); hipFree(x->cmean);
     hipFree(x->o_scores); hipFree(x->o_ids); hipFree(x->o_adj); hipFree(x->o_adj_raw);
     hipFree(x->o_adj_ids); hipFree(x->o_adj_lv);
     hipFree(x->dbg);
@@ -432,6 +438,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     FinArgs f{};
     f.k = k; f.queries = dq; f.corpus = x->corpus; f.dim = x->dim; f.qnorm = x->qnorm; f.qbad = x->qbad;
     f.qexp = x->qexp; f.rmax = x->rmax_scaled; f.cexp = x->cexp; f.eps_rel = EPS_REL; f.nflag = x->nflag; f.flagged = x->flagged;
+    if (x->cmean) { f.rmax_unc = x->rmax_unc_scaled; f.eps_f32 = 2.0f * (float)x->dim * 5.9604645e-8f; }
     f.levels = x->levels; f.id_base = x->id_base;
     f.out_scores = o.scores; f.out_ids = o.ids; f.out_adj = o.adj; f.out_adj_raw = o.adj_raw;
     f.out_adj_ids = o.adj_ids; f.out_adj_levels = o.adj_lv;
@@ -761,6 +768,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         }
 #endif
         else if (wide_lists) rc = launch_coarse_flat<768, CF_PRODUCT_VAR, CO_KP_WIDE>(x, a, nwg, s);
+        else if ((size_t)x->n_pad * x->dim * 2 <= COARSE_CACHED_IMAGE_BYTES) rc = launch_coarse_flat<768, CF_CACHED_VAR>(x, a, nwg, s);   // (the image stays in the Infinity Cache)
         else rc = launch_coarse_flat<768>(x, a, nwg, s);
         if (rc) return rc;
     }
@@ -775,6 +783,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         // every query at once, and the retry below has nothing to add.
         const bool wide_fin = wide_now && k <= 32 && pc * g.KP >= 128;
         if (wide_fin) g.wide_window = 1;
+        g.pair_walk = g_pair_walk ? 1 : 0;
         if (wide_fin && g_family_order && nq >= 1024) {
             // every query's window is its family (the corpus is in code order): visit the queries family by family, XCD by XCD
             OrderArgs o{};
@@ -933,25 +942,49 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
             while (gcd(a_, n) != 1) a_ += 2;
             x->perm_mul = a_ % n; x->perm_mod = (int)n;
         }
+        // pass 0: the column mean; the image is centred when the rows share a large common component (coarse_common.hpp)
+        if (n >= 64) {
+            const int nb = (int)std::min<int64_t>(256, n);
+            float *part = nullptr, *sqp = nullptr, *out2 = nullptr;
+            CR_TRY(dmalloc(&part, (size_t)nb * dim));
+            CR_TRY(dmalloc(&sqp, (size_t)nb));
+            CR_TRY(dmalloc(&out2, 2));
+            CR_TRY(dmalloc(&x->cmean, (size_t)dim));
+            hipLaunchKernelGGL(column_sum_partial_kernel, dim3(nb), dim3(256), 0, 0, x->corpus, (int)n, dim, part, sqp);
+            hipLaunchKernelGGL(column_sum_final_kernel, dim3(1), dim3(256), 0, 0, part, sqp, nb, (int)n, dim, x->cmean, out2);
+            CR_TRY(hipGetLastError());
+            float h2[2] = {0.f, 0.f};
+            CR_TRY(hipMemcpy(h2, out2, sizeof h2, hipMemcpyDeviceToHost));
+            hipFree(part); hipFree(sqp); hipFree(out2);
+            x->mean_share = h2[1] > 0.f ? h2[0] / h2[1] : 0.f;
+            if (!g_center || !(x->mean_share >= CENTER_MIN_SHARE) || !std::isfinite(h2[0]) || !std::isfinite(h2[1])) { hipFree(x->cmean); x->cmean = nullptr; }
+        }
         // pass 1: largest component of the corpus -> ONE power-of-two scale for its fp16 image; pass 2: convert
         ConvertArgs cv{};
-        cv.src = x->corpus; cv.dst = x->c16; cv.rows = (int)n; cv.rows_pad = x->n_pad; cv.dim = dim;
+        cv.src = x->corpus; cv.dst = x->c16; cv.rows = (int)n; cv.rows_pad = x->n_pad; cv.dim = dim; cv.mu = x->cmean;
         cv.amax_bits = x->scratch_u32 + 2; cv.any_bad = x->scratch_u32 + 1; cv.mode = 2;
         hipLaunchKernelGGL(convert_rows_kernel, dim3((x->n_pad + 3) / 4), dim3(256), 0, 0, cv);
         CR_TRY(hipGetLastError());
-        unsigned hv[3] = {0, 0, 0};
+        unsigned hv[4] = {0, 0, 0, 0};
         CR_TRY(hipMemcpy(hv, x->scratch_u32, sizeof hv, hipMemcpyDeviceToHost));
         float amax = 0.f;
         memcpy(&amax, &hv[2], 4);
         x->cexp = scale_exp_for(amax);
         cv.mode = 1; cv.fixed_exp = x->cexp; cv.amax_bits = nullptr;
         cv.rmax_bits = x->scratch_u32;
+        if (x->cmean) cv.norm_raw_max = reinterpret_cast<float *>(x->scratch_u32 + 3);
         cv.perm_mul = x->perm_mul; cv.perm_mod = x->perm_mod;
         hipLaunchKernelGGL(convert_rows_kernel, dim3((x->n_pad + 3) / 4), dim3(256), 0, 0, cv);
         CR_TRY(hipGetLastError());
         CR_TRY(hipMemcpy(hv, x->scratch_u32, sizeof hv, hipMemcpyDeviceToHost));
         memcpy(&x->rmax_scaled, &hv[0], 4);
         x->rmax = ldexpf(x->rmax_scaled, -x->cexp);
+        if (x->cmean) {   // (rmax as reported stays the largest UNcentred norm; the certificate uses both)
+            float raw = 0.f;
+            memcpy(&raw, &hv[3], 4);
+            x->rmax = raw;
+            x->rmax_unc_scaled = ldexpf(raw, x->cexp);
+        }
         x->fast = (hv[1] == 0) && std::isfinite(x->rmax_scaled);
         if (!x->fast) { hipFree(x->c16); x->c16 = nullptr; }
     }
@@ -1239,6 +1272,7 @@ int icd_index_stats(icd_index *idx, icd_stats *out) {
     out->wide_mode = idx->wide_mode ? 1 : 0;
     out->second_pass_armed = (idx->pass2_enabled && idx->p2_clean < PASS2_DISARM_AFTER) ? 1 : 0;
     out->sparse_fallback_armed = idx->sparse_disarmed ? 0 : 1;
+    out->centered = idx->cmean ? 1 : 0; out->mean_share = idx->mean_share;
     out->last_chunks = idx->last_chunks; out->last_mode = idx->last_mode;
     return ICD_OK;
 }
@@ -1253,8 +1287,14 @@ int icd_debug_set_create_probe(int32_t enabled) {
     return ICD_OK;
 }
 
+int icd_debug_set_center(int32_t enabled) {
+    g_center = enabled != 0;
+    return ICD_OK;
+}
+
 int icd_debug_set_family_order(int32_t enabled) {
-    g_family_order = enabled != 0;
+    g_family_order = (enabled & 1) != 0;
+    g_pair_walk = (enabled & 2) != 0;
     return ICD_OK;
 }
 

@@ -1,6 +1,6 @@
 # round-end evidence: tests, smoke, bench (default + rowshard), e2e, the timed full build, rocprof kernel stats + PMC passes
 # usage: scripts/gpu_final.sh r03
-TAG=${1:-r03}
+TAG=${1:-r04}
 mkdir -p gpurun_out
 (timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -6) > gpurun_out/pytest_gpu.log
 (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3) > gpurun_out/smoke.log
@@ -8,6 +8,9 @@ mkdir -p gpurun_out
 (timeout 600 python bench.py --workload rowshard --steps 3 2>/dev/null | tail -1) > gpurun_out/bench_rowshard.log
 (timeout 600 python scripts/bench_e2e.py 2>/dev/null | tail -60) > gpurun_out/e2e.json
 (timeout 600 python scripts/bench_build.py 2>/dev/null) > gpurun_out/build_full.json
+(timeout 900 python scripts/bench_encoder_corpus.py 2>/dev/null) > gpurun_out/e2e_encoder_corpus.json
+(timeout 600 python scripts/probe/family_fin_ab.py 2>&1 | grep -v amdgpu.ids) > gpurun_out/family_fin_ab.log
+(timeout 600 python scripts/probe/anisotropic_probe.py 2>&1 | grep -v amdgpu.ids) > gpurun_out/anisotropic_probe.log
 # two ranks on this box's ONE device: RCCL refuses duplicate devices; the gloo control flow with the HIP index on one device is what can run
 (ICD_BENCH_BACKEND=gloo ICD_BENCH_ONE_DEVICE=1 timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --rows-per-gpu 400000 --rowshard-queries 20000 2>&1 | tail -2) > gpurun_out/bench_2rank_one_device.log
 bash scripts/gpu_pmc.sh $TAG > gpurun_out/pmc_$TAG.log 2>&1

@@ -1,6 +1,6 @@
 # rocprofv3 evidence for profiles/: kernel trace + stats of bench.py, then PMC counters in SEPARATE passes
 # (never combined with a trace domain other than --kernel-trace). usage: scripts/gpu_pmc.sh r03
-TAG=${1:-r03}
+TAG=${1:-r04}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out

@@ -149,3 +149,48 @@ def test_packed_forward_with_native_attention_matches_sdpa_groups(services, monk
     monkeypatch.undo()
     monkeypatch.setattr(gpu, "pooling", "cls")
     assert np.max(np.abs(gpu.encode_query_batch(texts, batch_size=256) - cls_sdpa)) <= 2e-6
+
+
+@pytest.mark.parametrize("k", [10, 20])
+def test_search_on_an_encoder_made_corpus_is_bit_exact(k, tmp_path, monkeypatch):
+    """The reference searches rows produced by the SAME encoder that encodes the query (tools/build_database.py:217-222:
+    encode_query(semantic_text) per record): anisotropic, family-shaped embeddings, not Gaussian rows. The full-size corpus
+    (40 474 rows of the real CSV's shape: scripts/bench_build.py synth_csv over tests/golden/csv_shape.json) is built on the
+    GPU by DatabaseBuilder, 1 000 golden diagnosis strings are encoded by the same service, and the batch search - whatever
+    mix of certified, second-pass and exact-re-search queries this data produces - must equal the oracle bit for bit."""
+    import json
+    import sys
+    import torch
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import oracle as orc
+    from bench_build import synth_csv
+    monkeypatch.setenv("MILVUS_DB_PATH", str(tmp_path / "db"))
+    monkeypatch.setenv("MILVUS_COLLECTION_NAME", "icd10_enc_test")
+    monkeypatch.setenv("EMBEDDING_MODEL_NAME", "shibing624/text2vec-base-chinese")
+    monkeypatch.setenv("ICD_EMBEDDING_ALLOW_SYNTHETIC", "1")
+    shape = json.load(open(os.path.join(GOLDEN, "csv_shape.json"), encoding="utf-8"))
+    csv_path = str(tmp_path / "shape.csv")
+    nrows = synth_csv(csv_path, shape)
+    from rag_project_icd10_amd.tools.build_database import DatabaseBuilder
+    b = DatabaseBuilder()
+    assert b.build_full_database(csv_path, rebuild=True)
+    ms, es = b.milvus_service, b.embedding_service
+    corpus, levels = ms.client.matrix(), ms.client.levels()
+    assert corpus.shape == (nrows, 768) and nrows == 40474
+    strings = [l.strip() for l in open(os.path.join(GOLDEN, "diagnosis_strings.txt"), encoding="utf-8") if l.strip()][:1000]
+    dq = es.encode_query_batch(strings, batch_size=256, to_device=True)
+    queries = dq.cpu().numpy()
+    os_, oi = orc.flat_ip_topk(corpus, queries, k)
+    want = orc.reweight(os_, oi, levels)
+    for rep in range(2):   # the first batch of the fresh index, then one planned from its counters
+        adj, raw, ids, lv = ms.search_batch(dq, top_k=k)
+        torch.cuda.synchronize()
+        st = ms._ready_index().stats()
+        assert np.array_equal(ids.cpu().numpy(), want[2]), (rep, st)
+        assert adj.cpu().numpy().tobytes() == want[0].tobytes() and raw.cpu().numpy().tobytes() == want[1].tobytes(), (rep, st)
+        assert np.array_equal(lv.cpu().numpy(), want[3])
+    print(f"encoder-made corpus k={k}: second pass {st['last_second_pass']} (x {st['last_second_pass_lists']} lists), "
+          f"exact re-search {st['last_fallback']} of {len(strings)}, wide_mode {st['wide_mode']}")
+    ms.disconnect()
