@@ -8,7 +8,9 @@ scores (bit-identical) and the reweighted outputs with oracle/ on a query sample
 clustered rows (near ties: forces the exact fallback), rows with exact duplicates, a batch whose fp16 image overflows,
 corpora and batches scaled far below fp16's normal range ("tiny"), corpora of tight families of near-identical rows in code
 order with large batches ("family": the first coarse pass certifies little, the second coarse pass / the wide-window retry
-must; the searches of one index alternate so that the armed, disarmed and wide-mode states all occur).
+must; the searches of one index alternate so that the armed, disarmed and wide-mode states all occur), anisotropic rows
+("aniso": a large common component at several strengths - the fp16 image is centred above a share of 0.25 - also scaled as a
+whole, with rows of other magnitudes mixed in, and with duplicates).
 """
 import argparse
 import os
@@ -34,6 +36,12 @@ def rows(rng, n, dim, kind):
         cent = rng.standard_normal(((n + per - 1) // per, dim)).astype(np.float32)
         x = np.repeat(cent, per, axis=0)[:n] + 0.1 * rng.standard_normal((n, dim)).astype(np.float32)
         x /= np.linalg.norm(x, axis=1, keepdims=True)
+    if kind == "aniso":       # normalise(mu0 + s e / sqrt(dim)): mean pairwise cosine 1 / (1 + s^2)
+        mu0 = np.random.default_rng(5).standard_normal(dim).astype(np.float32)
+        mu0 /= np.linalg.norm(mu0)
+        sdev = float(rng.choice([0.07, 0.2, 0.5, 1.0, 2.5]))
+        x = mu0[None, :] + (sdev / np.sqrt(dim)) * rng.standard_normal((n, dim)).astype(np.float32)
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
     if kind == "dups" and n > 20:
         src = rng.integers(0, n, n // 10)
         dst = rng.integers(0, n, n // 10)
@@ -57,9 +65,11 @@ def main():
         n = int(rng.choice([1, 7, 127, 128, 129, 1000, 4097, 20000, 37000, 100003]))
         nq = int(rng.choice([1, 2, 9, 16, 17, 64, 65, 128, 129, 1000, 3000, 6000]))
         k = int(rng.choice([1, 5, 10, 10, 10, 12, 13, 50, 100]))
-        kind = str(rng.choice(["gauss", "gauss", "clustered", "dups", "overflow", "zeros", "scaled", "tiny", "tiny", "family", "family"]))
+        kind = str(rng.choice(["gauss", "gauss", "clustered", "dups", "overflow", "zeros", "scaled", "tiny", "tiny", "family", "family", "aniso", "aniso", "aniso"]))
         if kind == "family":
             dim, n, nq = int(rng.choice([768, 768, 1024])), int(rng.choice([4097, 20000, 37000])), int(rng.choice([1000, 3000, 6000]))
+        if kind == "aniso" and rng.random() < 0.7:   # mostly the shapes where the coarse pass and its certificate do the work
+            dim, n, nq = int(rng.choice([768, 768, 1024])), int(rng.choice([4097, 20000, 37000])), int(rng.choice([129, 1000, 3000, 6000]))
         mode = MODE_AUTO if rng.random() < 0.8 else MODE_EXACT
         id_base = int(rng.choice([0, 0, 5_000_000_000]))
         if n * dim > 100003 * 768 or (n >= 100000 and nq > 1000):
@@ -69,6 +79,17 @@ def main():
         if kind == "family":      # queries near rows of the corpus
             queries = corpus[rng.integers(0, n, nq)] + 0.02 * rng.standard_normal((nq, dim)).astype(np.float32)
             queries = np.ascontiguousarray(queries / np.linalg.norm(queries, axis=1, keepdims=True), dtype=np.float32)
+        if kind == "aniso":
+            twist = str(rng.choice(["plain", "plain", "scaled", "mixed", "dups"]))
+            if twist == "scaled":     # the whole corpus / batch at another magnitude (the mean scales with it)
+                corpus *= np.float32(10.0 ** rng.uniform(-20, 3))
+                queries *= (10.0 ** rng.uniform(-6, 2, (nq, 1))).astype(np.float32)
+            if twist == "mixed":      # a few rows of very different norm or direction among the anisotropic ones
+                m = rng.random(n) < 0.02
+                corpus[m] *= rng.choice([-3.0, 1e-3, 25.0], (int(m.sum()), 1)).astype(np.float32)
+            if twist == "dups" and n > 20:
+                src, dst = rng.integers(0, n, n // 10), rng.integers(0, n, n // 10)
+                corpus[dst] = corpus[src]
         if kind == "tiny":        # whole corpus / batch far below fp16's normal range (2^-14), or only parts of them
             corpus *= np.float32(10.0 ** rng.uniform(-30, -4))
             if rng.random() < 0.5:
@@ -112,7 +133,7 @@ def main():
               and np.array_equal(lv[sample], want[3]))
         bad += 0 if ok else 1
         print(f"{'ok  ' if ok else 'FAIL'} case {case:3d}: n={n} nq={nq} dim={dim} k={k} kind={kind} mode={'auto' if mode == MODE_AUTO else 'exact'} "
-              f"id_base={id_base} probe={int(probe)} sp={sp} long={int(long_run)} -> sparse_armed={st['sparse_fallback_armed']} last_mode={st['last_mode']} lists={st['last_chunks']} second_pass={st['last_second_pass']} wide={st['wide_mode']} fallback={st['last_fallback']}", flush=True)
+              f"id_base={id_base} probe={int(probe)} sp={sp} long={int(long_run)} -> sparse_armed={st['sparse_fallback_armed']} last_mode={st['last_mode']} lists={st['last_chunks']} second_pass={st['last_second_pass']} wide={st['wide_mode']} centered={st['centered']} fallback={st['last_fallback']}", flush=True)
     print(f"gpu_fuzz: {args.cases - bad} ok, {bad} failed in {time.time() - t0:.1f} s")
     sys.exit(1 if bad else 0)
 
