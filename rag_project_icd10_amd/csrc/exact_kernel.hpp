@@ -151,14 +151,29 @@ __global__ __launch_bounds__(NW * 64) void exact_topk_kernel(ExactArgs a) {
             }
             const float *qrow = Qs + cur * BMQ * LDT + (wave * 32 + c) * LDT + h;
             const float *crow = Cs + cur * BN * LDT + c * LDT + h;
+            // The operands of k-step pair g + 1 are read BEFORE the eight MFMAs of pair g are issued: read right in front of
+            // their MFMAs (what hipcc makes of the plain loop) every group waits out an LDS round trip with the pipe draining
+            // (round 4: MFMA pipe busy 56 % of the launch). Two register sets, constant indices.
+            float bq[2][2], av[2][2][4];
+            auto load_pair = [&](int g, int set) {
 #pragma unroll
-            for (int s = 0; s < BK / 2; ++s) {
-                const float b = qrow[2 * s];
+                for (int j = 0; j < 2; ++j) {
+                    bq[set][j] = qrow[2 * (2 * g + j)];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float av = crow[t * 32 * LDT + 2 * s];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[t], 0, 0, 0);
+                    for (int t = 0; t < 4; ++t) av[set][j][t] = crow[t * 32 * LDT + 2 * (2 * g + j)];
                 }
+            };
+            load_pair(0, 0);
+#pragma unroll
+            for (int g = 0; g < BK / 4; ++g) {
+                if (g + 1 < BK / 4) load_pair(g + 1, (g + 1) & 1);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][j][t], bq[g & 1][j], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);   // the next pair's ten reads first ...
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);    // ... then this pair's MFMAs
             }
             if (more) {
                 float *qd = Qs + (cur ^ 1) * BMQ * LDT;

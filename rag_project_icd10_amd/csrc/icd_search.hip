@@ -216,7 +216,10 @@ void free_all(icd_index *x) {
     delete x;
 }
 
-int exact_kp_for(int k) { return k <= 16 ? 16 : (k <= 64 ? 64 : 128); }
+// candidates per exact list: the smallest of 16 / 32 / 64 / 128 that holds k. (32 is round 4's: the serving path searches
+// top_k * 2 = 20, and finalize merges at most 512 candidates per query - 8 lists of 64 gave a few hundred flagged queries 80
+// two-wave work-groups, 16 lists of 32 give them 160.)
+int exact_kp_for(int k) { return k <= 16 ? 16 : (k <= 32 ? 32 : (k <= 64 ? 64 : 128)); }
 
 // chunk count heuristic: enough work-groups to fill the chip, few enough lists to merge
 int pick_chunks(int mtiles, int row_tiles, int pmax, int target_wgs) {
@@ -324,7 +327,7 @@ constexpr int LDS_LIMIT = 160 * 1024;   // LDS per CU (MI355X_MICROARCH.md)
 
 // does a pass of qb queries fit LDS with the minimum ring of two stages per wave?
 inline bool stream_fits(int kp, int qb, int dim) {
-    const int e = kp == 16 ? 2 : (kp == 64 ? 3 : 4);
+    const int e = kp <= 32 ? 2 : (kp == 64 ? 3 : 4);
     return (size_t)qb * dim * 4 + (size_t)4 * 2 * ST_STAGE_BYTES + (size_t)4 * qb * 64 * e * 8 <= (size_t)LDS_LIMIT;
 }
 
@@ -445,8 +448,8 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
 
     // exact-kernel configuration (full run, or fallback over the flagged list)
     const int kpx = exact_kp_for(k);
-    const int nwx = kpx == 16 ? 4 : (kpx == 64 ? 2 : 1);
-    const int ex = kpx == 16 ? 1 : (kpx == 64 ? 2 : 3);
+    const int nwx = kpx == 16 ? 4 : (kpx <= 64 ? 2 : 1);
+    const int ex = kpx == 16 ? 1 : (kpx <= 64 ? 2 : 3);
     const int bmq = nwx * 32;
     const int mtx = (nq + bmq - 1) / bmq;
     const int pmax_x = std::min(16, FIN_MAX_CAND / kpx);
@@ -468,6 +471,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
          qb == 4 ? launch_stream<KPV, EV, 4>(x, dq, qlist, nq_ptr, nqs, sparse_max, p_out, p_used, s) : \
                    launch_stream<KPV, EV, 8>(x, dq, qlist, nq_ptr, nqs, sparse_max, p_out, p_used, s))
         if (kpx == 16) return ICD_ST(16, 2);
+        if (kpx == 32) return ICD_ST(32, 2);
         if (kpx == 64) return ICD_ST(64, 3);
         return ICD_ST(128, 4);
 #undef ICD_ST
@@ -508,6 +512,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             a.rows_per_chunk = ((row_tiles + pm - 1) / pm) * 128;
             a.part_scores = x->partx_s; a.part_rows = x->partx_r;
             if (kpx == 16) rc = launch_exact<16, 1, 4>(x, a, mtx, s);
+            else if (kpx == 32) rc = launch_exact<32, 2, 2>(x, a, mtx, s);
             else if (kpx == 64) rc = launch_exact<64, 2, 2>(x, a, mtx, s);
             else rc = launch_exact<128, 3, 1>(x, a, mtx, s);
             if (rc) return rc;

@@ -64,7 +64,7 @@ def main():
         dim = int(rng.choice([768, 768, 768, 1024, 96, 256]))
         n = int(rng.choice([1, 7, 127, 128, 129, 1000, 4097, 20000, 37000, 100003]))
         nq = int(rng.choice([1, 2, 9, 16, 17, 64, 65, 128, 129, 1000, 3000, 6000]))
-        k = int(rng.choice([1, 5, 10, 10, 10, 12, 13, 50, 100]))
+        k = int(rng.choice([1, 5, 10, 10, 10, 12, 13, 17, 20, 20, 32, 33, 50, 100]))
         kind = str(rng.choice(["gauss", "gauss", "clustered", "dups", "overflow", "zeros", "scaled", "tiny", "tiny", "family", "family", "aniso", "aniso", "aniso"]))
         if kind == "family":
             dim, n, nq = int(rng.choice([768, 768, 1024])), int(rng.choice([4097, 20000, 37000])), int(rng.choice([1000, 3000, 6000]))
