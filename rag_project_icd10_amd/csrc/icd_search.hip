@@ -641,6 +641,20 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         if (x->chunks_override > 0 || wide_now) {   // test hook / wide mode: about `chunks` lists per query
             const int chunks = x->chunks_override > 0 ? x->chunks_override : PASS2_CHUNKS;
             U = std::max(1, (ctiles + chunks - 1) / chunks);
+            if (wide_now && x->chunks_override == 0) {
+                // The wide partition is several ROUNDS of work-groups (79 query tiles x 319 tiles / 16 = 1 576 of them on 256
+                // CUs: 6.15 rounds, the seventh 15 % full): among the list lengths that keep 17 ... 23 lists per query take the
+                // one whose last round is fullest (here 17 tiles: 5.8 rounds).
+                double best = -1.0;
+                int best_u = U;
+                for (int u = std::max(1, ctiles / 23); u <= (ctiles + 16) / 17; ++u) {
+                    const long long wgs = ((long long)mtc * ctiles + u - 1) / u;
+                    const long long rounds = (wgs + x->num_cu - 1) / x->num_cu;
+                    const double eff = (double)wgs / (double)(rounds * x->num_cu);
+                    if (eff > best + 0.02 || (eff > best - 0.02 && std::abs(u - U) < std::abs(best_u - U))) { best = std::max(best, eff); best_u = u; }
+                }
+                U = best_u;
+            }
             a.list_tiles = ctiles;
         }
         auto lists_needed_lt = [&](int u, int list_tiles) {   // the largest number of lists of any query tile (same rule as the kernel)
