@@ -17,6 +17,9 @@
 #if defined(ICD_ABLATE) && !defined(ICD_FV_LIST)
 #define ICD_ABLATE_EXPERIMENTS 1
 #endif
+#ifdef ICD_ABLATE
+#include "../../experiments/r04_ksplit_kernel/coarse_ksplit_kernel.hpp"   // (A/B builds only: wave pairs split K, 64 queries per wave)
+#endif
 #ifdef ICD_ABLATE_EXPERIMENTS
 #include "../../experiments/r02_rg_kernel/coarse_rg_kernel.hpp"   // (A/B builds only: the row-group experiment)
 #include "../../experiments/r02_w8_kernel/coarse_w8_kernel.hpp"   // (A/B builds only: eight waves, two per SIMD)
@@ -265,6 +268,18 @@ int launch_coarse_flat(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream
     return ICD_OK;
 }
 
+#ifdef ICD_ABLATE
+template <int D, int KP = CO_KP, int TV = 0>
+int launch_coarse_ksplit(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream_t s) {
+    auto kern = coarse_ksplit_kernel<D, KP, TV>;
+    constexpr int lds = ks_lds_bytes();
+    static int configured[MAX_DEVICES] = {};
+    HIP_TRY(ensure_dynamic_lds(kern, x->device, (size_t)(lds), configured));
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, s, a);
+    HIP_TRY(hipGetLastError());
+    return ICD_OK;
+}
+#endif
 #ifdef ICD_ABLATE_EXPERIMENTS
 template <int D, int KP = CO_KP, int VAR = 0>
 int launch_coarse_rg(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream_t s) {
@@ -771,6 +786,14 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         }
 #endif
 #ifdef ICD_ABLATE
+        else if (getenv("ICD_KS_VAR") && !wide_lists) {   // A/B builds: the K-split pair kernel (experiments/r04_ksplit_kernel)
+            const int v = atoi(getenv("ICD_KS_VAR"));
+            if (v == 0) rc = launch_coarse_ksplit<768, CO_KP, 0>(x, a, nwg, s);
+            else if (v == 1) rc = launch_coarse_ksplit<768, CO_KP, 1>(x, a, nwg, s);
+            else if (v == 2) rc = launch_coarse_ksplit<768, CO_KP, 2>(x, a, nwg, s);
+            else if (v == 5) rc = launch_coarse_ksplit<768, CO_KP, 5>(x, a, nwg, s);
+            else return fail(ICD_ERR_INVALID, "ICD_KS_VAR=%d is not built", v);
+        }
         else if (const char *fv = getenv("ICD_FLAT_VAR")) {   // A/B builds: stage / select variants of the flat kernel
             const int v = atoi(fv);
             if (false) {}
