@@ -153,3 +153,34 @@ def test_bench_refuses_more_ranks_than_gpus():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], env=env, capture_output=True, text=True,
                        timeout=120, cwd=ROOT)
     assert p.returncode != 0 and "GPU(s) visible" in p.stderr and not p.stdout.strip()
+
+
+def test_visible_gpus_counts_without_touching_the_runtime(monkeypatch, tmp_path):
+    """spawn_ranks' device count comes from the visibility variables or the KFD topology (nodes with SIMDs), never from the
+    HIP runtime: the parent of the ranks must not open the device"""
+    sys.path.insert(0, ROOT)
+    import bench
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,3,5")
+    assert bench.visible_gpus() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpus() == 0
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
+    assert bench.visible_gpus() == 1
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
+    # no variable: the topology directory (absent in this container -> None, and spawn_ranks asks torch instead)
+    got = bench.visible_gpus()
+    assert got is None or isinstance(got, int)
+    # a fake topology: two GPU nodes (simd_count > 0) and one CPU node
+    base = tmp_path / "nodes"
+    for i, simd in enumerate((0, 1024, 1024)):
+        d = base / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count 64\nsimd_count {simd}\nmem_banks_count 1\n")
+    import builtins, os as _os
+    real_listdir, real_open = _os.listdir, builtins.open
+    monkeypatch.setattr(_os, "listdir", lambda p: real_listdir(str(base)) if p == "/sys/class/kfd/kfd/topology/nodes" else real_listdir(p))
+    monkeypatch.setattr(builtins, "open", lambda p, *a, **k: real_open(str(p).replace("/sys/class/kfd/kfd/topology/nodes", str(base)), *a, **k))
+    assert bench.visible_gpus() == 2

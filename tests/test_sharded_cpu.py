@@ -172,3 +172,40 @@ def test_ranks_agree_on_the_engine(case):
         p.join(timeout=180)
     assert all(p.exitcode == 0 for p in procs)   # (nobody hung, nobody died)
     assert sorted(q.get(timeout=10) for _ in range(2)) == [(0, True), (1, True)]
+
+
+def test_default_engine_above_one_rank_is_torch_distributed(monkeypatch):
+    """from_index: a single rank takes the C-ABI group (needs the library: not here), several ranks take torch.distributed
+    collectives unless ICD_SHARDED_ENGINE=native / native=True asks for the group - the C-ABI collective has not run on two
+    GPUs yet. Checked on the decision alone: no process group, the factory records whether it was asked."""
+    calls = []
+
+    class Idx:
+        device, max_nq, max_k = 0, 8, 5
+        closed = False
+
+        def search(self, q, k):
+            raise AssertionError
+
+        lookup_levels = search_reweighted = search
+
+    def factory():
+        calls.append(1)
+
+        class G:
+            connected = True
+
+            def close(self):
+                pass
+        return G()
+
+    monkeypatch.delenv("ICD_SHARDED_ENGINE", raising=False)
+    sh = ShardedSearch.from_index(Idx(), ROW_SHARD, native_factory=factory)     # world 1, default: native
+    assert sh.world == 1 and sh.native_group is not None and calls == [1]
+    monkeypatch.setenv("ICD_SHARDED_ENGINE", "torch")
+    sh = ShardedSearch.from_index(Idx(), ROW_SHARD, native_factory=factory)
+    assert sh.native_group is None and calls == [1]
+    sh = ShardedSearch.from_index(Idx(), ROW_SHARD, native=True, native_factory=factory)   # explicit request wins
+    assert sh.native_group is not None and calls == [1, 1]
+    sh.close()
+    assert sh.native_group is None
