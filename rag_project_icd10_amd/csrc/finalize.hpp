@@ -363,7 +363,9 @@ __global__ __launch_bounds__(256, EWM == 1 ? ICD_FIN_OCC : 1) void finalize_kern
             for (int e = 0; e < EWM; ++e) W += __popcll(__ballot(e < EW && mine[e] != 0ull && coarse[e] >= L));
             const int nblk = a.dim >> 4;   // 64-B blocks per row; a multiple of 8 for the fast path's dims (768, 1024)
             if (EWM >= 4 && a.pair_walk && W > 32) {
-                // WIDE window (a family of near-identical rows, up to 256 candidates): TWO lanes per row, 32 rows per pass. The
+                // WIDE window (a family of near-identical rows, up to 256 candidates): TWO lanes per row, 32 rows per pass (on rows
+                // gathered from all over the corpus - k = 20 on Gaussian data, ~23 rows - the 32-B pieces cost more than the
+                // second quad pass: +5 %, profiles/r04_k20_pair_walk_ab.log; on a family served from L2: -4 %). The
                 // same scheme as the quad walk below with half its redundancy: lane 2 g + i loads piece 2 b + i of every 32-B
                 // half block b of row g, both lanes run their four fmaf from the same running value, the pair adopts lane
                 // 0's result, repeats and adopts lane 1's (quad_perm [0,0,2,2] / [1,1,3,3]): 10 VALU per 8 dimensions as in
