@@ -296,7 +296,16 @@ def oracle_check(corpus, levels, queries, k, out, world=1):
             "parity_checked_queries": int(len(queries)), "parity_check_s": round(time.perf_counter() - t0, 2)}
 
 
-def side_workload(ctx, args, index_factory, name, corpus, levels, queries, k, mode, steps, first_batch=False):
+def side_workload(*a, **kw):
+    """an `extra` object never costs the line its headline: a failure is reported in its place"""
+    try:
+        return _side_workload(*a, **kw)
+    except Exception as exc:   # pragma: no cover - reported, the headline above is already measured
+        import traceback
+        return {"workload": a[3] if len(a) > 3 else "?", "error": f"{type(exc).__name__}: {exc}", "traceback": traceback.format_exc()[-1500:]}
+
+
+def _side_workload(ctx, args, index_factory, name, corpus, levels, queries, k, mode, steps, first_batch=False):
     """one of the line's `extra` objects: the same step on other data / another size / the exact kernel alone, timed
     over `steps` steps after a short warm-up and checked against the oracle on every query, in this run.
     first_batch: also time the FIRST search of the fresh index on its own (what a new index costs its first user batch)"""

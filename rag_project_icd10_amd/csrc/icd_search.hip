@@ -224,18 +224,22 @@ void free_all(icd_index *x) {
 // two-wave work-groups, 16 lists of 32 give them 160.)
 int exact_kp_for(int k) { return k <= 16 ? 16 : (k <= 32 ? 32 : (k <= 64 ? 64 : 128)); }
 
-// chunk count heuristic: enough work-groups to fill the chip, few enough lists to merge
-int pick_chunks(int mtiles, int row_tiles, int pmax, int target_wgs) {
+// chunk count heuristic: enough work-groups to fill the chip, few enough lists to merge. `slots` = the work-groups the
+// chip holds at once: ONE per CU for every instantiation of exact_topk (its LDS - two 33-KB operand stages + the candidate
+// buffers - is 90 - 130 KB). Round 3 planned against two per CU: 79 query tiles x 4 chunks = 316 work-groups ran as a full
+// round of 256 and a second one of 60 (MFMA pipe busy 56 % of the launch); against the real count 79 x 3 = 237 fill 93 % of
+// ONE round.
+int pick_chunks(int mtiles, int row_tiles, int pmax, int slots) {
     int p = 1;
-    if (mtiles < target_wgs) {
-        p = std::max(1, target_wgs / mtiles);
+    if (mtiles * 2 <= slots) {
+        p = std::max(1, slots / mtiles);
     } else {
-        // big batches: smallest p whose last round is at least 90 % full
+        // the smallest p whose last round of work-groups is at least 90 % full (else the fullest)
         double best = 0;
         int bestp = 1;
-        for (int c = 1; c <= std::min(pmax, 4); ++c) {
+        for (int c = 1; c <= std::min(pmax, 8); ++c) {
             const long items = (long)mtiles * c;
-            const double util = (double)items / (double)(((items + target_wgs - 1) / target_wgs) * target_wgs);
+            const double util = (double)items / (double)(((items + slots - 1) / slots) * slots);
             if (util > best + 1e-9) { best = util; bestp = c; }
             if (util >= 0.9) { bestp = c; break; }
         }
@@ -512,7 +516,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             // the workspace like a full exact run; only the streaming kernel (<= ST_MAX_ACTIVE slots) uses px.
             int pm = px;
             if (stream) {
-                pm = pick_chunks(mtx, row_tiles, pmax_x, 2 * x->num_cu);
+                pm = pick_chunks(mtx, row_tiles, pmax_x, x->num_cu);
                 pm = fit_p(pm, x->partx_cap, kpx);
                 if ((size_t)nq * pm * kpx > x->partx_cap) return fail(ICD_ERR_INVALID, "workspace too small for nq=%d k=%d", nq, k);
                 const int tiles_per = (row_tiles + pm - 1) / pm;
@@ -560,7 +564,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     }
     if (!use_fast) {
         HIP_TRY(hipMemsetAsync(x->nflag, 0, sizeof(int), s));
-        int px = pick_chunks(mtx, row_tiles, pmax_x, 2 * x->num_cu);
+        int px = pick_chunks(mtx, row_tiles, pmax_x, x->num_cu);
         px = fit_p(px, x->partx_cap, kpx);
         if ((size_t)nq * px * kpx > x->partx_cap) return fail(ICD_ERR_INVALID, "workspace too small for nq=%d k=%d", nq, k);
         {
