@@ -579,7 +579,7 @@ __global__ __launch_bounds__(1024) void order_scatter_kernel(OrderArgs a) {
     __syncthreads();
     for (int q = t; q < a.nq; q += 1024) {
         const int p = (int)atomicAdd(&offs[a.key[q]], 1u);
-        a.order[order_slot(p, nblk)] = q;
+        if (p < 4 * nblk) a.order[order_slot(p, nblk)] = q;   // (always true for a consistent histogram)
     }
 }
 

@@ -237,11 +237,12 @@ int pick_chunks(int mtiles, int row_tiles, int pmax, int slots) {
         // the smallest p whose last round of work-groups is at least 90 % full (else the fullest)
         double best = 0;
         int bestp = 1;
+        const double want = 0.9;
         for (int c = 1; c <= std::min(pmax, 8); ++c) {
             const long items = (long)mtiles * c;
             const double util = (double)items / (double)(((items + slots - 1) / slots) * slots);
             if (util > best + 1e-9) { best = util; bestp = c; }
-            if (util >= 0.9) { bestp = c; break; }
+            if (util >= want) { bestp = c; break; }
         }
         p = bestp;
     }
@@ -838,6 +839,9 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             o.shift = 6;
             while (((long long)x->n >> o.shift) >= ORDER_BUCKETS) ++o.shift;
             o.key = x->order_key; o.hist = x->order_hist; o.order = x->order;
+            // (the scatter kernel leaves the histogram zero again; a search that failed between the two launches would not:
+            //  cleared here, 4 KB, so that a stale count can never push a position past the order buffer)
+            HIP_TRY(hipMemsetAsync(x->order_hist, 0, ORDER_BUCKETS * sizeof(unsigned int), s));
             hipLaunchKernelGGL(order_keys_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, o);
             hipLaunchKernelGGL(order_scatter_kernel, dim3(1), dim3(1024), 0, s, o);
             HIP_TRY(hipGetLastError());
