@@ -5,8 +5,9 @@
 // k-ordered fmaf chain, and k = 2s + (lane>>5) is mapped to d ascending, so every score equals
 // oracle/icd_oracle.c's chain_score() bit for bit.
 //
-// Work-group = NW waves; tile = NW*32 queries x 128 corpus rows; stages of 32 floats of K,
-// register-staged double buffering, LDS rows padded to 33 floats (conflict-free ds_read_b32).
+// Work-group = NW waves; tile = NW*32 queries x 128 corpus rows; stages of BK = 32 (16) floats of K; the corpus rows of
+// a stage go through LDS (register-staged double buffering, rows padded to BK + 1 floats: conflict-free ds_read_b32), the
+// queries straight from global memory into the MFMA's operand registers.
 #pragma once
 #include "topk_select.hpp"
 
@@ -41,16 +42,30 @@ __host__ __device__ inline int exact_adaptive_chunks(int nq_active, int bmq, int
     return p > 1 ? p : 1;
 }
 
-template <int KP, int E, int NW>
-__global__ __launch_bounds__(NW * 64) void exact_topk_kernel(ExactArgs a) {
-    constexpr int BMQ = NW * 32, BN = 128, BK = 32, LDT = 33, NT = NW * 64;
-    constexpr int CAP = 64 * E, LIMIT = CAP - 32;
-    constexpr int CL = (BN * 8) / NT;  // corpus float4 loads per thread per stage
-    constexpr int QL = (BMQ * 8) / NT; // = 4
+// CAPV: entries of one query's candidate buffer (<= 64 E; a compaction is due above CAPV - 32); BK: floats of K per stage;
+// OCC: waves per SIMD the register budget is sized for (two work-groups of four waves per CU when their LDS fits twice).
+//
+// The QUERY operand never touches LDS: a wave's 32 queries are its own (no other wave reads them), so lane (c, h) loads
+// the BK / 2 consecutive floats [h BK / 2, (h + 1) BK / 2) of query c for the stage straight into registers (a full
+// 128-byte line per query and stage at BK = 32) and one v_permlane32_swap per register pair turns them into the MFMA's
+// k-step pairs: swap(r[2 i], r[2 i + 1]) leaves (k = 2 i | 2 i + 1) in r[2 i] - pair i - and
+// (k = BK / 2 + 2 i | BK / 2 + 2 i + 1) in r[2 i + 1] - pair BK / 4 + i. (Round 4; before, the queries were staged like the
+// corpus rows: 34 KB of LDS, half of the scalar LDS writes of a stage, and with the 64-KB candidate buffers of k > 16 only
+// two waves fitted a CU: `--mode exact` at k = 20 ran at 0.27 of the fp32 MFMA peak against 0.59 at k = 10.)
+template <int KP, int E, int NW, int CAPV = 64 * E, int BK = 32, int OCC = 1>
+__global__ __launch_bounds__(NW * 64, OCC) void exact_topk_kernel(ExactArgs a) {
+    constexpr int BMQ = NW * 32, BN = 128, LDT = BK + 1, NT = NW * 64;
+    constexpr int CAP = CAPV, LIMIT = CAP - 32;
+    static_assert(CAP <= 64 * E && LIMIT >= KP && CAP % 2 == 0, "candidate buffer: KP kept + 32 appended per group, E keys per lane");
+    static_assert(BK == 16 || BK == 32, "stage depth");
+    constexpr int C4 = BK / 4;             // float4 per corpus row and stage
+    constexpr int CL = (BN * C4) / NT;     // corpus float4 loads per thread per stage
+    constexpr int QH = BK / 2;             // floats of a query a lane holds per stage = k-step pairs per stage
+    constexpr int Q4 = QH / 4;
+    static_assert(CL >= 1 && (BN * C4) % NT == 0, "stage loads divide over the threads");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *Qs = reinterpret_cast<float *>(smem);
-    float *Cs = Qs + 2 * BMQ * LDT;
-    u64 *bufs = reinterpret_cast<u64 *>(smem + (((size_t)(2 * BMQ * LDT + 2 * BN * LDT) * 4 + 15) & ~(size_t)15));
+    float *Cs = reinterpret_cast<float *>(smem);
+    u64 *bufs = reinterpret_cast<u64 *>(smem + (((size_t)(2 * BN * LDT) * 4 + 15) & ~(size_t)15));
 
     const int nq = a.nq_ptr ? min(*a.nq_ptr, a.nq) : a.nq;
     if (a.nq_ptr && nq <= a.min_active) return;
@@ -76,37 +91,45 @@ __global__ __launch_bounds__(NW * 64) void exact_topk_kernel(ExactArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int dim = a.dim, nks = dim / BK;
+    const int h = lane >> 5, c = lane & 31;
 
-    // query source rows for this thread's staging loads
-    const float *qsrc[QL];
-    int qdst[QL];
-#pragma unroll
-    for (int i = 0; i < QL; ++i) {
-        const int idx = tid + NT * i, qr = idx >> 3, c4 = idx & 7;
-        int s = min(slot0 + qr, nq - 1);
-        const int gq = a.qlist ? a.qlist[s] : s;
-        qsrc[i] = a.queries + (size_t)gq * dim + c4 * 4;
-        qdst[i] = qr * LDT + c4 * 4;
-    }
     int cdst[CL], crow_off[CL], ccol[CL];
 #pragma unroll
     for (int i = 0; i < CL; ++i) {
         const int idx = tid + NT * i;
-        crow_off[i] = idx >> 3;
-        ccol[i] = (idx & 7) * 4;
+        crow_off[i] = idx / C4;
+        ccol[i] = (idx % C4) * 4;
         cdst[i] = crow_off[i] * LDT + ccol[i];
     }
 
     SelState st;
-    const int my_slot = slot0 + wave * 32 + (lane & 31);
+    const int my_slot = slot0 + wave * 32 + c;
     const bool my_valid = my_slot < nq;
     st.thr = my_valid ? -INFINITY : INFINITY;
     st.thr_row = 0u;
     st.cnt = 0;
     u64 *wbuf = bufs + (size_t)(wave * 32) * CAP;
-    u64 *qbuf = wbuf + (size_t)(lane & 31) * CAP;
+    u64 *qbuf = wbuf + (size_t)c * CAP;
 
-    const int h = lane >> 5, c = lane & 31;
+    // this lane's half of its query's stage (slots past the end read the last query; their lists are never written)
+    const float *qsrc;
+    {
+        const int sq = min(my_slot, nq - 1);
+        const int gq = a.qlist ? a.qlist[sq] : sq;
+        qsrc = a.queries + (size_t)gq * dim + h * QH;
+    }
+    float bq[QH];   // the stage's k-step pairs of the query operand: bq[s] = (k = 2 s | 2 s + 1)
+    auto q_pairs = [&](const float4 (&qreg)[Q4]) {
+        float r[QH];
+#pragma unroll
+        for (int i = 0; i < Q4; ++i) { r[4 * i] = qreg[i].x; r[4 * i + 1] = qreg[i].y; r[4 * i + 2] = qreg[i].z; r[4 * i + 3] = qreg[i].w; }
+#pragma unroll
+        for (int i = 0; i < QH / 2; ++i) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(r[2 * i]), __float_as_uint(r[2 * i + 1]), false, false);
+            bq[i] = __uint_as_float(sw[0]);
+            bq[QH / 2 + i] = __uint_as_float(sw[1]);
+        }
+    };
 
     for (int tile_row0 = row_begin; tile_row0 < row_end; tile_row0 += BN) {
         f32x16 acc[4];
@@ -121,22 +144,18 @@ __global__ __launch_bounds__(NW * 64) void exact_topk_kernel(ExactArgs a) {
             const int row = min(tile_row0 + crow_off[i], a.n - 1);
             csrc[i] = a.corpus + (size_t)row * dim + ccol[i];
         }
-        float4 qreg[QL], creg[CL];
+        float4 qreg[Q4], creg[CL];
 #pragma unroll
-        for (int i = 0; i < QL; ++i) qreg[i] = *reinterpret_cast<const float4 *>(qsrc[i]);
+        for (int i = 0; i < Q4; ++i) qreg[i] = *reinterpret_cast<const float4 *>(qsrc + 4 * i);
 #pragma unroll
         for (int i = 0; i < CL; ++i) creg[i] = *reinterpret_cast<const float4 *>(csrc[i]);
         __syncthreads();  // previous tile's readers are done with buffer 0
-#pragma unroll
-        for (int i = 0; i < QL; ++i) {
-            float *d = Qs + qdst[i];
-            d[0] = qreg[i].x; d[1] = qreg[i].y; d[2] = qreg[i].z; d[3] = qreg[i].w;
-        }
 #pragma unroll
         for (int i = 0; i < CL; ++i) {
             float *d = Cs + cdst[i];
             d[0] = creg[i].x; d[1] = creg[i].y; d[2] = creg[i].z; d[3] = creg[i].w;
         }
+        q_pairs(qreg);
         __syncthreads();
 
         for (int ks = 0; ks < nks; ++ks) {
@@ -145,23 +164,20 @@ __global__ __launch_bounds__(NW * 64) void exact_topk_kernel(ExactArgs a) {
             if (more) {
                 const int k0 = (ks + 1) * BK;
 #pragma unroll
-                for (int i = 0; i < QL; ++i) qreg[i] = *reinterpret_cast<const float4 *>(qsrc[i] + k0);
+                for (int i = 0; i < Q4; ++i) qreg[i] = *reinterpret_cast<const float4 *>(qsrc + k0 + 4 * i);
 #pragma unroll
                 for (int i = 0; i < CL; ++i) creg[i] = *reinterpret_cast<const float4 *>(csrc[i] + k0);
             }
-            const float *qrow = Qs + cur * BMQ * LDT + (wave * 32 + c) * LDT + h;
             const float *crow = Cs + cur * BN * LDT + c * LDT + h;
-            // The operands of k-step pair g + 1 are read BEFORE the eight MFMAs of pair g are issued: read right in front of
-            // their MFMAs (what hipcc makes of the plain loop) every group waits out an LDS round trip with the pipe draining
-            // (round 4: MFMA pipe busy 56 % of the launch). Two register sets, constant indices.
-            float bq[2][2], av[2][2][4];
+            // The corpus operands of k-step pair g + 1 are read BEFORE the eight MFMAs of pair g are issued: read right in
+            // front of their MFMAs (what hipcc makes of the plain loop) every group waits out an LDS round trip with the pipe
+            // draining. Two register sets, constant indices.
+            float av[2][2][4];
             auto load_pair = [&](int g, int set) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    bq[set][j] = qrow[2 * (2 * g + j)];
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) av[set][j][t] = crow[t * 32 * LDT + 2 * (2 * g + j)];
-                }
             };
             load_pair(0, 0);
 #pragma unroll
@@ -171,23 +187,18 @@ __global__ __launch_bounds__(NW * 64) void exact_topk_kernel(ExactArgs a) {
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][j][t], bq[g & 1][j], acc[t], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);   // the next pair's ten reads first ...
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][j][t], bq[2 * g + j], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    // the next pair's eight reads first ...
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);    // ... then this pair's MFMAs
             }
             if (more) {
-                float *qd = Qs + (cur ^ 1) * BMQ * LDT;
                 float *cd = Cs + (cur ^ 1) * BN * LDT;
-#pragma unroll
-                for (int i = 0; i < QL; ++i) {
-                    float *d = qd + qdst[i];
-                    d[0] = qreg[i].x; d[1] = qreg[i].y; d[2] = qreg[i].z; d[3] = qreg[i].w;
-                }
 #pragma unroll
                 for (int i = 0; i < CL; ++i) {
                     float *d = cd + cdst[i];
                     d[0] = creg[i].x; d[1] = creg[i].y; d[2] = creg[i].z; d[3] = creg[i].w;
                 }
+                q_pairs(qreg);   // (the MFMAs above have been issued: in-order issue, their operands are read)
             }
             __syncthreads();
         }
@@ -230,12 +241,12 @@ __global__ __launch_bounds__(NW * 64) void exact_topk_kernel(ExactArgs a) {
                 }
             }
             filter16<true>(acc[t], row0, st, qbuf, lane);
-            if (__any(st.cnt > LIMIT)) compact_wave<KP, E>(wbuf, st, lane, false);
+            if (__any(st.cnt > LIMIT)) compact_wave<KP, E, CAP>(wbuf, st, lane, false);
         }
     }
 
     // final: sorted top-KP of every query of this wave -> partial list
-    compact_wave<KP, E>(wbuf, st, lane, true);
+    compact_wave<KP, E, CAP>(wbuf, st, lane, true);
     for (int b = 0; b < 32; ++b) {
         const int slot = slot0 + wave * 32 + b;
         if (slot >= nq) break;
@@ -256,11 +267,11 @@ __global__ __launch_bounds__(NW * 64) void exact_topk_kernel(ExactArgs a) {
     }
 }
 
-template <int KP, int E, int NW>
+template <int KP, int E, int NW, int CAPV = 64 * E, int BK = 32>
 inline size_t exact_lds_bytes() {
-    constexpr int BMQ = NW * 32, BN = 128, LDT = 33;
-    size_t stage = (((size_t)(2 * BMQ * LDT + 2 * BN * LDT) * 4 + 15) & ~(size_t)15);
-    return stage + (size_t)BMQ * 64 * E * 8;
+    constexpr int BMQ = NW * 32, BN = 128, LDT = BK + 1;
+    size_t stage = (((size_t)(2 * BN * LDT) * 4 + 15) & ~(size_t)15);
+    return stage + (size_t)BMQ * CAPV * 8;
 }
 
 }  // namespace icd

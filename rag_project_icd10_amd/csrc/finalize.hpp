@@ -14,12 +14,19 @@
 namespace icd {
 
 constexpr int FIN_MAX_CAND = 512;  // P * KP
+constexpr int FIN_MAX_CAND_X = 2048;   // ... of the exact kernel's lists at k <= 64 (finalize<false, ., 4> only: 32 keys per lane; a short
+                                       // flagged list is cut into up to 2048 / KP row chunks so that every CU has a work-group)
 constexpr int FIN_MAX_K = 128;     // largest k of a search
 constexpr int FIN_MAX_T = 256;     // largest rescoring window (RESCORE): the best T coarse candidates, T/64 per lane
 constexpr int FIN_EF = FIN_MAX_CAND / 64;
+constexpr int FIN_EF_X = FIN_MAX_CAND_X / 64;
 #ifndef ICD_FIN_WALK
 #define ICD_FIN_WALK 8
 #endif
+#ifndef ICD_FIN_PAIR_WALK
+#define ICD_FIN_PAIR_WALK 8
+#endif
+constexpr int FIN_PAIR_WALK = ICD_FIN_PAIR_WALK;   // the same for the pair walk of wide windows (32-B half blocks; divides 96 and 128)
 constexpr int FIN_WALK = ICD_FIN_WALK;   // 64-B blocks of a row a lane keeps in flight per trip of the rescoring walk (divides 48 and 64)
 #ifndef ICD_FIN_OCC
 #define ICD_FIN_OCC 7
@@ -171,6 +178,11 @@ __device__ __forceinline__ int perm_row(int p, long long mul, int n, double inv)
     return (int)(((long long)p * mul) % n);
 }
 
+// the certification bound of one query (derivation: step 3 of finalize_kernel)
+__device__ __forceinline__ float fin_eps(const FinArgs &a, float qn, int qexp) {
+    return a.eps_rel * qn * a.rmax + a.eps_f32 * qn * a.rmax_unc + ldexpf((float)a.dim, qexp + a.cexp - 148);
+}
+
 // Load one query's candidates (NE per lane), rank them (rank_top) and scatter the best T, sorted, into sorted[].
 // Returns the number of valid candidates; tau picks up the score of the candidate of rank T (the best one left out).
 template <bool RESCORE, int NE>
@@ -213,6 +225,108 @@ __device__ __forceinline__ int fin_merge(const FinArgs &a, size_t pbase, int nca
         }
     }
     return nvalid;
+}
+
+// Rank ns keys staged at keys[0..ns) among themselves (E2 per lane) and write them, best first, to sorted[].
+template <int E2>
+__device__ __forceinline__ void fin_rank_staged(const u64 *keys, int ns, u64 *sorted, int lane) {
+    u64 mine[E2];
+    int rk[E2];
+#pragma unroll
+    for (int e = 0; e < E2; ++e) {
+        const int i = lane + 64 * e;
+        mine[e] = i < ns ? keys[i] : 0ull;
+        rk[e] = 0;
+    }
+    for (int j = 0; j < ns; ++j) {
+        const u64 kj = keys[j];   // (wave-uniform address: an LDS broadcast)
+#pragma unroll
+        for (int e = 0; e < E2; ++e) rk[e] += (kj > mine[e]) ? 1 : 0;
+    }
+#pragma unroll
+    for (int e = 0; e < E2; ++e)
+        if (mine[e] != 0ull) sorted[rk[e]] = mine[e];
+}
+
+// The merge of a WIDE rescoring window (T = 128 / 256: a family of near-identical rows, 128-512 candidates in 8-32 lists).
+// Ranking every candidate against every other (rank_top) is ncand^2 / 64 64-bit compares per lane: 384 candidates cost
+// 9 000 VALU instructions per query, 0.26 of the 0.32 ms the wide-window finalize took per 10 000 family queries (the
+// rescoring walk: 0.07). But the window is only the candidates within 2 eps of the k-th best, and a lower bound of that
+// score is cheap: the k-th largest of the 64 lane maxima (k distinct candidates reach it). Everything below
+// `that - 2 eps` is below the certification limit L whatever the k-th best turns out to be: it can neither enter the
+// window nor the result, and - being a KNOWN candidate below L - it does not raise tau. The survivors (the family: ~124)
+// are compacted and ranked among themselves; a survivor's rank among them IS its rank among all candidates. More
+// survivors than the window holds: the general path (exact top-T, the rest raises tau).
+// Returns the number of keys in sorted[] (the caller's nres).
+template <int NE>
+__device__ __forceinline__ int fin_merge_window(const FinArgs &a, size_t pbase, int ncand, int T, int k, float two_eps,
+                                                u64 *keys, u64 *sorted, int lane, float &tau) {
+    u64 key[NE];
+    int nvalid = 0;
+    {
+        int crow[NE];
+        float cscore[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int i = lane + 64 * e;
+            crow[e] = -1;
+            cscore[e] = 0.0f;
+            if (i < ncand) {
+                crow[e] = a.part_rows[pbase + i];
+                cscore[e] = a.part_scores[pbase + i];
+            }
+        }
+        if (a.perm_mod > 0) {
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+                if (crow[e] >= 0) crow[e] = perm_row(crow[e], a.perm_mul, a.perm_mod, a.perm_inv);
+        }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            key[e] = crow[e] >= 0 ? make_key(cscore[e], (uint32_t)crow[e]) : 0ull;
+            nvalid += __popcll(__ballot(key[e] != 0ull));
+        }
+    }
+    u64 lmax = 0ull;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) lmax = key[e] > lmax ? key[e] : lmax;
+    int above = 0;   // lanes whose maximum beats this lane's (keys are unique; empty lanes hold 0)
+    for (int l = 0; l < 64; ++l) above += (readlane_u64(lmax, l) > lmax) ? 1 : 0;
+    const u64 hit = __ballot(lmax != 0ull && above == k - 1);
+    float lb = -INFINITY;   // fewer than k non-empty lanes: keep everything
+    if (hit) {
+        lb = key_score(readlane_u64(lmax, __ffsll((long long)hit) - 1)) - two_eps;
+        lb = lb - fabsf(lb) * 1.2e-7f;   // (one ulp down, as for L)
+    }
+    const u64 lt = (1ull << lane) - 1ull;
+    int ns = 0;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const bool keep = key[e] != 0ull && key_score(key[e]) >= lb;
+        const u64 m = __ballot(keep);
+        if (keep) keys[ns + __popcll(m & lt)] = key[e];
+        ns += __popcll(m);
+    }
+    if (ns > T) {   // more near-ties than the window holds
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int i = lane + 64 * e;
+            if (i < ncand) keys[i] = key[e];
+        }
+        int rank[NE];
+        rank_top<NE>(key, rank, ncand, T, keys, lane);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            if (key[e] != 0ull) {
+                if (rank[e] < T) sorted[rank[e]] = key[e];
+                else if (rank[e] == T) tau = fmaxf(tau, key_score(key[e]));
+            }
+        }
+        return min(nvalid, T);
+    }
+    if (ns <= 128) fin_rank_staged<2>(keys, ns, sorted, lane);
+    else fin_rank_staged<4>(keys, ns, sorted, lane);
+    return ns;
 }
 
 // DEEP: (round 1-2: a deeper per-lane prefetch of the rescoring rows for small launches; the quad-cooperative walk below
@@ -294,10 +408,26 @@ __global__ __launch_bounds__(256, EWM == 1 ? ICD_FIN_OCC : 1) void finalize_kern
             if (bd > -INFINITY) tau = bd + fabsf(bd) * COARSE_KEY_SLACK;
         }
     }
-    int nvalid;
-    if (ncand <= 128) nvalid = fin_merge<RESCORE, 2>(a, pbase, ncand, T, keys, sorted, lane, tau);
-    else nvalid = fin_merge<RESCORE, FIN_EF>(a, pbase, ncand, T, keys, sorted, lane, tau);
-    int nres = min(nvalid, T);
+    int nres = 0;
+    bool merged = false;
+    if constexpr (RESCORE && EWM >= 4) {
+        if (T > 64) {   // (wave-uniform) a wide window: only what can be within 2 eps of the k-th best is ranked
+            const float two_eps = 2.0f * fin_eps(a, qn_early, qexp_early);
+            nres = ncand <= 128 ? fin_merge_window<2>(a, pbase, ncand, T, k, two_eps, keys, sorted, lane, tau)
+                                : fin_merge_window<FIN_EF>(a, pbase, ncand, T, k, two_eps, keys, sorted, lane, tau);
+            merged = true;
+        }
+    }
+    if (!merged) {
+        int nvalid;
+        if (ncand <= 128) nvalid = fin_merge<RESCORE, 2>(a, pbase, ncand, T, keys, sorted, lane, tau);
+        else if (!RESCORE && EWM >= 4 && ncand > FIN_MAX_CAND) {
+            if constexpr (!RESCORE && EWM >= 4) nvalid = fin_merge<false, FIN_EF_X>(a, pbase, ncand, T, keys, sorted, lane, tau);
+            else nvalid = 0;
+        }
+        else nvalid = fin_merge<RESCORE, FIN_EF>(a, pbase, ncand, T, keys, sorted, lane, tau);
+        nres = min(nvalid, T);
+    }
 
     if (RESCORE) {
         tau = wave_max_f32(tau);
@@ -322,7 +452,7 @@ __global__ __launch_bounds__(256, EWM == 1 ? ICD_FIN_OCC : 1) void finalize_kern
         //   (rmax); the canonical chain still runs on the uncentred rows, and its own accumulation error - relative to THEIR
         //   norm - is the second term (eps_f32 = 2 dim 2^-24 >= the chain's gamma_dim). q.mu is one constant per query: it
         //   shifts every coarse score of the query alike and never enters a comparison.
-        const float eps = a.eps_rel * qn_early * a.rmax + a.eps_f32 * qn_early * a.rmax_unc + ldexpf((float)a.dim, qexp_early + a.cexp - 148);
+        const float eps = fin_eps(a, qn_early, qexp_early);
         bool certified;
         float L;
         if (nres >= k) {
@@ -357,12 +487,15 @@ __global__ __launch_bounds__(256, EWM == 1 ? ICD_FIN_OCC : 1) void finalize_kern
         u64 xkey[EWM];
 #pragma unroll
         for (int e = 0; e < EWM; ++e) xkey[e] = 0ull;
+        int W = 0;
         {
-            int W = 0;
 #pragma unroll
             for (int e = 0; e < EWM; ++e) W += __popcll(__ballot(e < EW && mine[e] != 0ull && coarse[e] >= L));
             const int nblk = a.dim >> 4;   // 64-B blocks per row; a multiple of 8 for the fast path's dims (768, 1024)
-            if (EWM >= 4 && a.pair_walk && W > 32) {
+#ifdef ICD_ABLATE
+            if (a.pair_walk & 4) W = 0;   // (timing only: the kernel without its rescoring walk; results are wrong)
+#endif
+            if (EWM >= 4 && (a.pair_walk & 1) && W > 32) {
                 // WIDE window (a family of near-identical rows, up to 256 candidates): TWO lanes per row, 32 rows per pass (on rows
                 // gathered from all over the corpus - k = 20 on Gaussian data, ~23 rows - the 32-B pieces cost more than the
                 // second quad pass: +5 %, profiles/r04_k20_pair_walk_ab.log; on a family served from L2: -4 %). The
@@ -387,12 +520,12 @@ __global__ __launch_bounds__(256, EWM == 1 ? ICD_FIN_OCC : 1) void finalize_kern
                         t = __builtin_fmaf(qv.w, cv.w, t);                                           \
                         acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), ctrl, 0xf, 0xf, false)); \
                     }
-                    for (int b0 = 0; b0 < 2 * nblk; b0 += FIN_WALK) {   // 32-B half blocks
-                        f32x4 cvv[FIN_WALK];
+                    for (int b0 = 0; b0 < 2 * nblk; b0 += FIN_PAIR_WALK) {   // 32-B half blocks
+                        f32x4 cvv[FIN_PAIR_WALK];
 #pragma unroll
-                        for (int u = 0; u < FIN_WALK; ++u) cvv[u] = c4[2 * (b0 + u)];
+                        for (int u = 0; u < FIN_PAIR_WALK; ++u) cvv[u] = c4[2 * (b0 + u)];
 #pragma unroll
-                        for (int u = 0; u < FIN_WALK; ++u) {
+                        for (int u = 0; u < FIN_PAIR_WALK; ++u) {
                             const f32x4 cv = cvv[u];
                             const f32x4 qv = q4q[2 * (b0 + u)];
                             ICD_PAIR_STEP(0xA0)   // quad_perm [0,0,2,2]: both lanes continue from the even lane's four steps
@@ -472,7 +605,7 @@ __global__ __launch_bounds__(256, EWM == 1 ? ICD_FIN_OCC : 1) void finalize_kern
                 xr[0] += (readlane_u64(xkey[0], j) > xkey[0]) ? 1 : 0;
             }
         } else {
-            for (int j = 0; j < 64 * EW; ++j) {
+            for (int j = 0; j < W; ++j) {   // (the window is the prefix [0, W) of the coarse ranking: only those slots hold a key)
                 const u64 kj = keys[j];
 #pragma unroll
                 for (int e = 0; e < EWM; ++e) xr[e] += (kj > xkey[e]) ? 1 : 0;

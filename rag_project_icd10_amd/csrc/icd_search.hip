@@ -251,10 +251,10 @@ int pick_chunks(int mtiles, int row_tiles, int pmax, int slots) {
     return std::max(1, p);
 }
 
-template <int KP, int E, int NW>
+template <int KP, int E, int NW, int CAPV = 64 * E, int BK = 32, int OCC = 1>
 int launch_exact(icd_index *x, const ExactArgs &a, int mtiles, hipStream_t s) {
-    auto kern = exact_topk_kernel<KP, E, NW>;
-    const size_t lds = exact_lds_bytes<KP, E, NW>();
+    auto kern = exact_topk_kernel<KP, E, NW, CAPV, BK, OCC>;
+    const size_t lds = exact_lds_bytes<KP, E, NW, CAPV, BK>();
     static int configured[MAX_DEVICES] = {};   // (guarded by the caller's one-stream-per-handle contract; worst case a repeated call)
     HIP_TRY(ensure_dynamic_lds(kern, x->device, (size_t)((int)lds), configured));
     hipLaunchKernelGGL(kern, dim3(mtiles * a.P), dim3(NW * 64), lds, s, a);
@@ -375,7 +375,7 @@ int launch_stream(icd_index *x, const float *dq, const int *qlist, const int *nq
     a.ring_stages = stages;
     if ((size_t)a.nq * 4 * nwg * KP > x->lists_cap) return fail(ICD_ERR_INVALID, "stream workspace too small");
     for (int l = 0; l < levels; ++l) {
-        const size_t cap = (l % 2 == 0) ? x->partx_cap + (size_t)128 * FIN_MAX_CAND : x->lists_cap;
+        const size_t cap = (l % 2 == 0) ? x->partx_cap + (size_t)128 * FIN_MAX_CAND_X : x->lists_cap;
         if ((size_t)a.nq * plan[l] * KP > cap) return fail(ICD_ERR_INVALID, "stream workspace too small for reduction level %d", l);
     }
     auto kern = stream_topk_kernel<KP, E, QB>;
@@ -404,7 +404,7 @@ int launch_finalize_t(icd_index *x, const FinArgs &a, hipStream_t s) {
     auto kern = finalize_kernel<RESCORE, DEEP, EWM>;
     const size_t lds = 4 * fin_wave_lds_bytes(RESCORE, x->dim, a.lds_cand > 0 ? a.lds_cand : a.P * a.KP, EWM);
     static int configured[MAX_DEVICES] = {};   // (guarded by the caller's one-stream-per-handle contract; worst case a repeated call)
-    HIP_TRY(ensure_dynamic_lds(kern, x->device, (size_t)((int)(4 * fin_wave_lds_bytes(RESCORE, x->dim, FIN_MAX_CAND, EWM))), configured));
+    HIP_TRY(ensure_dynamic_lds(kern, x->device, (size_t)((int)(4 * fin_wave_lds_bytes(RESCORE, x->dim, (!RESCORE && EWM >= 4) ? FIN_MAX_CAND_X : FIN_MAX_CAND, EWM))), configured));
     hipLaunchKernelGGL(kern, dim3((a.nq + 3) / 4), dim3(256), lds, s, a);
     HIP_TRY(hipGetLastError());
     return ICD_OK;
@@ -415,6 +415,7 @@ int launch_finalize(icd_index *x, const FinArgs &a, hipStream_t s) {
     // one wave per query: up to ~28 waves per CU are resident, so a launch of a few thousand queries is a single
     // round of waves and its duration is one wave's latency: prefetch the rescoring rows deeper there
     const bool deep = RESCORE && a.nq <= 8 * x->num_cu;
+    if (!RESCORE && std::max(a.lds_cand, a.P * a.KP) > FIN_MAX_CAND) return launch_finalize_t<false, false, 4>(x, a, s);   // (32 keys per lane)
     if (a.k <= 32) return deep ? launch_finalize_t<RESCORE, true, 1>(x, a, s) : launch_finalize_t<RESCORE, false, 1>(x, a, s);
     return deep ? launch_finalize_t<RESCORE, true, 4>(x, a, s) : launch_finalize_t<RESCORE, false, 4>(x, a, s);
 }
@@ -468,11 +469,15 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
 
     // exact-kernel configuration (full run, or fallback over the flagged list)
     const int kpx = exact_kp_for(k);
-    const int nwx = kpx == 16 ? 4 : (kpx <= 64 ? 2 : 1);
+    const int nwx = kpx <= 64 ? 4 : 2;
+    const int wg_per_cu_x = kpx == 16 ? 2 : 1;   // work-groups of exact_topk a CU holds (its LDS)
     const int ex = kpx == 16 ? 1 : (kpx <= 64 ? 2 : 3);
     const int bmq = nwx * 32;
     const int mtx = (nq + bmq - 1) / bmq;
-    const int pmax_x = std::min(16, FIN_MAX_CAND / kpx);
+    // lists per query finalize<false> merges: 2048 candidates at k <= 64 (its top-k prefilter keeps that cheap), 512 above
+    const int cand_x = kpx <= 64 ? FIN_MAX_CAND_X : FIN_MAX_CAND;
+    const int pmax_x = std::min(64, cand_x / kpx);
+    const int p_dense_max = cand_x / kpx;   // chunk limit of the device-sized partition of a flagged list
     // sparse: streaming kernel (+ list reduction) instead of / next to the MFMA exact kernel
     // queries per pass: host-known for direct calls (1, 2, 4 or 8), 8 for the device-gated fallback
     const int p_sparse = FIN_MAX_CAND / kpx;   // lists per slot that finalize<false> merges (32 / 8 / 4)
@@ -517,7 +522,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             // the workspace like a full exact run; only the streaming kernel (<= ST_MAX_ACTIVE slots) uses px.
             int pm = px;
             if (stream) {
-                pm = pick_chunks(mtx, row_tiles, pmax_x, x->num_cu);
+                pm = pick_chunks(mtx, row_tiles, pmax_x, x->num_cu * wg_per_cu_x);
                 pm = fit_p(pm, x->partx_cap, kpx);
                 if ((size_t)nq * pm * kpx > x->partx_cap) return fail(ICD_ERR_INVALID, "workspace too small for nq=%d k=%d", nq, k);
                 const int tiles_per = (row_tiles + pm - 1) / pm;
@@ -527,21 +532,28 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             ExactArgs a{};
             a.corpus = x->corpus; a.queries = dq; a.qlist = qlist; a.nq_ptr = nq_ptr; a.nq = nq;
             a.min_active = stream ? sparse_here : 0;
-            a.adaptive_max_p = stream ? p_sparse : 0;   // fallback: the chunk count follows the actual flagged count
+            a.adaptive_max_p = stream ? p_dense_max : 0;   // fallback: the chunk count follows the actual flagged count
             a.n = (int)x->n; a.dim = x->dim; a.P = pm;
             a.rows_per_chunk = ((row_tiles + pm - 1) / pm) * 128;
             a.part_scores = x->partx_s; a.part_rows = x->partx_r;
-            if (kpx == 16) rc = launch_exact<16, 1, 4>(x, a, mtx, s);
-            else if (kpx == 32) rc = launch_exact<32, 2, 2>(x, a, mtx, s);
-            else if (kpx == 64) rc = launch_exact<64, 2, 2>(x, a, mtx, s);
-            else rc = launch_exact<128, 3, 1>(x, a, mtx, s);
+            // (LDS: k <= 16 two work-groups per CU - 17 KB of stage + 60-entry buffers; k <= 64 one of four waves - 34 KB +
+            //  112-entry buffers; larger k two waves)
+#ifdef ICD_ABLATE
+            if (kpx == 16 && getenv("ICD_EXACT_CFG") && atoi(getenv("ICD_EXACT_CFG")) == 1) rc = launch_exact<16, 1, 4>(x, a, mtx, s);
+            else if (kpx == 16 && getenv("ICD_EXACT_CFG") && atoi(getenv("ICD_EXACT_CFG")) == 2) rc = launch_exact<16, 1, 4, 64, 16, 1>(x, a, mtx, s);
+            else
+#endif
+            if (kpx == 16) rc = launch_exact<16, 1, 4, 60, 16, 2>(x, a, mtx, s);
+            else if (kpx == 32) rc = launch_exact<32, 2, 4, 112>(x, a, mtx, s);
+            else if (kpx == 64) rc = launch_exact<64, 2, 4, 112>(x, a, mtx, s);
+            else rc = launch_exact<128, 3, 2>(x, a, mtx, s);
             if (rc) return rc;
         }
         rec(x, 4, s);
         FinArgs g = f;
         g.part_scores = x->partx_s; g.part_rows = x->partx_r; g.P = px; g.KP = kpx;
-        g.P_dense = px_dense; g.sparse_max = sparse_here; g.track_run = track_run ? 1 : 0; g.lds_cand = std::max(px, stream ? p_sparse : px_dense) * kpx;
-        g.dense_grid = mtx * std::max(1, px_dense); g.dense_bmq = bmq; g.dense_max_p = (stream && mfma) ? p_sparse : 0; g.n_rows = (int)x->n;
+        g.P_dense = px_dense; g.sparse_max = sparse_here; g.track_run = track_run ? 1 : 0; g.lds_cand = std::max(px, (stream && mfma) ? p_dense_max : px_dense) * kpx;
+        g.dense_grid = mtx * std::max(1, px_dense); g.dense_bmq = bmq; g.dense_max_p = (stream && mfma) ? p_dense_max : 0; g.n_rows = (int)x->n;
         g.nq = nq; g.nq_ptr = nq_ptr; g.qlist = qlist;
         g.counters = x->nflag; g.host_counters = x->h_nflag_dev;   // (the last launch of every search: no separate copy)
         rc = launch_finalize<false>(x, g, s);
@@ -565,7 +577,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     }
     if (!use_fast) {
         HIP_TRY(hipMemsetAsync(x->nflag, 0, sizeof(int), s));
-        int px = pick_chunks(mtx, row_tiles, pmax_x, x->num_cu);
+        int px = pick_chunks(mtx, row_tiles, pmax_x, x->num_cu * wg_per_cu_x);
         px = fit_p(px, x->partx_cap, kpx);
         if ((size_t)nq * px * kpx > x->partx_cap) return fail(ICD_ERR_INVALID, "workspace too small for nq=%d k=%d", nq, k);
         {
@@ -831,6 +843,9 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         const bool wide_fin = wide_now && k <= 32 && pc * g.KP >= 128;
         if (wide_fin) g.wide_window = 1;
         g.pair_walk = g_pair_walk ? 1 : 0;
+#ifdef ICD_ABLATE
+        if (getenv("ICD_FIN_SKIP_WALK")) g.pair_walk |= 4;
+#endif
         if (wide_fin && g_family_order && nq >= 1024) {
             // every query's window is its family (the corpus is in code order): visit the queries family by family, XCD by XCD
             OrderArgs o{};
@@ -1065,8 +1080,8 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     if (exact_kp_for(max_k) > 16)   // multi-level reduction of the streaming kernel's lists: ST_MAX_ACTIVE slots x 512 lists
         x->partx_cap = std::max<size_t>(x->partx_cap, (size_t)ST_MAX_ACTIVE * 512 * exact_kp_for(max_k));
     // (+ one query tile of the widest layout: the device-chosen chunk count of the fallback rounds the slot count up)
-    CR_TRY(wsalloc(&x->partx_s, x->partx_cap + (size_t)128 * FIN_MAX_CAND));
-    CR_TRY(wsalloc(&x->partx_r, x->partx_cap + (size_t)128 * FIN_MAX_CAND));
+    CR_TRY(wsalloc(&x->partx_s, x->partx_cap + (size_t)128 * FIN_MAX_CAND_X));
+    CR_TRY(wsalloc(&x->partx_r, x->partx_cap + (size_t)128 * FIN_MAX_CAND_X));
     x->lists_cap = std::max((size_t)ST_MAX_ACTIVE * 1024 * exact_kp_for(max_k), (size_t)ST_FALLBACK_MAX_ACTIVE * 1024 * 16);
     CR_TRY(wsalloc(&x->lists_s, x->lists_cap));
     CR_TRY(wsalloc(&x->lists_r, x->lists_cap));

@@ -139,9 +139,8 @@ __device__ __forceinline__ void compact_one(u64 *qbuf, int nb, int lane, u64 &kt
 
 // Compact every query of this wave whose buffer could overflow in the next group (or all when
 // force is set). wbuf = this wave's 32 buffers, CAP apart.
-template <int KP, int E>
+template <int KP, int E, int CAP = 64 * E>
 __device__ __forceinline__ void compact_wave(u64 *wbuf, SelState &st, int lane, bool force) {
-    constexpr int CAP = 64 * E;
     constexpr int LIMIT = CAP - 32;
     uint32_t need = (uint32_t)__ballot(force ? (st.cnt > 0) : (st.cnt > LIMIT));
     while (need) {
