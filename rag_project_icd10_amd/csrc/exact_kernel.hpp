@@ -28,6 +28,11 @@ struct ExactArgs {
                            // S = min(adaptive_max_p, gridDim.x / active query tiles), lists laid out [slot][S][KP]
                            // (finalize.hpp recomputes S the same way). A short flagged list then spreads over many
                            // more work-groups than the worst-case (every query flagged) chunk count allows.
+    const float *thr0;     // nullable: [query] a score that k distinct rows of the corpus are known to reach (finalize.hpp: the
+                           // canonical scores of the query's k best coarse candidates). The lists then start at that threshold
+                           // instead of -inf: a chunk keeps only rows that can be in the top-k (ties with thr0 pass), and the
+                           // compaction storms of a list's first tiles - every row passes an empty list's threshold, 32 queries
+                           // are compacted every other 32-row group: more than the tiles' MFMA time - do not happen.
     float *part_scores;    // [slot][P][KP]
     int *part_rows;        // [slot][P][KP]
 };
@@ -117,6 +122,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void exact_topk_kernel(ExactArgs a) {
         const int sq = min(my_slot, nq - 1);
         const int gq = a.qlist ? a.qlist[sq] : sq;
         qsrc = a.queries + (size_t)gq * dim + h * QH;
+        if (a.thr0 && my_valid) {
+            const float t0 = a.thr0[gq];
+            if (t0 > -INFINITY) { st.thr = t0; st.thr_row = 0xFFFFFFFFu; }   // (rows that tie with it pass)
+        }
     }
     float bq[QH];   // the stage's k-step pairs of the query operand: bq[s] = (k = 2 s | 2 s + 1)
     auto q_pairs = [&](const float4 (&qreg)[Q4]) {

@@ -67,6 +67,9 @@ struct FinArgs {
     int cexp;                    // the corpus's scale exponent
     int *nflag;    // fallback counter
     int *flagged;  // fallback list
+    float *thr0;   // nullable, fast path: [query] an uncertified query leaves the smallest canonical score of its k best
+                   // coarse candidates here - k distinct rows reach it, so no row below it is in the top-k and the exact
+                   // re-search starts its lists at that threshold instead of -inf (exact_kernel.hpp)
     int *counters;         // nullable (last launch of a search): the search's four fallback counters (+ [4], the run length below) ...
     int track_run;         // finalize<false> of a fast-path search: counters[4] = consecutive searches whose re-search had nothing to do
     int *host_counters;    // ... are copied to this pinned host array by block 0 (icd_index_stats reads them after the stream's event)
@@ -181,6 +184,43 @@ __device__ __forceinline__ int perm_row(int p, long long mul, int n, double inv)
 // the certification bound of one query (derivation: step 3 of finalize_kernel)
 __device__ __forceinline__ float fin_eps(const FinArgs &a, float qn, int qexp) {
     return a.eps_rel * qn * a.rmax + a.eps_f32 * qn * a.rmax_unc + ldexpf((float)a.dim, qexp + a.cexp - 148);
+}
+
+// Canonical score of one corpus row, four lanes per row (the quad walk of step 4 of finalize_kernel): lane 4 g + qi loads
+// piece 4 b + qi of every 64-byte block b, all four lanes run their four fmaf from the same running value and adopt lane
+// 0's, 1's, 2's, 3's result in turn. Every lane of the quad returns the chain value (d ascending: the oracle's bits).
+__device__ __forceinline__ float fin_quad_row(const float *corpus, uint32_t row, int dim, const float *qvec, int qi) {
+    const int nblk = dim >> 4;
+    const f32x4 *c4 = reinterpret_cast<const f32x4 *>(corpus + (size_t)row * dim) + qi;
+    const f32x4 *q4q = reinterpret_cast<const f32x4 *>(qvec) + qi;
+    float acc = 0.0f;
+#define ICD_QUAD_STEP(ctrl)                                                                          \
+    {                                                                                                \
+        float t = acc;                                                                               \
+        t = __builtin_fmaf(qv.x, cv.x, t);                                                           \
+        t = __builtin_fmaf(qv.y, cv.y, t);                                                           \
+        t = __builtin_fmaf(qv.z, cv.z, t);                                                           \
+        t = __builtin_fmaf(qv.w, cv.w, t);                                                           \
+        acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), ctrl, 0xf, 0xf, false)); \
+    }
+    // (eight blocks = eight independent 16-B loads per lane in flight per trip; the inner trip count is a constant
+    //  because hipcc does not unroll a runtime-count loop around the convergent DPP move)
+    for (int b0 = 0; b0 < nblk; b0 += FIN_WALK) {
+        f32x4 cvv[FIN_WALK];
+#pragma unroll
+        for (int u = 0; u < FIN_WALK; ++u) cvv[u] = c4[4 * (b0 + u)];
+#pragma unroll
+        for (int u = 0; u < FIN_WALK; ++u) {
+            const f32x4 cv = cvv[u];
+            const f32x4 qv = q4q[4 * (b0 + u)];
+            ICD_QUAD_STEP(0x00)   // quad_perm [0,0,0,0]: everyone continues from lane 0's four steps
+            ICD_QUAD_STEP(0x55)   // [1,1,1,1]
+            ICD_QUAD_STEP(0xAA)   // [2,2,2,2]
+            ICD_QUAD_STEP(0xFF)   // [3,3,3,3]
+        }
+    }
+#undef ICD_QUAD_STEP
+    return acc;
 }
 
 // Load one query's candidates (NE per lane), rank them (rank_top) and scatter the best T, sorted, into sorted[].
@@ -466,9 +506,23 @@ __global__ __launch_bounds__(256, EWM == 1 ? ICD_FIN_OCC : 1) void finalize_kern
         }
         if (qbad_early) certified = false;
         if (!certified) {
+            float t0 = -INFINITY;
+            if (a.thr0 && nres >= k) {   // the canonical scores of the k best coarse candidates: k distinct rows reach their minimum
+                const int gi = lane >> 2, qi = lane & 3;
+                float mn = INFINITY;
+                for (int g0 = 0; g0 < k; g0 += 16) {
+                    const int r = g0 + gi;
+                    const float sc = fin_quad_row(a.corpus, key_row(sorted[r < k ? r : g0]), a.dim, qvec, qi);
+                    if (r < k) mn = (sc == sc) ? fminf(mn, sc) : -INFINITY;
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off));
+                t0 = mn;
+            }
             if (lane == 0) {
                 const int i = atomicAdd(a.nflag, 1);
                 a.flagged[i] = qidx;
+                if (a.thr0) a.thr0[qidx] = t0;
             }
             return;
         }
@@ -548,35 +602,7 @@ __global__ __launch_bounds__(256, EWM == 1 ? ICD_FIN_OCC : 1) void finalize_kern
             for (int g0 = 0; g0 < W; g0 += 16) {
                 const int r = g0 + gi;
                 const uint32_t row = key_row(sorted[r < W ? r : g0]);   // (past the window: a valid row, result unused)
-                const f32x4 *c4 = reinterpret_cast<const f32x4 *>(a.corpus + (size_t)row * a.dim) + qi;
-                const f32x4 *q4q = reinterpret_cast<const f32x4 *>(qvec) + qi;
-                float acc = 0.0f;
-#define ICD_QUAD_STEP(ctrl)                                                                          \
-                    {                                                                                \
-                        float t = acc;                                                               \
-                        t = __builtin_fmaf(qv.x, cv.x, t);                                           \
-                        t = __builtin_fmaf(qv.y, cv.y, t);                                           \
-                        t = __builtin_fmaf(qv.z, cv.z, t);                                           \
-                        t = __builtin_fmaf(qv.w, cv.w, t);                                           \
-                        acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), ctrl, 0xf, 0xf, false)); \
-                    }
-                // (eight blocks = eight independent 16-B loads per lane in flight per trip; the inner trip count is a constant
-                //  because hipcc does not unroll a runtime-count loop around the convergent DPP move)
-                for (int b0 = 0; b0 < nblk; b0 += FIN_WALK) {
-                    f32x4 cvv[FIN_WALK];
-#pragma unroll
-                    for (int u = 0; u < FIN_WALK; ++u) cvv[u] = c4[4 * (b0 + u)];
-#pragma unroll
-                    for (int u = 0; u < FIN_WALK; ++u) {
-                        const f32x4 cv = cvv[u];
-                        const f32x4 qv = q4q[4 * (b0 + u)];
-                        ICD_QUAD_STEP(0x00)   // quad_perm [0,0,0,0]: everyone continues from lane 0's four steps
-                        ICD_QUAD_STEP(0x55)   // [1,1,1,1]
-                        ICD_QUAD_STEP(0xAA)   // [2,2,2,2]
-                        ICD_QUAD_STEP(0xFF)   // [3,3,3,3]
-                    }
-                }
-#undef ICD_QUAD_STEP
+                const float acc = fin_quad_row(a.corpus, row, a.dim, qvec, qi);
                 // every lane of quad g holds the score of rank g0 + g: hand it to the lane (and element) that owns that rank
                 if (qi == 0) hand[gi] = acc;   // (same wave: LDS serves its operations in order)
                 const int e_g = g0 >> 6, l0 = g0 & 63;

@@ -135,6 +135,7 @@ struct icd_index {
     float *qnorm = nullptr;
     int *qexp = nullptr;
     unsigned char *qbad = nullptr;
+    float *thr0 = nullptr;   // [query] threshold an uncertified query hands to its exact re-search (finalize.hpp)
     unsigned int *shared_thr = nullptr;   // [max_nq_pad] coarse pass: per-query threshold shared by its lists
     long long perm_mul = 0; int perm_mod = 0;   // row order of the fp16 corpus: position p holds row (p * perm_mul) mod perm_mod
     float *partc_s = nullptr; int *partc_r = nullptr; float *partc_b = nullptr; size_t partc_cap = 0;   // coarse lists + bounds
@@ -203,7 +204,7 @@ bool valid(icd_index *idx) { return idx && idx->magic == 0x1CD10A3Du; }
 void free_all(icd_index *x) {
     if (!x) return;
     hipFree(x->corpus); hipFree(x->c16); hipFree(x->levels); hipFree(x->qdev); hipFree(x->q16);
-    hipFree(x->qnorm); hipFree(x->qexp); hipFree(x->qbad); hipFree(x->shared_thr); hipFree(x->partc_s); hipFree(x->partc_r); hipFree(x->partc_b); hipFree(x->partx_s);
+    hipFree(x->qnorm); hipFree(x->qexp); hipFree(x->qbad); hipFree(x->thr0); hipFree(x->shared_thr); hipFree(x->partc_s); hipFree(x->partc_r); hipFree(x->partc_b); hipFree(x->partx_s);
     hipFree(x->part2_s); hipFree(x->part2_r); hipFree(x->part2_b);
     hipFree(x->partx_r); hipFree(x->lists_s); hipFree(x->lists_r); hipFree(x->nflag); hipFree(x->flagged); hipFree(x->scratch_u32);
     hipFree(x->order); hipFree(x->order_key); hipFree(x->order_hist); hipFree(x->cmean);
@@ -462,6 +463,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     FinArgs f{};
     f.k = k; f.queries = dq; f.corpus = x->corpus; f.dim = x->dim; f.qnorm = x->qnorm; f.qbad = x->qbad;
     f.qexp = x->qexp; f.rmax = x->rmax_scaled; f.cexp = x->cexp; f.eps_rel = EPS_REL; f.nflag = x->nflag; f.flagged = x->flagged;
+    if (use_fast) f.thr0 = x->thr0;
     if (x->cmean) { f.rmax_unc = x->rmax_unc_scaled; f.eps_f32 = 2.0f * (float)x->dim * 5.9604645e-8f; }
     f.levels = x->levels; f.id_base = x->id_base;
     f.out_scores = o.scores; f.out_ids = o.ids; f.out_adj = o.adj; f.out_adj_raw = o.adj_raw;
@@ -505,7 +507,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         while (p > 1 && (size_t)nq * p * kp > cap) --p;
         return p;
     };
-    auto run_exact = [&](const int *qlist, const int *nq_ptr, int px, bool mfma, bool stream, bool stream_launch = true, bool track_run = false) -> int {
+    auto run_exact = [&](const int *qlist, const int *nq_ptr, int px, bool mfma, bool stream, bool stream_launch = true, bool track_run = false, const float *thr0 = nullptr) -> int {
         const int sparse_here = stream_launch ? sparse_max : 0;   // (streaming pair left out: the MFMA kernel takes every count >= 1)
         if (!nq_ptr) x->last_chunks = px;   // (the fallback keeps the coarse pass's chunk count)
         int rc = ICD_OK;
@@ -535,7 +537,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             a.adaptive_max_p = stream ? p_dense_max : 0;   // fallback: the chunk count follows the actual flagged count
             a.n = (int)x->n; a.dim = x->dim; a.P = pm;
             a.rows_per_chunk = ((row_tiles + pm - 1) / pm) * 128;
-            a.part_scores = x->partx_s; a.part_rows = x->partx_r;
+            a.part_scores = x->partx_s; a.part_rows = x->partx_r; a.thr0 = thr0;
             // (LDS: k <= 16 two work-groups per CU - 17 KB of stage + 60-entry buffers; k <= 64 one of four waves - 34 KB +
             //  112-entry buffers; larger k two waves)
 #ifdef ICD_ABLATE
@@ -922,9 +924,9 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         if ((size_t)nq * px * kpx > x->partx_cap) return fail(ICD_ERR_INVALID, "workspace too small for nq=%d k=%d", nq, k);
         const int tiles_per = (row_tiles + px - 1) / px;
         px = (row_tiles + tiles_per - 1) / tiles_per;
-        return run_exact(fl_list, fl_count, px, true, false, true, true);
+        return run_exact(fl_list, fl_count, px, true, false, true, true, f.thr0);
     }
-    return run_exact(fl_list, fl_count, p_sparse, true, stream_ok, !sparse_off, true);
+    return run_exact(fl_list, fl_count, p_sparse, true, stream_ok, !sparse_off, true, f.thr0);
 }
 
 }  // namespace
@@ -1074,6 +1076,7 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     CR_TRY(wsalloc(&x->qnorm, (size_t)x->max_nq_pad));
     CR_TRY(wsalloc(&x->qexp, (size_t)x->max_nq_pad));
     CR_TRY(wsalloc(&x->qbad, (size_t)x->max_nq_pad));
+    CR_TRY(wsalloc(&x->thr0, (size_t)x->max_nq_pad));
     CR_TRY(wsalloc(&x->shared_thr, (size_t)2 * x->max_nq_pad));   // [0]: first coarse pass, [1]: second
     CR_TRY(wsalloc(&x->qdev, (size_t)max_nq * dim));
     x->partx_cap = std::max<size_t>((size_t)x->max_nq_pad * 2 * exact_kp_for(max_k), (size_t)1 << 21);
