@@ -491,12 +491,13 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
                                                  kpx == 16 ? (size_t)ST_FALLBACK_MAX_ACTIVE : x->partx_cap / ((size_t)512 * kpx));
     auto run_stream = [&](const int *qlist, const int *nq_ptr, int nqs, int p_out, int *p_used) -> int {
         int qb = nq_ptr ? 8 : (nqs <= 1 ? 1 : (nqs <= 2 ? 2 : (nqs <= 4 ? 4 : 8)));
+        const int max_act = nq_ptr ? sparse_max : std::max(sparse_max, nqs);   // (a direct call - up to ST_MAX_ACTIVE queries - is not gated)
         while (qb > 1 && !stream_fits(kpx, qb, x->dim)) qb >>= 1;
 #define ICD_ST(KPV, EV) \
-        (qb == 1 ? launch_stream<KPV, EV, 1>(x, dq, qlist, nq_ptr, nqs, sparse_max, p_out, p_used, s) : \
-         qb == 2 ? launch_stream<KPV, EV, 2>(x, dq, qlist, nq_ptr, nqs, sparse_max, p_out, p_used, s) : \
-         qb == 4 ? launch_stream<KPV, EV, 4>(x, dq, qlist, nq_ptr, nqs, sparse_max, p_out, p_used, s) : \
-                   launch_stream<KPV, EV, 8>(x, dq, qlist, nq_ptr, nqs, sparse_max, p_out, p_used, s))
+        (qb == 1 ? launch_stream<KPV, EV, 1>(x, dq, qlist, nq_ptr, nqs, max_act, p_out, p_used, s) : \
+         qb == 2 ? launch_stream<KPV, EV, 2>(x, dq, qlist, nq_ptr, nqs, max_act, p_out, p_used, s) : \
+         qb == 4 ? launch_stream<KPV, EV, 4>(x, dq, qlist, nq_ptr, nqs, max_act, p_out, p_used, s) : \
+                   launch_stream<KPV, EV, 8>(x, dq, qlist, nq_ptr, nqs, max_act, p_out, p_used, s))
         if (kpx == 16) return ICD_ST(16, 2);
         if (kpx == 32) return ICD_ST(32, 2);
         if (kpx == 64) return ICD_ST(64, 3);

@@ -25,7 +25,7 @@ namespace icd {
 constexpr int ST_QB = 8;          // queries per pass (template QB <= ST_QB: fewer for tiny batches)
 constexpr int ST_PF = 1;          // dim must be a multiple of 32 * ST_PF
 constexpr int ST_MAX_ACTIVE = 64; // direct calls: batches up to this size take the streaming kernel (EXACT mode)
-constexpr int ST_FALLBACK_MAX_ACTIVE = 144;   // AUTO fallback: flagged lists up to this long (less for large k: workspace). One sweep per 8 queries costs ~37 us at 37 000 rows, the MFMA kernel ~0.68 ms for any count up to a few thousand: they meet near 146 (profiles/r03_sparse_fallback_policy.log)
+constexpr int ST_FALLBACK_MAX_ACTIVE = 40;    // AUTO fallback: flagged lists up to this long (less for large k: workspace). One sweep per 8 queries costs ~37 us at 37 000 rows; the MFMA kernel, its short flagged list cut into up to 2048 / KP row chunks, ~0.22 ms for any count up to a few hundred even when the handed-over threshold is useless (all-zero queries): they meet near 45 (profiles/r04_sparse_fallback_policy.log; round 3, 16 chunks at most: 0.68 ms, 146)
 constexpr int ST_STAGE_BYTES = 8192;   // one wave stage: 64 rows x 32 floats
 constexpr int ST_PAD_ROWS = 512;       // zero rows the index keeps behind the corpus (stages may run past n)
 

@@ -60,7 +60,7 @@ def main():
         print(f"  all four launches (armed={st['sparse_fallback_armed']}, second pass armed={st['second_pass_armed']}): {t_all:.4f}   "
               f"streaming pair left out (armed={st2['sparse_fallback_armed']}, second pass armed={st2['second_pass_armed']}): {t_two:.4f}   saved {1e3 * (t_all - t_two):.1f} us")
     print("a batch with unanswerable (all-zero) queries, ms for that one search:")
-    for bad in (1, 8, 64, 128, 144, 145, 256, 512):
+    for bad in (1, 8, 32, 40, 41, 64, 128, 256, 512):
         dirty = dq.clone()
         dirty[torch.arange(bad, device="cuda") * 17] = 0
         row = []
