@@ -540,7 +540,8 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             a.rows_per_chunk = ((row_tiles + pm - 1) / pm) * 128;
             a.part_scores = x->partx_s; a.part_rows = x->partx_r; a.thr0 = thr0;
             // (LDS: k <= 16 two work-groups per CU - 17 KB of stage + 60-entry buffers; k <= 64 one of four waves - 34 KB +
-            //  112-entry buffers; larger k two waves)
+            //  112-entry buffers; larger k two waves. Eight waves on 64-entry buffers at k <= 32 - two per SIMD - were built and
+            //  are slower, 9.2 against 7.2 ms per 10 000 queries: a 64-entry buffer with 32 kept is compacted after every append)
 #ifdef ICD_ABLATE
             if (kpx == 16 && getenv("ICD_EXACT_CFG") && atoi(getenv("ICD_EXACT_CFG")) == 1) rc = launch_exact<16, 1, 4>(x, a, mtx, s);
             else if (kpx == 16 && getenv("ICD_EXACT_CFG") && atoi(getenv("ICD_EXACT_CFG")) == 2) rc = launch_exact<16, 1, 4, 64, 16, 1>(x, a, mtx, s);
