@@ -674,24 +674,18 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         if (const char *e = getenv("ICD_FLAT_BOOT")) a.boot_tiles = std::max(0, atoi(e));   // A/B: bootstrap tiles
         if (const char *e = getenv("ICD_FLAT_SPARSE")) a.sparse_from = std::max(0, atoi(e));   // A/B: first tile of a list with the group pre-filter
 #endif
-        if (x->chunks_override > 0 || wide_now) {   // test hook / wide mode: about `chunks` lists per query
-            const int chunks = x->chunks_override > 0 ? x->chunks_override : PASS2_CHUNKS;
-            U = std::max(1, (ctiles + chunks - 1) / chunks);
-            if (wide_now && x->chunks_override == 0) {
-                // The wide partition is several ROUNDS of work-groups (79 query tiles x 319 tiles / 16 = 1 576 of them on 256
-                // CUs: 6.15 rounds, the seventh 15 % full): among the list lengths that keep 17 ... 23 lists per query take the
-                // one whose last round is fullest (here 17 tiles: 5.8 rounds).
-                double best = -1.0;
-                int best_u = U;
-                for (int u = std::max(1, ctiles / 23); u <= (ctiles + 16) / 17; ++u) {
-                    const long long wgs = ((long long)mtc * ctiles + u - 1) / u;
-                    const long long rounds = (wgs + x->num_cu - 1) / x->num_cu;
-                    const double eff = (double)wgs / (double)(rounds * x->num_cu);
-                    if (eff > best + 0.02 || (eff > best - 0.02 && std::abs(u - U) < std::abs(best_u - U))) { best = std::max(best, eff); best_u = u; }
-                }
-                U = best_u;
-            }
+        if (x->chunks_override > 0) {   // test hook: about `chunks` lists per query, every work-group's run one list
+            U = std::max(1, (ctiles + x->chunks_override - 1) / x->chunks_override);
             a.list_tiles = ctiles;
+        } else if (wide_now) {
+            // Wide mode: about PASS2_CHUNKS lists per query, cut out of the SAME long sweeps as the narrow plan (a work-group
+            // keeps its queries in registers and its ring running over ~100 tiles and closes a list every 16). Until round 4
+            // every list was its own work-group (1 576 of them, six rounds on 256 CUs, each loading its queries and refilling
+            // the ring): 0.67 against 0.60 ms on the family corpus, same lists (profiles/r04_wide_long_sweeps.log).
+            a.list_tiles = std::max(1, (ctiles + PASS2_CHUNKS - 1) / PASS2_CHUNKS);
+#ifdef ICD_ABLATE
+            if (getenv("ICD_WIDE_SHORT_SWEEP")) { U = a.list_tiles; a.list_tiles = ctiles; }   // A/B: round 3's partition
+#endif
         }
         auto lists_needed_lt = [&](int u, int list_tiles) {   // the largest number of lists of any query tile (same rule as the kernel)
             int worst = 0;
