@@ -283,10 +283,9 @@ int icd_debug_set_permute(int32_t enabled);
  * identical either way, and later searches keep deciding from their own counters. */
 int icd_debug_set_create_probe(int32_t enabled);
 
-/* Test switch, process-wide, read by every search (default 3 = both bits): bit 0 clear keeps the wide-window finalize of a
- * family-shaped corpus (icd_stats.wide_mode) in batch order instead of visiting the queries family by family, XCD by XCD
- * (finalize.hpp, order_keys_kernel / order_scatter_kernel); bit 1 clear walks wide rescoring windows four lanes per row
- * instead of two. Performance decisions only: results are identical either way. */
+/* Test switch, process-wide, read by every search (default 1): 0 keeps the wide-window finalize of a family-shaped corpus
+ * (icd_stats.wide_mode) in batch order instead of visiting the queries family by family, XCD by XCD (finalize.hpp,
+ * order_keys_kernel / order_scatter_kernel). A performance decision only: results are identical either way. */
 int icd_debug_set_family_order(int32_t enabled);
 
 /* Test switch, process-wide, read by icd_index_create (default 1): 0 keeps the fp16 corpus image uncentred whatever the

@@ -23,10 +23,6 @@ constexpr int FIN_EF_X = FIN_MAX_CAND_X / 64;
 #ifndef ICD_FIN_WALK
 #define ICD_FIN_WALK 8
 #endif
-#ifndef ICD_FIN_PAIR_WALK
-#define ICD_FIN_PAIR_WALK 8
-#endif
-constexpr int FIN_PAIR_WALK = ICD_FIN_PAIR_WALK;   // the same for the pair walk of wide windows (32-B half blocks; divides 96 and 128)
 constexpr int FIN_WALK = ICD_FIN_WALK;   // 64-B blocks of a row a lane keeps in flight per trip of the rescoring walk (divides 48 and 64)
 #ifndef ICD_FIN_OCC
 #define ICD_FIN_OCC 7
@@ -47,7 +43,7 @@ struct FinArgs {
     int lists_by_query; // with qlist: the lists (and bounds) of slot s belong to query qlist[s] and sit at that query's index
     int skip_below;     // with qlist + nq_ptr: at most this many slots -> this stage is skipped; the slot list is handed on
                         // unchanged to the stage behind it (flagged / nflag), which is cheaper for a handful of queries
-    int pair_walk;      // wide-window instantiation: windows of more than 32 rows are walked two lanes per row (else four)
+    int skip_walk;      // ablation builds only: skip the rescoring walk (timing; results are wrong)
     int wide_window;    // fast path: rescoring window as wide as the instantiation allows (second chance of a query whose
                         // first window overflowed with near-ties), not the one sized for k
     int nq;             // slots (upper bound if nq_ptr)
@@ -535,9 +531,11 @@ __global__ __launch_bounds__(256, EWM == 1 ? ICD_FIN_OCC : 1) void finalize_kern
         // within a block all four lanes run their four fmaf from the SAME running value, then the quad adopts lane 0's
         // result, repeats and adopts lane 1's, ... (one DPP quad broadcast per step; three of the four lanes' arithmetic is
         // discarded each time, VALU slots this kernel has to spare). Same fmaf order, d ascending: the same bits.
-        // (Round 4: for WIDE windows - a 124-row family - one lane per row, 64 rows per pass, has a fifth of the VALU work;
-        //  measured SLOWER, 0.51 against 0.32 ms per 10 000 family queries: 64 different rows per load instruction are 64
-        //  cache lines per instruction and the CU's waves evict each other's lines from its 32 KB L1.)
+        // (Round 4, WIDE windows - a 124-row family: one lane per row, 64 rows per pass, has a fifth of the VALU work and was
+        //  measured SLOWER, 0.51 against 0.32 ms per 10 000 family queries - 64 different rows per load instruction are 64
+        //  cache lines per instruction and the CU's waves evict each other's lines from its 32 KB L1; two lanes per row
+        //  gained 4 % while the all-pairs merge was the larger cost and loses 12 % since it is not (0.27 against 0.24 ms);
+        //  walking the window in ROW order so that the four waves of a work-group touch the same rows together: 0.38.)
         u64 xkey[EWM];
 #pragma unroll
         for (int e = 0; e < EWM; ++e) xkey[e] = 0ull;
@@ -545,58 +543,9 @@ __global__ __launch_bounds__(256, EWM == 1 ? ICD_FIN_OCC : 1) void finalize_kern
         {
 #pragma unroll
             for (int e = 0; e < EWM; ++e) W += __popcll(__ballot(e < EW && mine[e] != 0ull && coarse[e] >= L));
-            const int nblk = a.dim >> 4;   // 64-B blocks per row; a multiple of 8 for the fast path's dims (768, 1024)
 #ifdef ICD_ABLATE
-            if (a.pair_walk & 4) W = 0;   // (timing only: the kernel without its rescoring walk; results are wrong)
+            if (a.skip_walk) W = 0;   // (timing only: the kernel without its rescoring walk; results are wrong)
 #endif
-            if (EWM >= 4 && (a.pair_walk & 1) && W > 32) {
-                // WIDE window (a family of near-identical rows, up to 256 candidates): TWO lanes per row, 32 rows per pass (on rows
-                // gathered from all over the corpus - k = 20 on Gaussian data, ~23 rows - the 32-B pieces cost more than the
-                // second quad pass: +5 %, profiles/r04_k20_pair_walk_ab.log; on a family served from L2: -4 %). The
-                // same scheme as the quad walk below with half its redundancy: lane 2 g + i loads piece 2 b + i of every 32-B
-                // half block b of row g, both lanes run their four fmaf from the same running value, the pair adopts lane
-                // 0's result, repeats and adopts lane 1's (quad_perm [0,0,2,2] / [1,1,3,3]): 10 VALU per 8 dimensions as in
-                // the quad walk, but for twice the rows per pass. Same fmaf order, d ascending: the same bits.
-                const int gi = lane >> 1, qi = lane & 1;
-                float *hand = reinterpret_cast<float *>(adjbuf);   // (free until emit_outputs)
-                for (int g0 = 0; g0 < W; g0 += 32) {
-                    const int r = g0 + gi;
-                    const uint32_t row = key_row(sorted[r < W ? r : g0]);
-                    const f32x4 *c4 = reinterpret_cast<const f32x4 *>(a.corpus + (size_t)row * a.dim) + qi;
-                    const f32x4 *q4q = reinterpret_cast<const f32x4 *>(qvec) + qi;
-                    float acc = 0.0f;
-#define ICD_PAIR_STEP(ctrl)                                                                          \
-                    {                                                                                \
-                        float t = acc;                                                               \
-                        t = __builtin_fmaf(qv.x, cv.x, t);                                           \
-                        t = __builtin_fmaf(qv.y, cv.y, t);                                           \
-                        t = __builtin_fmaf(qv.z, cv.z, t);                                           \
-                        t = __builtin_fmaf(qv.w, cv.w, t);                                           \
-                        acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), ctrl, 0xf, 0xf, false)); \
-                    }
-                    for (int b0 = 0; b0 < 2 * nblk; b0 += FIN_PAIR_WALK) {   // 32-B half blocks
-                        f32x4 cvv[FIN_PAIR_WALK];
-#pragma unroll
-                        for (int u = 0; u < FIN_PAIR_WALK; ++u) cvv[u] = c4[2 * (b0 + u)];
-#pragma unroll
-                        for (int u = 0; u < FIN_PAIR_WALK; ++u) {
-                            const f32x4 cv = cvv[u];
-                            const f32x4 qv = q4q[2 * (b0 + u)];
-                            ICD_PAIR_STEP(0xA0)   // quad_perm [0,0,2,2]: both lanes continue from the even lane's four steps
-                            ICD_PAIR_STEP(0xF5)   // [1,1,3,3]
-                        }
-                    }
-#undef ICD_PAIR_STEP
-                    if (qi == 0) hand[gi] = acc;   // (same wave: LDS serves its operations in order)
-                    const int e_g = g0 >> 6, l0 = g0 & 63;
-                    if (lane >= l0 && lane < l0 + 32 && g0 + (lane - l0) < W) {
-                        const float sc = hand[lane - l0];
-#pragma unroll
-                        for (int e = 0; e < EWM; ++e)
-                            if (e == e_g && sc == sc && sc != -INFINITY) xkey[e] = make_key(sc, key_row(mine[e]));
-                    }
-                }
-            } else {
             const int gi = lane >> 2, qi = lane & 3;
             float *hand = reinterpret_cast<float *>(adjbuf);   // (free until emit_outputs)
             for (int g0 = 0; g0 < W; g0 += 16) {
@@ -612,7 +561,6 @@ __global__ __launch_bounds__(256, EWM == 1 ? ICD_FIN_OCC : 1) void finalize_kern
                     for (int e = 0; e < EWM; ++e)
                         if (e == e_g && sc == sc && sc != -INFINITY) xkey[e] = make_key(sc, key_row(mine[e]));
                 }
-            }
             }
         }
         // 5. rank the rescored candidates and keep the best k

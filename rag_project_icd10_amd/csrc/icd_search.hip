@@ -40,8 +40,7 @@ thread_local std::string g_err = "";
 bool g_permute = true;   // test switch (icd_debug_set_permute): row order of the fp16 corpus copy
 bool g_probe = true;     // test switch (icd_debug_set_create_probe): the corpus-shape probe of icd_index_create
 bool g_center = true;         // test switch (icd_debug_set_center): the fp16 corpus image is centred when the rows share a large common component
-bool g_family_order = true;
-bool g_pair_walk = true;      // test switch (icd_debug_set_family_order, bit 1): wide windows walked two lanes per row   // test switch (icd_debug_set_family_order): the wide-window finalize visits the queries in family order
+bool g_family_order = true;   // test switch (icd_debug_set_family_order): the wide-window finalize visits the queries in family order
 
 int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -840,9 +839,8 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         // every query at once, and the retry below has nothing to add.
         const bool wide_fin = wide_now && k <= 32 && pc * g.KP >= 128;
         if (wide_fin) g.wide_window = 1;
-        g.pair_walk = g_pair_walk ? 1 : 0;
 #ifdef ICD_ABLATE
-        if (getenv("ICD_FIN_SKIP_WALK")) g.pair_walk |= 4;
+        if (getenv("ICD_FIN_SKIP_WALK")) g.skip_walk = 1;
 #endif
         if (wide_fin && g_family_order && nq >= 1024) {
             // every query's window is its family (the corpus is in code order): visit the queries family by family, XCD by XCD
@@ -1358,7 +1356,6 @@ int icd_debug_set_center(int32_t enabled) {
 
 int icd_debug_set_family_order(int32_t enabled) {
     g_family_order = (enabled & 1) != 0;
-    g_pair_walk = (enabled & 2) != 0;
     return ICD_OK;
 }
 

@@ -1,5 +1,5 @@
 """A/B of the wide-window finalize on the family corpus (300 x 124 rows, cosine 0.99, 10 000 queries, k = 10 / 20):
-icd_debug_set_family_order bits: 0 = batch order + quad walk (round 3), 1 = family order, 2 = pair walk, 3 = both."""
+icd_debug_set_family_order: 0 = batch order (round 3), 1 = family order (shipped)."""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,7 +16,7 @@ ref = None
 for k in (10, 20):
     idx = IcdIndex(corpus, levels, max_nq=10000, max_k=20)
     for rnd in range(2):
-        for bits in (0, 1, 2, 3):
+        for bits in (0, 1):
             lib.icd_debug_set_family_order(bits)
             for _ in range(3):
                 out = idx.search_reweighted(dq, k, MODE_AUTO)
@@ -32,5 +32,5 @@ for k in (10, 20):
                 ref = (k, out)
             same = all(torch.equal(a, b) for a, b in zip(out, ref[1]))
             print(f"k={k} bits={bits}: {dt:.3f} ms | coarse {p['ms_coarse']:.3f} finalize {p['ms_finalize']:.3f} | wide {st['wide_mode']} fallback {st['last_fallback']} same_as_first {same}", flush=True)
-    lib.icd_debug_set_family_order(3)
+    lib.icd_debug_set_family_order(1)
     idx.close()
