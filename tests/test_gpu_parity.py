@@ -1038,3 +1038,43 @@ def test_anisotropic_embeddings_are_certified_on_a_centred_image(oracle, k):
     idx = IcdIndex(unit_rows(3000, 768, 33), icd_levels(3000, 34), max_nq=64, max_k=10)
     assert idx.stats()["centered"] == 0 and idx.stats()["mean_share"] < 0.05
     idx.close()
+
+
+@pytest.mark.parametrize("flagged,k", [(41, 10), (120, 10), (300, 20), (700, 20)])
+def test_short_flagged_lists_take_the_chunked_exact_research(oracle, flagged, k):
+    """A family of 400 near-identical rows is larger than any rescoring window (256): the queries that land in it cannot be
+    certified from candidate lists and take the exact re-search - more than 40 of them the fp32-MFMA kernel, whose short
+    flagged list is cut into up to 2 048 / KP row chunks (finalize<false, ., 4> merges them) and whose lists start at the
+    threshold finalize hands over (the exact score of the query's k-th coarse candidate; ties with it must pass: the
+    family's scores tie in many bits). Every flagged query and a sample of the others against the oracle, bit for bit."""
+    import torch
+    rng = np.random.default_rng(90 + flagged)
+    n, nq, dim, fam = 37000, 10000, 768, 400
+    corpus = unit_rows(n, dim, 91)
+    f = rng.standard_normal(dim).astype(np.float32)
+    f /= np.linalg.norm(f)
+
+    def near(m):
+        x = f[None, :] + (0.02 / np.sqrt(dim)) * rng.standard_normal((m, dim)).astype(np.float32)
+        return np.ascontiguousarray(x / np.linalg.norm(x, axis=1, keepdims=True), dtype=np.float32)
+
+    at = rng.choice(n, fam, replace=False)
+    corpus[at] = near(fam)
+    corpus[at[:8]] = corpus[at[8]]                      # exact duplicates inside the family: score ties, decided by the row id
+    queries = unit_rows(nq, dim, 92)
+    where = rng.choice(nq, flagged, replace=False)
+    queries[where] = near(flagged)
+    levels = icd_levels(n, 93)
+    check = np.concatenate([where, rng.choice(nq, 64, replace=False)])
+    os_, oi = oracle.flat_ip_topk(corpus, queries[check], k)
+    want = oracle.reweight(os_, oi, levels)
+    idx = IcdIndex(corpus, levels, max_nq=nq, max_k=k)
+    dq = torch.from_numpy(queries).cuda()
+    for _ in range(2):
+        adj, raw, ids, lv = idx.search_reweighted(dq, k)
+    torch.cuda.synchronize()
+    st = idx.stats()
+    assert st["last_mode"] == MODE_AUTO and flagged <= st["last_fallback"] <= flagged + 8, st
+    assert np.array_equal(ids.cpu().numpy()[check], want[2])
+    assert _bits(adj.cpu().numpy()[check]) == _bits(want[0]) and _bits(raw.cpu().numpy()[check]) == _bits(want[1])
+    idx.close()
