@@ -852,9 +852,9 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             o.key = x->order_key; o.hist = x->order_hist; o.order = x->order;
             // (the scatter kernel leaves the histogram zero again; a search that failed between the two launches would not:
             //  cleared here, 4 KB, so that a stale count can never push a position past the order buffer)
-            HIP_TRY(hipMemsetAsync(x->order_hist, 0, ORDER_BUCKETS * sizeof(unsigned int), s));
+            HIP_TRY(hipMemsetAsync(x->order_hist, 0, 2 * ORDER_BUCKETS * sizeof(unsigned int), s));
             hipLaunchKernelGGL(order_keys_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, o);
-            hipLaunchKernelGGL(order_scatter_kernel, dim3(1), dim3(1024), 0, s, o);
+            hipLaunchKernelGGL(order_scatter_kernel, dim3((nq + 1023) / 1024), dim3(1024), 0, s, o);
             HIP_TRY(hipGetLastError());
             g.qlist = x->order; g.lists_by_query = 1; g.nq = 4 * ((nq + 3) / 4);
         }
@@ -1093,8 +1093,8 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     CR_TRY(wsalloc(&x->flagged, (size_t)3 * x->max_nq_pad));
     CR_TRY(wsalloc(&x->order, (size_t)x->max_nq_pad + 8));
     CR_TRY(wsalloc(&x->order_key, (size_t)x->max_nq_pad));
-    CR_TRY(wsalloc(&x->order_hist, (size_t)ORDER_BUCKETS));
-    CR_TRY(hipMemset(x->order_hist, 0, ORDER_BUCKETS * sizeof(unsigned int)));
+    CR_TRY(wsalloc(&x->order_hist, (size_t)2 * ORDER_BUCKETS));
+    CR_TRY(hipMemset(x->order_hist, 0, 2 * ORDER_BUCKETS * sizeof(unsigned int)));
     const size_t no = (size_t)max_nq * max_k;
     CR_TRY(wsalloc(&x->o_scores, no)); CR_TRY(wsalloc(&x->o_ids, no)); CR_TRY(wsalloc(&x->o_adj, no));
     CR_TRY(wsalloc(&x->o_adj_raw, no)); CR_TRY(wsalloc(&x->o_adj_ids, no)); CR_TRY(wsalloc(&x->o_adj_lv, no));
