@@ -24,6 +24,7 @@ struct ExactArgs {
     int dim;               // multiple of 32
     int P;                 // corpus chunks
     int rows_per_chunk;    // multiple of 128
+    int adaptive_one_per_cu;   // with adaptive_max_p: the CU count when a CU holds two work-groups of this kernel, else 0 (exact_adaptive_chunks)
     int adaptive_max_p;    // > 0 (with nq_ptr): choose the chunk count on the device from the actual slot count:
                            // S = min(adaptive_max_p, gridDim.x / active query tiles), lists laid out [slot][S][KP]
                            // (finalize.hpp recomputes S the same way). A short flagged list then spreads over many
@@ -38,11 +39,17 @@ struct ExactArgs {
 };
 
 // chunk count of the adaptive layout (device: exact_topk_kernel; the same call in finalize.hpp)
-__host__ __device__ inline int exact_adaptive_chunks(int nq_active, int bmq, int grid, int max_p, int n_rows) {
+// one_per_cu > 0 (kernels of which a CU holds two work-groups): when the list limit max_p caps the count somewhere between
+// one and two work-groups per CU, take exactly one per CU - 320 work-groups on 256 CUs leave 64 CUs with two that share
+// their MFMA pipes and finish last (measured: 0.55 against 0.45 ms for a 568-query re-search)
+__host__ __device__ inline int exact_adaptive_chunks(int nq_active, int bmq, int grid, int max_p, int n_rows, int one_per_cu = 0) {
     const int mtiles = (nq_active + bmq - 1) / bmq;
     const int row_tiles = (n_rows + 127) / 128;
     int p = mtiles > 0 ? grid / mtiles : 1;
-    p = p < max_p ? p : max_p;
+    if (p > max_p) {
+        p = max_p;
+        if (one_per_cu > 0 && mtiles * p > one_per_cu && mtiles <= one_per_cu) p = one_per_cu / mtiles;
+    }
     p = p < row_tiles ? p : row_tiles;
     return p > 1 ? p : 1;
 }
@@ -57,11 +64,14 @@ __host__ __device__ inline int exact_adaptive_chunks(int nq_active, int bmq, int
 // (k = BK / 2 + 2 i | BK / 2 + 2 i + 1) in r[2 i + 1] - pair BK / 4 + i. (Round 4; before, the queries were staged like the
 // corpus rows: 34 KB of LDS, half of the scalar LDS writes of a stage, and with the 64-KB candidate buffers of k > 16 only
 // two waves fitted a CU: `--mode exact` at k = 20 ran at 0.27 of the fp32 MFMA peak against 0.59 at k = 10.)
-template <int KP, int E, int NW, int CAPV = 64 * E, int BK = 32, int OCC = 1>
+// GROUP: rows of a 32-row block tested between two overflow checks (32, or 16: two half blocks, for buffers with little room
+// above KP)
+template <int KP, int E, int NW, int CAPV = 64 * E, int BK = 32, int OCC = 1, int GROUP = 32>
 __global__ __launch_bounds__(NW * 64, OCC) void exact_topk_kernel(ExactArgs a) {
     constexpr int BMQ = NW * 32, BN = 128, LDT = BK + 1, NT = NW * 64;
-    constexpr int CAP = CAPV, LIMIT = CAP - 32;
-    static_assert(CAP <= 64 * E && LIMIT >= KP && CAP % 2 == 0, "candidate buffer: KP kept + 32 appended per group, E keys per lane");
+    constexpr int CAP = CAPV, LIMIT = CAP - GROUP;
+    static_assert(GROUP == 32 || GROUP == 16, "a whole 32-row block or half of one per overflow check");
+    static_assert(CAP <= 64 * E && LIMIT >= KP && CAP % 2 == 0, "candidate buffer: KP kept + GROUP appended per check, E keys per lane");
     static_assert(BK == 16 || BK == 32, "stage depth");
     constexpr int C4 = BK / 4;             // float4 per corpus row and stage
     constexpr int CL = (BN * C4) / NT;     // corpus float4 loads per thread per stage
@@ -76,7 +86,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void exact_topk_kernel(ExactArgs a) {
     if (a.nq_ptr && nq <= a.min_active) return;
     int P = a.P, rows_per_chunk = a.rows_per_chunk;
     if (a.nq_ptr && a.adaptive_max_p > 0) {
-        P = exact_adaptive_chunks(nq, BMQ, (int)gridDim.x, a.adaptive_max_p, a.n);
+        P = exact_adaptive_chunks(nq, BMQ, (int)gridDim.x, a.adaptive_max_p, a.n, a.adaptive_one_per_cu);
         rows_per_chunk = (((a.n + BN - 1) / BN + P - 1) / P) * BN;
     }
     const int mtile = blockIdx.x / P, chunk = blockIdx.x % P;
@@ -249,13 +259,20 @@ __global__ __launch_bounds__(NW * 64, OCC) void exact_topk_kernel(ExactArgs a) {
                     if (row >= row_end) acc[t][r] = __builtin_nanf("");
                 }
             }
-            filter16<true>(acc[t], row0, st, qbuf, lane);
-            if (__any(st.cnt > LIMIT)) compact_wave<KP, E, CAP>(wbuf, st, lane, false);
+            if constexpr (GROUP == 32) {
+                filter16<true>(acc[t], row0, st, qbuf, lane);
+                if (__any(st.cnt > LIMIT)) compact_wave<KP, E, CAP, GROUP>(wbuf, st, lane, false);
+            } else {
+                filter16<true, 0, 8>(acc[t], row0, st, qbuf, lane);
+                if (__any(st.cnt > LIMIT)) compact_wave<KP, E, CAP, GROUP>(wbuf, st, lane, false);
+                filter16<true, 8, 16>(acc[t], row0, st, qbuf, lane);
+                if (__any(st.cnt > LIMIT)) compact_wave<KP, E, CAP, GROUP>(wbuf, st, lane, false);
+            }
         }
     }
 
     // final: sorted top-KP of every query of this wave -> partial list
-    compact_wave<KP, E, CAP>(wbuf, st, lane, true);
+    compact_wave<KP, E, CAP, GROUP>(wbuf, st, lane, true);
     for (int b = 0; b < 32; ++b) {
         const int slot = slot0 + wave * 32 + b;
         if (slot >= nq) break;

@@ -38,6 +38,7 @@ struct FinArgs {
     int P, KP;
     int P_dense;        // with nq_ptr: lists per slot when more than sparse_max slots are active (0: always P)
     int sparse_max;
+    int dense_one_per_cu;   // (exact_adaptive_chunks)
     int dense_grid, dense_bmq, dense_max_p, n_rows;   // dense_max_p > 0: exact_topk chose its chunk count on the device
     int lds_cand;       // candidate slots the launch's LDS was sized for (0: P * KP)
     int lists_by_query; // with qlist: the lists (and bounds) of slot s belong to query qlist[s] and sit at that query's index
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256, EWM == 1 ? ICD_FIN_OCC : 1) void finalize_kern
     // the fallback's two producers leave different numbers of lists per slot (stream_topk: P, exact_topk: P_dense)
     int P = a.P;
     if (a.nq_ptr && a.P_dense > 0 && nq > a.sparse_max)
-        P = a.dense_max_p > 0 ? exact_adaptive_chunks(nq, a.dense_bmq, a.dense_grid, a.dense_max_p, a.n_rows) : a.P_dense;
+        P = a.dense_max_p > 0 ? exact_adaptive_chunks(nq, a.dense_bmq, a.dense_grid, a.dense_max_p, a.n_rows, a.dense_one_per_cu) : a.P_dense;
     const int ncand = P * a.KP;
     const int lds_cand = a.lds_cand > 0 ? a.lds_cand : ncand;
     char *wbase = smem + (size_t)wave * fin_wave_lds_bytes(RESCORE, a.dim, lds_cand, EWM);

@@ -251,9 +251,9 @@ int pick_chunks(int mtiles, int row_tiles, int pmax, int slots) {
     return std::max(1, p);
 }
 
-template <int KP, int E, int NW, int CAPV = 64 * E, int BK = 32, int OCC = 1>
+template <int KP, int E, int NW, int CAPV = 64 * E, int BK = 32, int OCC = 1, int GROUP = 32>
 int launch_exact(icd_index *x, const ExactArgs &a, int mtiles, hipStream_t s) {
-    auto kern = exact_topk_kernel<KP, E, NW, CAPV, BK, OCC>;
+    auto kern = exact_topk_kernel<KP, E, NW, CAPV, BK, OCC, GROUP>;
     const size_t lds = exact_lds_bytes<KP, E, NW, CAPV, BK>();
     static int configured[MAX_DEVICES] = {};   // (guarded by the caller's one-stream-per-handle contract; worst case a repeated call)
     HIP_TRY(ensure_dynamic_lds(kern, x->device, (size_t)((int)lds), configured));
@@ -471,7 +471,10 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     // exact-kernel configuration (full run, or fallback over the flagged list)
     const int kpx = exact_kp_for(k);
     const int nwx = kpx <= 64 ? 4 : 2;
-    const int wg_per_cu_x = kpx == 16 ? 2 : 1;   // work-groups of exact_topk a CU holds (its LDS)
+    int wg_per_cu_x = kpx <= 32 ? 2 : 1;   // work-groups of exact_topk a CU holds (its LDS)
+#ifdef ICD_ABLATE
+    if (kpx == 32 && getenv("ICD_EXACT_CFG") && atoi(getenv("ICD_EXACT_CFG")) == 3) wg_per_cu_x = 1;
+#endif
     const int ex = kpx == 16 ? 1 : (kpx <= 64 ? 2 : 3);
     const int bmq = nwx * 32;
     const int mtx = (nq + bmq - 1) / bmq;
@@ -534,6 +537,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             ExactArgs a{};
             a.corpus = x->corpus; a.queries = dq; a.qlist = qlist; a.nq_ptr = nq_ptr; a.nq = nq;
             a.min_active = stream ? sparse_here : 0;
+            a.adaptive_one_per_cu = wg_per_cu_x > 1 ? x->num_cu : 0;
             a.adaptive_max_p = stream ? p_dense_max : 0;   // fallback: the chunk count follows the actual flagged count
             a.n = (int)x->n; a.dim = x->dim; a.P = pm;
             a.rows_per_chunk = ((row_tiles + pm - 1) / pm) * 128;
@@ -547,7 +551,10 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             else
 #endif
             if (kpx == 16) rc = launch_exact<16, 1, 4, 60, 16, 2>(x, a, mtx, s);
-            else if (kpx == 32) rc = launch_exact<32, 2, 4, 112>(x, a, mtx, s);
+#ifdef ICD_ABLATE
+            else if (kpx == 32 && getenv("ICD_EXACT_CFG") && atoi(getenv("ICD_EXACT_CFG")) == 3) rc = launch_exact<32, 2, 4, 112>(x, a, mtx, s);
+#endif
+            else if (kpx == 32) rc = launch_exact<32, 1, 4, 62, 16, 2, 16>(x, a, mtx, s);
             else if (kpx == 64) rc = launch_exact<64, 2, 4, 112>(x, a, mtx, s);
             else rc = launch_exact<128, 3, 2>(x, a, mtx, s);
             if (rc) return rc;
@@ -556,7 +563,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         FinArgs g = f;
         g.part_scores = x->partx_s; g.part_rows = x->partx_r; g.P = px; g.KP = kpx;
         g.P_dense = px_dense; g.sparse_max = sparse_here; g.track_run = track_run ? 1 : 0; g.lds_cand = std::max(px, (stream && mfma) ? p_dense_max : px_dense) * kpx;
-        g.dense_grid = mtx * std::max(1, px_dense); g.dense_bmq = bmq; g.dense_max_p = (stream && mfma) ? p_dense_max : 0; g.n_rows = (int)x->n;
+        g.dense_grid = mtx * std::max(1, px_dense); g.dense_bmq = bmq; g.dense_max_p = (stream && mfma) ? p_dense_max : 0; g.dense_one_per_cu = wg_per_cu_x > 1 ? x->num_cu : 0; g.n_rows = (int)x->n;
         g.nq = nq; g.nq_ptr = nq_ptr; g.qlist = qlist;
         g.counters = x->nflag; g.host_counters = x->h_nflag_dev;   // (the last launch of every search: no separate copy)
         rc = launch_finalize<false>(x, g, s);

@@ -139,9 +139,10 @@ __device__ __forceinline__ void compact_one(u64 *qbuf, int nb, int lane, u64 &kt
 
 // Compact every query of this wave whose buffer could overflow in the next group (or all when
 // force is set). wbuf = this wave's 32 buffers, CAP apart.
-template <int KP, int E, int CAP = 64 * E>
+// GROUP: the most entries one filter call can append to a query's buffer (32: a whole 32x32 tile, 16: half of one)
+template <int KP, int E, int CAP = 64 * E, int GROUP = 32>
 __device__ __forceinline__ void compact_wave(u64 *wbuf, SelState &st, int lane, bool force) {
-    constexpr int LIMIT = CAP - 32;
+    constexpr int LIMIT = CAP - GROUP;
     uint32_t need = (uint32_t)__ballot(force ? (st.cnt > 0) : (st.cnt > LIMIT));
     while (need) {
         const int b = __ffs((int)need) - 1;
@@ -161,13 +162,14 @@ __device__ __forceinline__ void compact_wave(u64 *wbuf, SelState &st, int lane, 
 
 // Threshold-filter one 32x32 MFMA tile's 16 registers. row0 = absolute row of the tile's row 0.
 // EXACT_TIES: also accept score == thr with a lower row than the current KP-th (canonical order).
-template <bool EXACT_TIES>
+// R0, R1: the registers of the tile this call tests (all 16, or one half: at most 16 appends per query)
+template <bool EXACT_TIES, int R0 = 0, int R1 = 16>
 __device__ __forceinline__ void filter16(const f32x16 &acc, uint32_t row0, SelState &st, u64 *qbuf, int lane) {
     const uint32_t rbase = row0 + 4u * (uint32_t)(lane >> 5);
     const uint32_t c = (uint32_t)lane & 31u;
     const uint32_t hi_half = (uint32_t)lane >> 5;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = R0; r < R1; ++r) {
         const float v = acc[r];
         const uint32_t row = rbase + (uint32_t)((r & 3) + 8 * (r >> 2));
         bool pass = v > st.thr;
