@@ -20,7 +20,7 @@ def main():
     import torch
     from rag_project_icd10_amd._native import IcdIndex
     rng = np.random.default_rng(3)
-    n, nq, d, k = 37000, 10000, 768, 10
+    n, nq, d, k = 37000, 10000, 768, int(os.environ.get("ICD_PROBE_K", "10"))
     corpus = rng.standard_normal((n, d), dtype=np.float32)
     corpus /= np.linalg.norm(corpus, axis=1, keepdims=True)
     levels = rng.integers(1, 4, n).astype(np.int32)
