@@ -485,9 +485,9 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     // sparse: streaming kernel (+ list reduction) instead of / next to the MFMA exact kernel
     // queries per pass: host-known for direct calls (1, 2, 4 or 8), 8 for the device-gated fallback
     const int p_sparse = FIN_MAX_CAND / kpx;   // lists per slot that finalize<false> merges (32 / 8 / 4)
-    // How many flagged queries still go to the streaming kernel: it re-reads the corpus once per 8 queries (~35 us at
-    // 37k rows), the fp32-MFMA kernel needs ~1.4 ms for ANY count up to a few thousand (one 128-query tile per
-    // work-group, 16 chunks at most: few CUs busy), so the crossover is near 300; the list workspace caps it by k.
+    // How many flagged queries still go to the streaming kernel: it re-reads the corpus once per 8 queries (~37 us at
+    // 37k rows); the fp32-MFMA kernel, its short list cut into up to 2048 / KP chunks, needs ~0.22 ms for any count up to a
+    // few hundred: they meet near 45 (ST_FALLBACK_MAX_ACTIVE, stream_kernel.hpp); the list workspace caps it by k.
     // (the first reduction level leaves at most 512 lists per slot in the second workspace)
     const int sparse_max = (int)std::min<size_t>(std::min<size_t>(ST_FALLBACK_MAX_ACTIVE, x->lists_cap / ((size_t)1024 * kpx)),
                                                  kpx == 16 ? (size_t)ST_FALLBACK_MAX_ACTIVE : x->partx_cap / ((size_t)512 * kpx));
