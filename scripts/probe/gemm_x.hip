@@ -151,6 +151,98 @@ __device__ __forceinline__ void gemm_x_body(const _Float16 *q16, const _Float16 
     out[blockIdx.x * 512 + tid] = keep;
 }
 
+// ---- ping-pong form (round 4): the same 256 x 256 tile, 8 waves, but the two waves of a SIMD (rh = 0 / 1, same qg) run ONE PHASE
+// APART: a stage (32 halves of K: 32 KB, ring of four) is a LOAD phase (4 LDS-DMA pieces of stage g + 3, the stage's 12 fragment
+// reads) and an MFMA phase (32 MFMAs under s_setprio), every phase ends in a raw s_barrier, and group rh = 1 enters the loop one
+// barrier late - while one wave of a SIMD issues its MFMAs the other one loads (the guide's 8-phase template reduced to two phases).
+// RAW: a stage is read two phases after the vmcnt that retires its pieces (vmcnt(4): one stage in flight) and a barrier;
+// WAR: its slot is restaged one phase after its last read.
+__device__ __forceinline__ void gemm_x_pp_body(const _Float16 *q16, const _Float16 *c16, int ctiles, int tiles_per_wg, int lists, float *out) {
+    constexpr int BKP = 32, KSP = D / BKP, S = 4, RG = 8, TR = 256;
+    constexpr int A_BYTES = TR * BKP * 2, B_BYTES = TQ * BKP * 2, STAGE_BYTES = A_BYTES + B_BYTES;   // 16 + 16 KB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qg = wave & 3, rh = wave >> 2;
+    const int r16 = lane & 15, g16 = lane >> 4;
+    const int mtile = blockIdx.x / lists, li = blockIdx.x % lists;
+    const int t0 = li * tiles_per_wg, t1 = min(ctiles, t0 + tiles_per_wg);
+    if (t0 >= t1) return;
+    // pieces of 1 KiB = 16 rows x 64 B: lane l -> row l >> 2, 16-byte slot l & 3 (LDS side linear); the source chunk is the slot
+    // XOR (row >> 2) & 3, so that the fragment read of row r16, chunk g16 finds it at slot g16 ^ ((r16 >> 2) & 3): conflict-free
+    uint32_t a_off[2], b_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 16 + (lane >> 2);
+        const uint32_t o = (uint32_t)row * (D * 2) + (uint32_t)(((lane & 3) ^ ((row >> 2) & 3)) * 16);
+        a_off[i] = o; b_off[i] = o;
+    }
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(c16), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(q16) + (size_t)mtile * TQ * D, 0, 0x7FFFFFFF, 0x00020000);
+    auto issue = [&](int tile, int ks, int slot) {
+        char *sb = smem + slot * STAGE_BYTES;
+        const int trow = min(tile, ctiles - 1);
+        const uint32_t asoff = (uint32_t)trow * (uint32_t)(TR * D * 2) + (uint32_t)ks * (BKP * 2);
+        const uint32_t bsoff = (uint32_t)ks * (BKP * 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(crs, (__attribute__((address_space(3))) void *)(sb + (wave * 2 + i) * 1024), 16, a_off[i], asoff, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (__attribute__((address_space(3))) void *)(sb + A_BYTES + (wave * 2 + i) * 1024), 16, b_off[i], bsoff, 0, 0);
+    };
+    const uint32_t rd = (uint32_t)r16 * 64u + (uint32_t)((g16 ^ ((r16 >> 2) & 3)) * 16);
+    const uint32_t a_base = (uint32_t)(rh * 16 * RG) * 64u, b_base = (uint32_t)A_BYTES + (uint32_t)(qg * 64) * 64u;
+    f32x4 acc[RG][4];
+    float keep = 0.f;
+    const int ntiles = t1 - t0, nstages = ntiles * KSP;
+#pragma unroll
+    for (int p = 0; p < S - 1; ++p) issue(t0 + p / KSP, p % KSP, p % S);
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");   // stages 0 and 1 have landed everywhere
+    if (rh == 1) asm volatile("s_barrier" ::: "memory");             // the stagger
+    for (int g = 0; g < nstages; ++g) {
+        const int ks = g % KSP, slot = g % S;
+        if (ks == 0) {
+#pragma unroll
+            for (int a = 0; a < RG; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
+        }
+        // LOAD phase
+        {
+            const int n = g + S - 1;
+            issue(t0 + n / KSP, n % KSP, n % S);
+        }
+        const char *sb = smem + slot * STAGE_BYTES;
+        half8 af[RG], bf[4];
+#pragma unroll
+        for (int t = 0; t < RG; ++t) af[t] = *reinterpret_cast<const half8 *>(sb + a_base + rd + t * 1024);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bf[t] = *reinterpret_cast<const half8 *>(sb + b_base + rd + t * 1024);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // MFMA phase
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int a = 0; a < RG; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (ks == KSP - 1) {
+#pragma unroll
+            for (int a = 0; a < RG; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) keep += acc[a][b][0] + acc[a][b][3];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    }
+    if (rh == 0) asm volatile("s_barrier" ::: "memory");   // (the late group's last barrier)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    out[blockIdx.x * 512 + tid] = keep;
+}
+__global__ __launch_bounds__(512, 1) void gemm_x_pp(const _Float16 *q, const _Float16 *c, int ct, int tpw, int l, float *o) { gemm_x_pp_body(q, c, ct, tpw, l, o); }
+
 #define ICD_GX(SV, RGV)                                                                                              \
     __global__ __launch_bounds__(512, 1) void gemm_x_##SV##_##RGV(const _Float16 *q, const _Float16 *c, int ct, int tpw, int l, float *o) { \
         gemm_x_body<SV, RGV>(q, c, ct, tpw, l, o);                                                                        \
@@ -206,6 +298,39 @@ int main(int argc, char **argv) {
         RUN_CASE(2, 4);
         RUN_CASE(3, 4);
         RUN_CASE(2, 8);
+    }
+    {   // ping-pong form against the plain 256 x 256 kernel: same sums expected bit for bit
+        constexpr int TR = 256;
+        const int ctiles = n / TR, mtiles = nq / TQ;
+        const int tiles_per_wg = (ctiles + lists - 1) / lists, grid = mtiles * lists;
+        const size_t lds_ref = (size_t)2 * (TR * BK * 2 + TQ * BK * 2), lds_pp = (size_t)4 * (TR * 32 * 2 + TQ * 32 * 2);
+        float *o1, *o2;
+        hipMalloc(&o1, (size_t)grid * 512 * 4); hipMalloc(&o2, (size_t)grid * 512 * 4);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_x_pp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp);
+        hipLaunchKernelGGL(gemm_x_2_8, dim3(grid), dim3(512), lds_ref, 0, dq, dc, ctiles, tiles_per_wg, lists, o1);
+        for (int w = 0; w < 50; ++w) hipLaunchKernelGGL(gemm_x_pp, dim3(grid), dim3(512), lds_pp, 0, dq, dc, ctiles, tiles_per_wg, lists, o2);
+        hipDeviceSynchronize();
+        if (hipGetLastError() != hipSuccess) { printf("launch failed\n"); return 1; }
+        std::vector<float> h1((size_t)grid * 512), h2((size_t)grid * 512);
+        int bad_total = 0;
+        for (int rep = 0; rep < 5; ++rep) {   // (a race would show as sums that come and go)
+            hipLaunchKernelGGL(gemm_x_pp, dim3(grid), dim3(512), lds_pp, 0, dq, dc, ctiles, tiles_per_wg, lists, o2);
+            hipMemcpy(h1.data(), o1, h1.size() * 4, hipMemcpyDeviceToHost);
+            hipMemcpy(h2.data(), o2, h2.size() * 4, hipMemcpyDeviceToHost);
+            int bad = 0;
+            for (size_t i = 0; i < h1.size(); ++i) bad += (h1[i] != h2[i]);
+            bad_total += bad;
+        }
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(e0);
+            for (int it = 0; it < iters; ++it) hipLaunchKernelGGL(gemm_x_pp, dim3(grid), dim3(512), lds_pp, 0, dq, dc, ctiles, tiles_per_wg, lists, o2);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            const double flop = 2.0 * nq * (double)n * D * iters;
+            printf("tile 256 x 256 PING-PONG (two waves of a SIMD one phase apart, 32-deep stages, ring of 4 = 128 KB): %.4f ms per launch, %.0f TFLOP/s (%.3f of 2500); checksums differing from the plain kernel's in 5 runs: %d\n",
+                   ms / iters, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 2500.0, bad_total);
+        }
+        hipFree(o1); hipFree(o2);
     }
     // 256 x 256 tiles with the register / ballot select and global spill lists (fixed thresholds)
     {
