@@ -243,6 +243,122 @@ __device__ __forceinline__ void gemm_x_pp_body(const _Float16 *q16, const _Float
 }
 __global__ __launch_bounds__(512, 1) void gemm_x_pp(const _Float16 *q, const _Float16 *c, int ct, int tpw, int l, float *o) { gemm_x_pp_body(q, c, ct, tpw, l, o); }
 
+// ---- two INDEPENDENT work-groups per CU (round 4): four waves (one per SIMD), tile = 128 rows x 256 queries, wave tile 128 x 64
+// (128 accumulator registers), 32-deep stages of 24 KB in a ring of three (72 KB: two work-groups fit a CU), 256 registers per wave.
+// The two work-groups of a CU share nothing and drift apart: the select of one can run under the MFMAs of the other. SEL as above
+// (2 = private sub-lists, slot counters in registers).
+template <int SEL>
+__device__ __forceinline__ void gemm_x4_body(const _Float16 *q16, const _Float16 *c16, int ctiles, int tiles_per_wg, int lists, float *out,
+                                             float thr, int *spill_cnt, unsigned long long *spill, int spill_cap) {
+    constexpr int BKP = 32, KSP = D / BKP, S = 3, RG = 8, TR = 128;
+    constexpr int A_BYTES = TR * BKP * 2, B_BYTES = TQ * BKP * 2, STAGE_BYTES = A_BYTES + B_BYTES;   // 8 + 16 KB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int qg = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g16 = lane >> 4;
+    const int mtile = blockIdx.x / lists, li = blockIdx.x % lists;
+    const int t0 = li * tiles_per_wg, t1 = min(ctiles, t0 + tiles_per_wg);
+    if (t0 >= t1) return;
+    uint32_t a_off[2], b_off[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (qg * 2 + i) * 16 + (lane >> 2);
+        a_off[i] = (uint32_t)row * (D * 2) + (uint32_t)(((lane & 3) ^ ((row >> 2) & 3)) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (qg * 4 + i) * 16 + (lane >> 2);
+        b_off[i] = (uint32_t)row * (D * 2) + (uint32_t)(((lane & 3) ^ ((row >> 2) & 3)) * 16);
+    }
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(c16), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(q16) + (size_t)mtile * TQ * D, 0, 0x7FFFFFFF, 0x00020000);
+    auto issue = [&](int tile, int ks, int slot) {
+        char *sb = smem + slot * STAGE_BYTES;
+        const int trow = min(tile, ctiles - 1);
+        const uint32_t asoff = (uint32_t)trow * (uint32_t)(TR * D * 2) + (uint32_t)ks * (BKP * 2);
+        const uint32_t bsoff = (uint32_t)ks * (BKP * 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(crs, (__attribute__((address_space(3))) void *)(sb + (qg * 2 + i) * 1024), 16, a_off[i], asoff, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (__attribute__((address_space(3))) void *)(sb + A_BYTES + (qg * 4 + i) * 1024), 16, b_off[i], bsoff, 0, 0);
+    };
+    const uint32_t rd = (uint32_t)r16 * 64u + (uint32_t)((g16 ^ ((r16 >> 2) & 3)) * 16);
+    const uint32_t b_base = (uint32_t)A_BYTES + (uint32_t)(qg * 64) * 64u;
+    f32x4 acc[RG][4];
+    float keep = 0.f;
+    int mypos[4] = {0, 0, 0, 0};
+    const int ntiles = t1 - t0, nstages = ntiles * KSP;
+#pragma unroll
+    for (int p = 0; p < S - 1; ++p) issue(t0 + p / KSP, p % KSP, p % S);
+    asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    for (int g = 0; g < nstages; ++g) {
+        const int ks = g % KSP, slot = g % S;
+        if (ks == 0) {
+#pragma unroll
+            for (int a = 0; a < RG; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
+        }
+        {   // every wave is past stage g-1: its slot takes stage g+S-1
+            const int n = g + S - 1;
+            issue(t0 + n / KSP, n % KSP, n % S);
+        }
+        const char *sb = smem + slot * STAGE_BYTES;
+        half8 af[RG], bf[4];
+#pragma unroll
+        for (int t = 0; t < RG; ++t) af[t] = *reinterpret_cast<const half8 *>(sb + rd + t * 1024);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bf[t] = *reinterpret_cast<const half8 *>(sb + b_base + rd + t * 1024);
+#pragma unroll
+        for (int a = 0; a < RG; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        if (ks == KSP - 1) {
+            if constexpr (SEL != 0) {
+                const int tile = t0 + g / KSP;
+#pragma unroll
+                for (int a = 0; a < RG; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const f32x4 v = acc[a][b];
+                        const bool any = v[0] > thr || v[1] > thr || v[2] > thr || v[3] > thr;
+                        if (__builtin_amdgcn_ballot_w64(any)) {
+                            const int q = mtile * TQ + qg * 64 + b * 16 + r16;
+                            const int row0 = tile * TR + a * 16 + 4 * g16;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (v[i] > thr) {
+                                    const int pos = mypos[b]++;
+                                    if (pos < spill_cap / 4)
+                                        spill[(((size_t)q * lists + li) * 4 + g16) * (spill_cap / 4) + pos] = ((unsigned long long)__float_as_uint(v[i]) << 32) | (unsigned)(row0 + i);
+                                }
+                        }
+                    }
+            } else {
+#pragma unroll
+                for (int a = 0; a < RG; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) keep += acc[a][b][0] + acc[a][b][3];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (SEL != 0) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) atomicAdd(&spill_cnt[(mtile * TQ + qg * 64 + b * 16 + r16) * lists + li], mypos[b]);
+    }
+    out[blockIdx.x * 256 + tid] = keep;
+}
+__global__ __launch_bounds__(256, 2) void gemm_x4_plain(const _Float16 *q, const _Float16 *c, int ct, int tpw, int l, float *o, float thr, int *cnt, unsigned long long *sp, int cap) {
+    gemm_x4_body<0>(q, c, ct, tpw, l, o, thr, cnt, sp, cap);
+}
+__global__ __launch_bounds__(256, 2) void gemm_x4_sel(const _Float16 *q, const _Float16 *c, int ct, int tpw, int l, float *o, float thr, int *cnt, unsigned long long *sp, int cap) {
+    gemm_x4_body<2>(q, c, ct, tpw, l, o, thr, cnt, sp, cap);
+}
+
 #define ICD_GX(SV, RGV)                                                                                              \
     __global__ __launch_bounds__(512, 1) void gemm_x_##SV##_##RGV(const _Float16 *q, const _Float16 *c, int ct, int tpw, int l, float *o) { \
         gemm_x_body<SV, RGV>(q, c, ct, tpw, l, o);                                                                        \
@@ -331,6 +447,47 @@ int main(int argc, char **argv) {
                    ms / iters, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 2500.0, bad_total);
         }
         hipFree(o1); hipFree(o2);
+    }
+    {   // two independent four-wave work-groups per CU: 128 x 256 tiles, plain and with the private-sub-list select
+        constexpr int TR = 128;
+        const int ctiles = n / TR, mtiles = nq / TQ, cap = 256;
+        const size_t lds = (size_t)3 * (TR * 32 * 2 + TQ * 32 * 2);
+        for (int lists4 : {12, 13}) {
+            const int tiles_per_wg = (ctiles + lists4 - 1) / lists4, grid = mtiles * lists4;
+            float *o; int *cnt; unsigned long long *spill;
+            hipMalloc(&o, (size_t)grid * 256 * 4);
+            hipMalloc(&cnt, (size_t)nq * lists4 * 4);
+            hipMalloc(&spill, (size_t)nq * lists4 * cap * 8);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_x4_plain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_x4_sel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            const float thrs[2] = {2.576f * 9.2376f, 1e30f};
+            for (int var = 0; var < 3; ++var) {   // plain, select without appends, select at the product's append rate
+                auto kern = var == 0 ? gemm_x4_plain : gemm_x4_sel;
+                const float thr = var == 2 ? thrs[0] : thrs[1];
+                for (int w = 0; w < 20; ++w) {
+                    hipMemsetAsync(cnt, 0, (size_t)nq * lists4 * 4, 0);
+                    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, dq, dc, ctiles, tiles_per_wg, lists4, o, thr, cnt, spill, cap);
+                }
+                hipDeviceSynchronize();
+                if (hipGetLastError() != hipSuccess) { printf("launch failed\n"); return 1; }
+                float tot = 0.f;
+                for (int it = 0; it < iters; ++it) {
+                    hipMemsetAsync(cnt, 0, (size_t)nq * lists4 * 4, 0);
+                    hipEventRecord(e0);
+                    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, dq, dc, ctiles, tiles_per_wg, lists4, o, thr, cnt, spill, cap);
+                    hipEventRecord(e1); hipEventSynchronize(e1);
+                    float ms; hipEventElapsedTime(&ms, e0, e1); tot += ms;
+                }
+                std::vector<int> hc2((size_t)nq * lists4);
+                hipMemcpy(hc2.data(), cnt, hc2.size() * 4, hipMemcpyDeviceToHost);
+                double appended = 0; for (int v : hc2) appended += v;
+                const double flop = 2.0 * nq * (double)n * D * iters;
+                printf("TWO work-groups per CU, tile 128 x 256, 4 waves, lists %d (grid %d), %s: %.4f ms per launch, %.0f TFLOP/s (%.3f of 2500), %.2f M appends\n", lists4, grid,
+                       var == 0 ? "plain" : (var == 1 ? "select, nothing passes" : "select at the product's append rate"), tot / iters, flop / (tot * 1e-3) / 1e12,
+                       flop / (tot * 1e-3) / 1e12 / 2500.0, appended / 1e6);
+            }
+            hipFree(o); hipFree(cnt); hipFree(spill);
+        }
     }
     // 256 x 256 tiles with the register / ballot select and global spill lists (fixed thresholds)
     {
