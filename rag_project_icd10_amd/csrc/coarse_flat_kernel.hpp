@@ -288,6 +288,9 @@ __device__ __forceinline__ void compact_all_parallel(char *smem, Sel2 &st, uint3
 //        maximum (three v_max3 + one v_max) and tests THAT against the threshold: one compare and one scalar branch per 8
 //        registers while nothing passes, the two quads' own tests only behind it. A warm list passes most groups untouched
 //        (a 1.25 M-row shard's lists are 4 900 tiles long and append a handful of rows per hundred tiles)
+//   33554432  diagnostic: every wave stamps s_memtime / s_memrealtime once at its start and once at its end and leaves the two
+//        differences in CoarseFlatArgs::dbg: the in-kernel clock the chip holds under this kernel (MI355X_MICROARCH.md,
+//        DVFS give-back item 6); nothing inside the loops changes
 //   TIMING ONLY (the results are not the scores; they size the parts of the kernel, profiles/r02_coarse_loop_decomposition.log):
 //   256 no s_barrier   512 no wait for the LDS-DMA pieces   4096 thresholds at +inf (nothing passes)
 //   8192 no select at all   16384 no LDS-DMA inside the tile loop   65536 (with 32768) no lane swaps
@@ -334,7 +337,10 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     constexpr bool DIRTY_GUARD = (VAR & 8388608) != 0;
     constexpr bool SPARSE_PRE = (VAR & 16777216) != 0;
     static_assert(!SPARSE_PRE || (QUAD && X16), "the group pre-filter is built on the quad select of the 16x16x32 form");
-    static_assert(!DMA_WIDE || (DMA_SPREAD && PF2 && !NODMA), "the wide spread is built on the product's stage");
+    // (only the 16x16x32 branch of mfma4 honours the half-calls the wide spread splits a k-step into)
+    static_assert(!DMA_WIDE || (X16 && DMA_SPREAD && PF2 && !NODMA), "the wide spread is built on the product's 16x16x32 stage");
+    constexpr bool CLOCKS = (VAR & 33554432) != 0;
+    static_assert(!(CLOCKS && STAMPS), "one use of the debug buffer at a time");
     constexpr int S = cf_ring_stages(VAR);            // ring slots
     constexpr int VM_MID = NOVM ? 63 : (PAIRBAR ? 4 : 4 * (S - 3));   // LDS-DMA pieces that may stay in flight at the mid-stage wait
     constexpr int PRO = PAIRBAR ? 4 : S - 1;          // stages issued by a list's prologue
@@ -362,6 +368,12 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     // all map to two blocks: 0.44 ms for 15 queries, measured)
     const int nwg_logical = PERSIST ? (total_units + a.units_per_wg - 1) / a.units_per_wg : (int)gridDim.x;
     if (PERSIST && nq_act <= a.skip_below) return;
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if constexpr (CLOCKS) {
+        clk_c0 = __builtin_amdgcn_s_memtime();
+        clk_r0 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // (lgkmcnt(0) alone: see cdna_hip_programming.md section 7, In-kernel stamps)
+    }
 
     // LDS-DMA: per-lane source offsets (bytes from the tile's first row, k = 0); piece i of this wave =
     // rows 8 (4 wave + i) .. +7, one full 128-B line each, 16-B pieces XOR-swizzled on the source side
@@ -829,14 +841,13 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                 if (thr0 > st.thr) st.thr = thr0;   // (padding queries keep +inf)
             }
             if constexpr (STAMPS) { unsigned long long ts_b; ICD_CF_STAMP(ts_b); st_boot += ts_b - ts_a; }
-            if constexpr (NOSEL) {
-#pragma unroll
-                for (int t = 0; t < (X16 ? 1 : 4); ++t) asm volatile("" ::"v"(acc[t]));
+            if constexpr (NOSEL) {   // the scores stay live (cdna_hip_programming.md rule 17), nothing else happens to them
                 if constexpr (X16) {
-                    float keep = 0.0f;
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) keep += xs[X16 ? t : 0][0] + xs[X16 ? t : 0][1] + xs[X16 ? t : 0][2] + xs[X16 ? t : 0][3];
-                    asm volatile("" ::"v"(keep));
+                    for (int t = 0; t < 16; ++t) asm volatile("" ::"v"(xs[X16 ? t : 0]));
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(acc[X16 ? 0 : t]));
                 }
             } else if constexpr (QUAD) {
                 if (tile_row0 + CO_BN > a.n) static_for<0, 16>([&](auto Q) { filter_quad(acc, xs, Q, rowbase, std::true_type{}); });
@@ -886,6 +897,13 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
         u += ntiles;
     }
     }   // (logical work-groups of this block)
+    if constexpr (CLOCKS) {
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0 && a.dbg && blockIdx.x < 2048) {   // (a buffer of its own: nothing in the kernel reads it)
+            unsigned long long *d = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
+            d[0] = c1 - clk_c0; d[1] = r1 - clk_r0; d[4] = 1;
+        }
+    }
     if constexpr (STAMPS) {
         if (lane == 0 && a.dbg) {
             unsigned long long *d = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 8;

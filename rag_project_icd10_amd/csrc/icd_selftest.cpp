@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -120,7 +121,7 @@ static void run_case(const char *name, const Data &d, int k, int mode, int64_t i
     icd_index_destroy(idx);
 }
 
-static void bench(int64_t n, int64_t nq, int dim, int k, int iters, int chunks, bool verify) {
+static void bench(int64_t n, int64_t nq, int dim, int k, int iters, int chunks, bool verify, bool auto_only = false) {
     printf("== bench n=%lld nq=%lld dim=%d k=%d iters=%d chunks=%d\n", (long long)n, (long long)nq, dim, k, iters, chunks);
     Data d = make_data(n, nq, dim, 0, 1234);
     icd_index *idx = nullptr;
@@ -132,7 +133,7 @@ static void bench(int64_t n, int64_t nq, int dim, int k, int iters, int chunks, 
     hipMalloc((void **)&di, (size_t)nq * k * 8);
     hipMemcpy(dq, d.queries.data(), (size_t)nq * dim * 4, hipMemcpyHostToDevice);
     icd_index_set_profiling(idx, 1);
-    for (int mode = 0; mode < 2; ++mode) {
+    for (int mode = 0; mode < (auto_only ? 1 : 2); ++mode) {
         const int it = mode == 0 ? iters : std::max(1, iters / 5);
         icd_profile acc{};
         double wall = 0;
@@ -170,6 +171,18 @@ static void bench(int64_t n, int64_t nq, int dim, int k, int iters, int chunks, 
         printf("   stamps (avg per wave over %d waves, cycles per tile): dma wait=%.0f barrier=%.0f body=%.0f select=%.0f (thr exchange %.0f, bootstrap %.0f, compactions %.2f x %.0f = %.0f) tiles/wave=%.1f\n",
                cnt, vm / tiles, bar / tiles, body / tiles, sel / tiles, thr / tiles, boot / tiles, nc / tiles, nc ? cc / nc : 0.0, cc / tiles, tiles / cnt);
     }
+    if (getenv("ICD_FLAT_VAR") && (atoi(getenv("ICD_FLAT_VAR")) & 33554432)) {
+        // in-kernel clock of the coarse launch: d(s_memtime) / d(s_memrealtime) x 100 MHz per wave, median over the waves
+        std::vector<unsigned long long> c(8192 * 8);
+        CHECK_RC(icd_index_debug_counters(idx, c.data(), (int)c.size()));
+        std::vector<double> ghz;
+        for (size_t i = 0; i + 7 < c.size(); i += 8)
+            if (c[i + 4] == 1 && c[i + 1] > 0) ghz.push_back((double)c[i] / (double)c[i + 1] * 0.1);
+        std::sort(ghz.begin(), ghz.end());
+        if (!ghz.empty())
+            printf("   in-kernel clock of the coarse launch (s_memtime / s_memrealtime, %zu waves): median %.3f GHz (min %.3f, max %.3f)\n",
+                   ghz.size(), ghz[ghz.size() / 2], ghz.front(), ghz.back());
+    }
     if (verify) {
         // parity of a query sample of the big run against the oracle (AUTO mode)
         const int ns = 128;
@@ -197,7 +210,7 @@ static void bench(int64_t n, int64_t nq, int dim, int k, int iters, int chunks, 
 
 int main(int argc, char **argv) {
     std::string opath = "oracle/libicd_oracle.so";
-    bool quick = false, do_bench = false, skip_cases = false;
+    bool quick = false, do_bench = false, skip_cases = false, auto_only = false;
     int64_t bn = 37000, bnq = 10000;
     int iters = 20, chunks = 0;
     for (int i = 1; i < argc; ++i) {
@@ -206,6 +219,7 @@ int main(int argc, char **argv) {
         else if (a == "--quick") quick = true;
         else if (a == "--bench") do_bench = true;
         else if (a == "--skip-cases") skip_cases = true;
+        else if (a == "--auto-only") auto_only = true;   // (--bench: the AUTO-mode loop alone, e.g. seconds of one load for a clock sampler)
         else if (a == "--n" && i + 1 < argc) bn = atoll(argv[++i]);
         else if (a == "--nq" && i + 1 < argc) bnq = atoll(argv[++i]);
         else if (a == "--iters" && i + 1 < argc) iters = atoi(argv[++i]);
@@ -250,7 +264,7 @@ int main(int argc, char **argv) {
     }
     if (do_bench) {
         const int var = getenv("ICD_FLAT_VAR") ? atoi(getenv("ICD_FLAT_VAR")) : 0;
-        bench(bn, bnq, 768, 10, iters, chunks, (var & (64 | 256 | 512)) == 0);   // (timing-only variants compute garbage)
+        bench(bn, bnq, 768, 10, iters, chunks, (var & (64 | 256 | 512 | 8192)) == 0, auto_only);   // (timing-only variants compute garbage)
     }
     printf("icd_selftest: %d passed, %d failed\n", g_pass, g_fail);
     return g_fail ? 1 : 0;
