@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define ICD_ABI_VERSION 4   /* 4: icd_debug_set_family_order, icd_debug_set_center, icd_stats.centered / mean_share appended, icd_group_prepare / icd_group_connect (round 4). 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
+#define ICD_ABI_VERSION 5   /* 5: icd_debug_unpack_query_slices (round 5). 4: icd_debug_set_family_order, icd_debug_set_center, icd_stats.centered / mean_share appended, icd_group_prepare / icd_group_connect (round 4). 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
 #define ICD_MAX_K 128
 
 typedef struct icd_index icd_index;
@@ -291,6 +291,15 @@ int icd_debug_set_family_order(int32_t enabled);
 /* Test switch, process-wide, read by icd_index_create (default 1): 0 keeps the fp16 corpus image uncentred whatever the
  * rows look like (icd_stats.centered). A performance decision only: results are identical either way. */
 int icd_debug_set_center(int32_t enabled);
+
+/* Test entry: the unpack step of a query-sharded icd_group_search (one kernel: the all-gathered PADDED slices -> the
+ * contiguous [nq][k] outputs) on a caller-made receive buffer, so that its index arithmetic can be checked for any world
+ * size on ONE GPU. `gathered` (device) is laid out as the group's receive buffer: with width = ceil(nq / world) and
+ * per = width * k, four arrays back to back - adj f64 [world][per] | ids i64 [world][per] | raw f32 [world][per] |
+ * levels i32 [world][per]; rank r's slice holds queries [lo_r, hi_r) (contiguous split, the first nq % world ranks one
+ * more) in its first hi_r - lo_r rows. Outputs: device pointers, [nq][k]. No reference counterpart (single process). */
+int icd_debug_unpack_query_slices(int32_t device, const void *gathered, int32_t world, int64_t nq, int32_t k, double *out_adj,
+                                  float *out_raw, int64_t *out_ids, int32_t *out_levels, void *stream);
 
 /* Diagnostic builds only (make ABLATE=1, env ICD_FLAT_VAR with bit 1024): per-wave cycle sums of the coarse kernel,
  * [work-group][wave][8] = {LDS-DMA wait, barrier, stage body, fused select, tiles, ...}. */

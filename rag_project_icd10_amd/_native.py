@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libicdsearch.so")
 MODE_AUTO = 0   # fp16-MFMA coarse pass + certified exact rescoring (+ exact fallback); same results as EXACT
 MODE_EXACT = 1  # fp32-MFMA kernel only
 MAX_K = 128
-ABI_VERSION = 4   # include/icd_search.h ICD_ABI_VERSION: a stale libicdsearch.so is refused with a clear message
+ABI_VERSION = 5   # include/icd_search.h ICD_ABI_VERSION: a stale libicdsearch.so is refused with a clear message
 
 EXPORTED_SYMBOLS = (
     "icd_abi_version", "icd_last_error", "icd_device_count", "icd_index_create", "icd_index_destroy",
@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = (
     "icd_cosine_rows",
     "icd_index_set_second_pass",
     "icd_group_unique_id", "icd_group_create", "icd_group_prepare", "icd_group_connect", "icd_group_search", "icd_group_destroy",
+    "icd_debug_unpack_query_slices",
 )
 GROUP_ROW_SHARD = 0
 GROUP_QUERY_SHARD = 1
@@ -98,6 +99,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.icd_debug_set_create_probe.argtypes = [i32]
     lib.icd_debug_set_family_order.argtypes = [i32]
     lib.icd_debug_set_center.argtypes = [i32]
+    lib.icd_debug_unpack_query_slices.argtypes = [i32, vp, i32, i64, i32, vp, vp, vp, vp, vp]
     lib.icd_packed_attention.argtypes = [i32, vp, i64, vp, i32, i32, i32, i32, vp, i64, vp]
     lib.icd_hier_rescore.argtypes = [i32, vp, vp, i64, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.icd_score_stats.argtypes = [i32, vp, vp, i64, i32, i32, vp, vp]

@@ -28,6 +28,9 @@
 #include "../../include/icd_search.h"
 
 extern "C" __attribute__((visibility("hidden"))) int icd_internal_fail(int code, const char *fmt, ...);
+// (icd_search.hip) one launch: the gathered padded slices of a query-sharded search -> the contiguous [nq][k] outputs
+extern "C" __attribute__((visibility("hidden"))) int icd_internal_unpack_query_slices(const void *r_adj, const void *r_ids, const void *r_raw,
+        const void *r_lv, int world, long long nq, int k, long long width, void *out_adj, void *out_raw, void *out_ids, void *out_lv, void *stream);
 
 namespace {
 
@@ -311,16 +314,10 @@ int icd_group_search(icd_group *g, const float *queries, int64_t nq, int32_t k, 
     NCCL_TRY_G(g, true, g_rccl.AllGather(s_raw, r_raw, per, ncclFloat32, g->comm, s));
     NCCL_TRY_G(g, true, g_rccl.AllGather(s_lv, r_lv, per, ncclInt32, g->comm, s));
     NCCL_TRY_G(g, false, g_rccl.GroupEnd());
-    for (int r = 0; r < g->world; ++r) {   // padded slices -> the contiguous [nq][k] outputs
-        int64_t a, b;
-        shard_bounds(nq, g->world, r, &a, &b);
-        const size_t n = (size_t)(b - a) * k, src = (size_t)r * per, dst = (size_t)a * k;
-        if (n == 0) continue;
-        HIPG_TRY(hipMemcpyAsync(out_adj + dst, r_adj + src, n * 8, hipMemcpyDeviceToDevice, s));
-        HIPG_TRY(hipMemcpyAsync(out_ids + dst, r_ids + src, n * 8, hipMemcpyDeviceToDevice, s));
-        HIPG_TRY(hipMemcpyAsync(out_raw + dst, r_raw + src, n * 4, hipMemcpyDeviceToDevice, s));
-        HIPG_TRY(hipMemcpyAsync(out_levels + dst, r_lv + src, n * 4, hipMemcpyDeviceToDevice, s));
-    }
+    // padded slices -> the contiguous [nq][k] outputs: one kernel (it restates shard_bounds; the gloo / torch engine's host-side
+    // concatenation in sharded.py is the reference the GPU test compares with)
+    if (icd_internal_unpack_query_slices(r_adj, r_ids, r_raw, r_lv, g->world, nq, k, (long long)width, out_adj, out_raw, out_ids, out_levels, stream))
+        return icd_internal_fail(ICD_ERR_HIP, "rank %d of %d: the unpack launch of the query-sharded gather failed", g->rank, g->world);
     return ICD_OK;
 }
 

@@ -55,6 +55,38 @@ int fail(int code, const char *fmt, ...) {
 }  // namespace
 
 // (icd_group.cpp reports its errors through the same thread-local text)
+// Query-sharded gather (icd_group.cpp): the all-gathered send buffers hold, per rank r, one PADDED slice of `width` queries
+// in four arrays (adj f64 | ids i64 | raw f32 | levels i32, each [world][width * k]); rank r's valid part is the first
+// (hi_r - lo_r) queries. ONE launch scatters every rank's valid hits to the contiguous [nq][k] outputs (it replaces four
+// hipMemcpyAsync per rank: 32 copies at 8 ranks). shard_bounds' arithmetic restated: base = nq / world, rem = nq % world.
+__global__ void unpack_query_slices_kernel(const double *r_adj, const long long *r_ids, const float *r_raw, const int *r_lv,
+                                           int world, long long nq, int k, long long width, double *out_adj, float *out_raw,
+                                           long long *out_ids, int *out_lv) {
+    const long long total = nq * (long long)k;
+    const long long base = nq / world, rem = nq % world;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long q = e / k;
+        const int j = (int)(e - q * k);
+        // rank of query q: the first `rem` ranks own base + 1 queries each
+        const long long split = rem * (base + 1);
+        const int r = q < split ? (int)(q / (base + 1)) : (int)(rem + (q - split) / (base > 0 ? base : 1));
+        const long long lo = (long long)r * base + (r < rem ? r : rem);
+        const long long src = (long long)r * width * k + (q - lo) * k + j;
+        out_adj[e] = r_adj[src]; out_ids[e] = r_ids[src]; out_raw[e] = r_raw[src]; out_lv[e] = r_lv[src];
+    }
+}
+extern "C" __attribute__((visibility("hidden"))) int icd_internal_unpack_query_slices(const void *r_adj, const void *r_ids, const void *r_raw,
+        const void *r_lv, int world, long long nq, int k, long long width, void *out_adj, void *out_raw, void *out_ids, void *out_lv, void *stream) {
+    const long long total = nq * (long long)k;
+    if (total <= 0) return 0;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(unpack_query_slices_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       static_cast<const double *>(r_adj), static_cast<const long long *>(r_ids), static_cast<const float *>(r_raw),
+                       static_cast<const int *>(r_lv), world, nq, k, width, static_cast<double *>(out_adj), static_cast<float *>(out_raw),
+                       static_cast<long long *>(out_ids), static_cast<int *>(out_lv));
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 extern "C" __attribute__((visibility("hidden"))) int icd_internal_fail(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
@@ -1358,6 +1390,19 @@ int icd_debug_set_create_probe(int32_t enabled) {
 
 int icd_debug_set_center(int32_t enabled) {
     g_center = enabled != 0;
+    return ICD_OK;
+}
+
+int icd_debug_unpack_query_slices(int32_t device, const void *gathered, int32_t world, int64_t nq, int32_t k, double *out_adj,
+                                  float *out_raw, int64_t *out_ids, int32_t *out_levels, void *stream) {
+    if (!gathered || !out_adj || !out_raw || !out_ids || !out_levels) return fail(ICD_ERR_INVALID, "pointer is NULL");
+    if (world < 1 || nq < 0 || k <= 0) return fail(ICD_ERR_INVALID, "world=%d nq=%lld k=%d", world, (long long)nq, k);
+    HIP_TRY(hipSetDevice(device));
+    const size_t width = ((size_t)nq + world - 1) / world, per = width * k;
+    const char *rb = static_cast<const char *>(gathered);
+    if (icd_internal_unpack_query_slices(rb, rb + per * world * 8, rb + per * world * 16, rb + per * world * 20, world, nq, k,
+                                         (long long)width, out_adj, out_raw, out_ids, out_levels, stream))
+        return fail(ICD_ERR_HIP, "the unpack launch failed");
     return ICD_OK;
 }
 

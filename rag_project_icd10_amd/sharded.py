@@ -18,8 +18,8 @@ Two engines behind one class:
     reweight, all enqueued on one stream inside one call; PyTorch only hands over the 128-byte RCCL unique id of rank 0
     (through the process group that already exists) and the tensors' pointers. The ranks AGREE on the engine: every rank
     does the fallible local half (icd_group_prepare), one all_reduce(MIN) of a success flag decides, and only then does
-    every rank enter the collective ncclCommInitRank (icd_group_connect) - or none does and all of them run the engine
-    below. With more than one rank the default is the torch.distributed engine until the C-ABI collective has run on >= 2
+    every rank enter the collective ncclCommInitRank (icd_group_connect, under a wall-clock limit: a connect that fails on
+    one rank alone brings the others back after CONNECT_TIMEOUT_S) - or none does and all of them run the engine below. With more than one rank the default is the torch.distributed engine until the C-ABI collective has run on >= 2
     GPUs (bench.py tries it next to the measurement, under a time limit, and reports the outcome);
   * injected callables + `torch.distributed` collectives (the constructor): the CPU (gloo, world_size 2) tests inject the
     oracle so the sharding + collective logic is covered without a GPU, and a gloo group over GPU tensors (several ranks
@@ -35,6 +35,13 @@ import torch.distributed as dist
 
 QUERY_SHARD = "query"
 ROW_SHARD = "row"
+# the row-sharded merge (csrc/icd_search.hip icd_merge_topk, csrc/icd_group.cpp icd_group_prepare) ranks the world * k
+# gathered candidates of a query in one work-group's LDS: at most this many
+MERGE_MAX_CANDIDATES = 1024
+# ncclCommInitRank (icd_group_connect) is collective and has no time limit of its own: a rank whose connect fails FAST (bad id,
+# duplicate device, out of memory) would leave the others inside the bootstrap forever. Every rank therefore runs it in a
+# worker thread and gives up after this many seconds (ICD_GROUP_CONNECT_TIMEOUT_S); see ShardedSearch._open_native
+CONNECT_TIMEOUT_S = 120.0
 
 
 def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
@@ -77,6 +84,8 @@ class ShardedSearch:
         self.merge_fn = merge_fn
         self.local_reweighted_fn = local_reweighted_fn
         self.native_group = None   # _native.IcdGroup when the C ABI runs the whole sharded search
+        self.native_stuck = False  # a worker thread of THIS process is still inside ncclCommInitRank (see _open_native)
+        self.engine = "torch.distributed"   # or "icd_group (C ABI)": which engine search_reweighted runs on (the ranks agree)
 
     # ---- construction over the HIP index ---------------------------------------------------------------
     @classmethod
@@ -125,8 +134,6 @@ class ShardedSearch:
         make = native_factory or (lambda: _native.IcdGroup(index, mode, rank=self.rank, world=self.world, connect=False, with_comm=self.world > 1))
         grp, err = None, None
         try:
-            if os.environ.get("ICD_SHARDED_TEST_FAIL_PREPARE") == str(self.rank):   # test hook: this rank's local half fails
-                raise _native.IcdError(-3, f"rank {self.rank}: forced failure of icd_group_prepare (ICD_SHARDED_TEST_FAIL_PREPARE)")
             grp = make()
         except Exception as exc:   # (no librccl, out of memory, bad arguments, ...)
             err = exc
@@ -150,16 +157,43 @@ class ShardedSearch:
             uid = bytes(t.cpu().numpy().tobytes())
             ok = any(uid)
             if ok:
-                try:
-                    grp.connect(uid)
-                except Exception as exc:
-                    ok, err = False, exc
+                ok, err = self._connect_with_deadline(grp, uid)
             if not self._agree(ok, group, dev):
-                grp.close()
+                if not self.native_stuck:
+                    grp.close()   # (a group whose connect is still running is left to process exit: closing it would free what that thread uses)
                 log.warning("rank %d of %d: icd_group_connect %s: EVERY rank runs the sharded search on torch.distributed collectives",
                             self.rank, self.world, f"failed here ({err})" if err else "failed on another rank")
                 return
         self.native_group = grp
+        self.engine = "icd_group (C ABI)"
+
+    def _connect_with_deadline(self, grp, uid):
+        """grp.connect(uid) in a worker thread, given up after CONNECT_TIMEOUT_S (env ICD_GROUP_CONNECT_TIMEOUT_S): (ok, error).
+        ncclCommInitRank is collective: when it fails fast on ONE rank, the others wait inside its bootstrap with no limit of
+        their own while the failed rank waits in the agreement's all_reduce. With the deadline the waiting ranks
+        come back, the all_reduce(MIN) completes and every rank runs the torch engine. The worker thread of a rank that gave up
+        is STILL inside ncclCommInitRank (ctypes released the GIL; nothing can cancel it): `native_stuck` says so, the group is
+        not closed under it, and a long-lived serving process should restart at its next convenience - searches are correct
+        meanwhile (the torch engine shares nothing with that communicator). Asymmetric connect failures are only SAFE through
+        this deadline; symmetric ones (every rank fails) never needed it."""
+        import threading
+        limit = float(os.environ.get("ICD_GROUP_CONNECT_TIMEOUT_S", CONNECT_TIMEOUT_S))
+        box = {}
+
+        def body():
+            try:
+                grp.connect(uid)
+                box["ok"] = True
+            except Exception as exc:
+                box["err"] = exc
+
+        th = threading.Thread(target=body, daemon=True, name="icd_group_connect")
+        th.start()
+        th.join(limit)
+        if th.is_alive():
+            self.native_stuck = True
+            return False, TimeoutError(f"rank {self.rank} of {self.world}: icd_group_connect (ncclCommInitRank) did not return within {limit:.0f} s")
+        return bool(box.get("ok")), box.get("err")
 
     def close(self):
         """the C-ABI group, if any (it borrows the index's handle; IcdIndex.close() would close it too)"""
@@ -172,6 +206,10 @@ class ShardedSearch:
         """Row mode: `queries` is the full batch on every rank -> identical (adj, raw, ids, levels) on
         every rank. Query mode: `queries` is the full batch on every rank; rank r searches its slice
         and, with gather=True, all ranks receive the full result (else only the local slice)."""
+        if self.mode == ROW_SHARD and self.world * int(k) > MERGE_MAX_CANDIDATES:
+            # (every rank sees the same world and k: all of them raise here, none enters a collective)
+            raise ValueError(f"row-sharded search: world * k = {self.world} * {int(k)} = {self.world * int(k)} candidates per query, "
+                             f"the merge ranks at most {MERGE_MAX_CANDIDATES} (k <= {MERGE_MAX_CANDIDATES // self.world} at {self.world} ranks)")
         if self.native_group is not None:
             return self.native_group.search(queries, k, gather=gather)
         if self.mode == ROW_SHARD:
@@ -190,17 +228,23 @@ class ShardedSearch:
         # query-sharded
         nq = queries.shape[0]
         lo, hi = shard_bounds(nq, self.world, self.rank)
-        adj, raw, ids, levels = self.local_reweighted_fn(queries[lo:hi], k)
-        if not gather or self.world == 1:
+        if hi > lo:
+            adj, raw, ids, levels = self.local_reweighted_fn(queries[lo:hi], k)
+        else:   # fewer queries than ranks: this rank's slice is empty (the engines are not asked to search nothing)
+            qd = queries.device
+            adj, raw = torch.empty((0, k), dtype=torch.float64, device=qd), torch.empty((0, k), dtype=torch.float32, device=qd)
+            ids, levels = torch.empty((0, k), dtype=torch.int64, device=qd), torch.empty((0, k), dtype=torch.int32, device=qd)
+        if not gather or self.world == 1 or nq == 0:
             return adj, raw, ids, levels
         width = -(-nq // self.world)  # pad every slice to the same length for one all-gather
         dev = adj.device
         pay = torch.zeros((width, k, 6), dtype=torch.int32, device=dev)
         m = hi - lo
-        pay[:m, :, 0:2] = adj.contiguous().view(torch.int32).view(m, k, 2)
-        pay[:m, :, 2] = raw.contiguous().view(torch.int32)
-        pay[:m, :, 3:5] = ids.contiguous().view(torch.int32).view(m, k, 2)
-        pay[:m, :, 5] = levels
+        if m > 0:
+            pay[:m, :, 0:2] = adj.contiguous().view(torch.int32).view(m, k, 2)
+            pay[:m, :, 2] = raw.contiguous().view(torch.int32)
+            pay[:m, :, 3:5] = ids.contiguous().view(torch.int32).view(m, k, 2)
+            pay[:m, :, 5] = levels
         flat = torch.empty((self.world * width, k, 6), dtype=torch.int32, device=dev)
         dist.all_gather_into_tensor(flat, pay, group=self.group)
         gathered = flat.view(self.world, width, k, 6)

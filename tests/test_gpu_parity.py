@@ -12,6 +12,7 @@ import os
 import numpy as np
 import pytest
 
+import perf_records
 from conftest import icd_levels, unit_rows
 
 pytestmark = pytest.mark.gpu
@@ -682,8 +683,8 @@ def test_family_corpus_is_certified_within_the_call(oracle, k, no_gc):
         torch.cuda.synchronize()
         each.append((time.perf_counter() - t0) * 1e3)
     print(f"family corpus k={k}: fresh index with the create probe: first batch {fresh_ms:.2f} ms, then {' '.join('%.2f' % x for x in each)}")
-    # the device time of a batch is what the fastest of nine shows (host one-offs of a long pytest process only add to it)
-    assert min(each) <= 2.0 and sorted(each)[4] <= 4.0, each
+    # wall-clock limits live in tests/test_zz_perf_gpu.py (run last): a slow box must not stop `pytest -x` in front of parity tests
+    perf_records.record(f"family_k{k}_fresh_index_batches_ms", each)
     idx_a.close()
     # (b) the same without the probe: the second coarse pass inside the call
     _native.load_library().icd_debug_set_create_probe(0)
@@ -723,7 +724,8 @@ def test_family_corpus_is_certified_within_the_call(oracle, k, no_gc):
     st3 = idx.stats()
     print(f"family corpus k={k}: first batch {first_ms:.2f} ms (second pass for {st['last_second_pass']} queries, {st['last_fallback']} exact), "
           f"wide-mode batches {wide_ms:.2f} ms (each: {' '.join('%.2f' % x for x in each)}; last: wide {st3['wide_mode']} lists {st3['last_chunks']} exact {st3['last_fallback']})")
-    assert first_ms < 12.0 and wide_ms < 3.0   # (first_ms is ONE measurement: 2.2-2.4 ms on a quiet host)
+    perf_records.record(f"family_k{k}_first_large_batch_ms", [first_ms])
+    perf_records.record(f"family_k{k}_wide_mode_batches_ms", each)
     # a Gaussian batch on the same index is still exact (wide mode costs speed, never results), and a small batch is untouched
     g = unit_rows(4000, 768, 99)
     _check(oracle, idx, corpus, levels, g[:300], k, MODE_AUTO)
@@ -1078,3 +1080,44 @@ def test_short_flagged_lists_take_the_chunked_exact_research(oracle, flagged, k)
     assert np.array_equal(ids.cpu().numpy()[check], want[2])
     assert _bits(adj.cpu().numpy()[check]) == _bits(want[0]) and _bits(raw.cpu().numpy()[check]) == _bits(want[1])
     idx.close()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_query_sharded_unpack_kernel_matches_the_host_concatenation(world):
+    """icd_group_search, query-sharded with gather: ONE kernel scatters the all-gathered padded slices to the [nq][k] outputs
+    (it replaced four hipMemcpyAsync per rank). Its index arithmetic restates shard_bounds; checked here for any world size on
+    one GPU through icd_debug_unpack_query_slices against sharded.py's host-side concatenation rule (nq % world != 0 and
+    nq < world included). No reference counterpart: the reference is a single process (main.py:753-758)."""
+    import ctypes
+
+    import torch
+    from rag_project_icd10_amd.sharded import shard_bounds
+    lib = _native.load_library()
+    rng = np.random.default_rng(7 + world)
+    for nq, k in ((1, 1), (5, 10), (world - 1 or 1, 3), (17, 10), (1000, 7), (4097, 100)):
+        adj = rng.standard_normal((nq, k))
+        raw = rng.standard_normal((nq, k)).astype(np.float32)
+        ids = rng.integers(-1, 2 ** 40, (nq, k))
+        lv = rng.integers(0, 4, (nq, k)).astype(np.int32)
+        width = -(-nq // world)
+        per = width * k
+        g_adj, g_ids = np.full((world, per), np.nan), np.full((world, per), -7, np.int64)
+        g_raw, g_lv = np.full((world, per), np.nan, np.float32), np.full((world, per), -7, np.int32)
+        for r in range(world):
+            lo, hi = shard_bounds(nq, world, r)
+            m = (hi - lo) * k
+            g_adj[r, :m], g_ids[r, :m] = adj[lo:hi].ravel(), ids[lo:hi].ravel()
+            g_raw[r, :m], g_lv[r, :m] = raw[lo:hi].ravel(), lv[lo:hi].ravel()
+        blob = g_adj.tobytes() + g_ids.tobytes() + g_raw.tobytes() + g_lv.tobytes()
+        gathered = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
+        o_adj = torch.empty((nq, k), dtype=torch.float64, device="cuda")
+        o_raw = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+        o_ids = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        o_lv = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+        vp = ctypes.c_void_p
+        rc = lib.icd_debug_unpack_query_slices(0, vp(gathered.data_ptr()), world, nq, k, vp(o_adj.data_ptr()), vp(o_raw.data_ptr()),
+                                               vp(o_ids.data_ptr()), vp(o_lv.data_ptr()), vp(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, lib.icd_last_error()
+        torch.cuda.synchronize()
+        assert _bits(o_adj.cpu().numpy()) == _bits(adj) and _bits(o_raw.cpu().numpy()) == _bits(raw), (world, nq, k)
+        assert np.array_equal(o_ids.cpu().numpy(), ids) and np.array_equal(o_lv.cpu().numpy(), lv), (world, nq, k)

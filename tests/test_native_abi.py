@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_native.EXPORTED_SYMBOLS)
-    assert lib.icd_abi_version() == _native.ABI_VERSION == 4
+    assert lib.icd_abi_version() == _native.ABI_VERSION == 5
 
 
 def test_error_reporting_without_gpu():
