@@ -172,12 +172,36 @@ def pmc_traffic(kernel, nq, n, suffix=""):
     if not files or (nq, n) != want:
         return None, None
     try:
-        d = json.load(open(files[-1]))
+        import hashlib
+        raw = open(files[-1], "rb").read()
+        d = json.loads(raw)
         for name, v in d.items():
             if kernel in name:
-                return float(v["traffic_bytes"]), os.path.relpath(files[-1], ROOT)
+                # (the file's digest rides along: a line names exactly the bytes it cites - scripts/gpu_final.sh makes the PMC
+                #  passes BEFORE the bench lines and installs them in profiles/, so a round's lines cite that round's passes)
+                return float(v["traffic_bytes"]), f"{os.path.relpath(files[-1], ROOT)} sha256:{hashlib.sha256(raw).hexdigest()[:16]}"
     except Exception:
         return None, None
+    return None, None
+
+
+def reference_gemm():
+    """The vendor fp16 GEMM (hipBLASLt through torch.matmul) measured on ONE box in ONE call next to the coarse kernel
+    (scripts/probe/gemm_reference.py -> profiles/rNN_gemm_reference.log): TFLOP/s at the coarse pass's own shape
+    (10 240 x 37 120 x 768) - the known-good GEMM `roofline.frac_of_reference_gemm` is quoted against (cdna_hip_programming.md
+    section 5.4 rule 10). A CITATION of the committed log of the newest round, like `traffic`; None when there is none."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_reference.log")))
+    if not files:
+        return None, None
+    try:
+        for ln in open(files[-1]):
+            m = re.match(r"torch\.matmul fp16 coarse_shape_10240x37120x768: [0-9.]+ ms, ([0-9.]+) TFLOP/s", ln)
+            if m:
+                return float(m.group(1)), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        pass
     return None, None
 
 
@@ -210,6 +234,16 @@ class Ctx:
             torch.cuda.set_device(self.local_rank)
             self.dev = torch.device("cuda", self.local_rank)
         self.red_dev = self.dev if self.backend == "nccl" else torch.device("cpu")
+        # a CPU side channel for decisions that must not depend on the GPU queue (main(): did any rank's C-ABI trial hang?)
+        self.side = dist.new_group(backend="gloo") if self.world > 1 and self.backend == "nccl" else None
+
+    def any_rank(self, flag):
+        """True on every rank iff `flag` on any rank (all_reduce(MAX) of a CPU tensor over the gloo side group)"""
+        if self.world == 1:
+            return bool(flag)
+        t = self.torch.tensor([1 if flag else 0], dtype=self.torch.int32)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.side)
+        return bool(int(t.item()))
 
     def sync(self):
         if not self.cpu_only:
@@ -396,6 +430,7 @@ def run_replicated(ctx, args, index_factory=hip_index_factory):
         peak = PEAK_TFLOPS_F16 if fast else PEAK_TFLOPS_F32
         kern = "coarse_flat_kernel" if fast else "exact_topk_kernel"
         traffic, traffic_src = pmc_traffic(kern, nq, n)
+        ref_tf, ref_src = reference_gemm() if fast else (None, None)
         per_step = sorted(x / args.steps * 1e3 for x in [elapsed] + info["repeat_s"])
         line = {
             "metric": "queries_per_sec", "value": ctx.world * nq * args.steps / elapsed, "unit": "queries/s",
@@ -417,6 +452,10 @@ def run_replicated(ctx, args, index_factory=hip_index_factory):
             "kernel_ms": {kname: round(v, 5) for kname, v in prof.items() if kname != "count"},
             "roofline": {"bound": "mfma", "kernel": kern,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "frac_of_reference_gemm": (achieved / ref_tf) if ref_tf else None,
+                         "reference_gemm": {"tflops": ref_tf, "what": "vendor fp16 GEMM (hipBLASLt through torch.matmul) at 10240 x 37120 x 768 on random unit rows, "
+                                            "the same box and call as the coarse kernel's own line in that log; a plain GEMM: it selects nothing and writes 760 MB",
+                                            "source": ref_src} if ref_tf else None,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_unit": "bytes per launch (rocprofv3 PMC passes of this kernel, 2 x FETCH_SIZE + WRITE_SIZE); a citation "
                                          "of the committed profile of this workload, not measured in this run",
@@ -660,7 +699,8 @@ def run_rowshard(ctx, args, index_factory=hip_index_factory, sharded_factory=Non
                        "rows_per_gpu": n, "corpus_rows_total": ctx.world * n, "queries": nq, "slice": sl, "dim": dim, "top_k": k,
                        "parallelism": f"row-sharded x{ctx.world}", "collective": ("ncclAllGather inside icd_group_search (C ABI, RCCL opened by the library)" if getattr(sharded, "native_group", None) is not None
                                       else "all_gather_into_tensor (torch.distributed)") if ctx.world > 1 else "none (one shard)",
-                       "collective_ranks": dist.get_world_size() if ctx.world > 1 else 1},
+                       "collective_ranks": dist.get_world_size() if ctx.world > 1 else 1,
+                       "engine": getattr(sharded, "engine", "torch.distributed") if ctx.world > 1 or getattr(sharded, "native_group", None) is not None else "icd_group (C ABI)"},
             "whole_job_tflops": ctx.world * flops_gpu * steps / elapsed / 1e12,
             "ids_exact_on_sample": ids_ok, "raw_scores_exact_on_sample": raw_ok, "adjusted_sorted": sorted_ok,
             "adjusted_scores_exact_on_sample": adj_ok, "sample_queries": int(m), "sample_slices": int(len(starts)),
@@ -691,7 +731,11 @@ def test_engine():
     spec = importlib.util.spec_from_file_location("icd_bench_test_engine", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    return {"index_factory": mod.index_factory, "sharded_factory": mod.sharded_factory}
+    out = {"index_factory": mod.index_factory, "sharded_factory": mod.sharded_factory}
+    for hook in ("on_start", "on_exit"):
+        if hasattr(mod, hook):
+            out[hook] = getattr(mod, hook)
+    return out
 
 
 def free_port():
@@ -703,20 +747,34 @@ def free_port():
 
 def visible_gpus():
     """GPUs this process may use, counted WITHOUT touching the HIP runtime (torch.cuda.device_count() falls through to
-    hipGetDeviceCount when amdsmi is absent, which opens /dev/kfd): the visibility variables when set, else the KFD topology
-    nodes that have SIMDs (CPU nodes have none). None when neither source exists."""
+    hipGetDeviceCount when amdsmi is absent, which opens /dev/kfd). The visibility variables when set - the MINIMUM over
+    all that are set: HIP_/CUDA_VISIBLE_DEVICES index INTO the subset ROCR_VISIBLE_DEVICES leaves, so the smallest list
+    bounds the count - else the KFD topology nodes that have SIMDs (CPU nodes have none) and whose render device this
+    process can open (a container may see every node of the host and own only some). None when neither source exists."""
+    counts = []
     for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
-            return len([t for t in v.split(",") if t.strip() != ""])
+            counts.append(len([t for t in v.split(",") if t.strip() != ""]))
+    if counts:
+        return min(counts)
     base = "/sys/class/kfd/kfd/topology/nodes"
     try:
         count = 0
         for node in os.listdir(base):
+            simd, minor = 0, None
             with open(os.path.join(base, node, "properties")) as fh:
                 for ln in fh:
                     if ln.startswith("simd_count"):
-                        count += 1 if int(ln.split()[1]) > 0 else 0
+                        simd = int(ln.split()[1])
+                    elif ln.startswith("drm_render_minor"):
+                        minor = int(ln.split()[1])
+            if simd <= 0:
+                continue
+            dev = f"/dev/dri/renderD{minor}" if minor is not None and minor > 0 else None
+            if dev is not None and os.path.exists("/dev/dri") and not os.access(dev, os.R_OK | os.W_OK):
+                continue   # (a node of the host this container was not given)
+            count += 1
         return count
     except OSError:
         return None
@@ -794,6 +852,8 @@ def spawn_ranks(args, argv):
     watchdog.cancel()
     if timed_out:
         print(f"bench.py: the {args.gpus}-rank child did not finish within --rank-timeout {args.rank_timeout:.0f} s: the ranks (its process tree) were killed", file=sys.stderr)
+        if line is not None:   # rank 0 had printed its line before a rank hung (e.g. in the teardown): the measurement is relayed, the status says what happened
+            print(line, flush=True)
         return 124
     if rc != 0 or line is None:
         print(f"bench.py: the {args.gpus}-rank child exited with status {rc}" + ("" if line else " and printed no result line"), file=sys.stderr)
@@ -844,11 +904,10 @@ def main(argv=None):
         print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks: reporting the latter", file=sys.stderr)
 
     ctx = Ctx()
-    if os.environ.get("ICD_BENCH_TEST_FAIL_RANK") == str(ctx.rank):   # test hook: a rank that dies must fail the whole run
-        raise RuntimeError(f"rank {ctx.rank}: forced failure (ICD_BENCH_TEST_FAIL_RANK)")
-    if os.environ.get("ICD_BENCH_TEST_HANG_RANK") == str(ctx.rank):   # test hook: a rank that never returns must not hang the parent
-        time.sleep(10 ** 6)
     eng = test_engine()
+    on_exit = eng.pop("on_exit", None)
+    if "on_start" in eng:   # (the CPU test engine's fault injection: a rank that dies / never returns; nothing of the kind lives here)
+        eng.pop("on_start")(ctx)
     if args.workload == "rowshard":
         line = run_rowshard(ctx, args, **eng)
     else:
@@ -863,8 +922,16 @@ def main(argv=None):
                 line["rowshard"] = rs
     if ctx.rank == 0:
         print(json.dumps(line), flush=True)
-    if getattr(ctx, "native_hung", False):
-        # the trial's thread is stuck in a collective of the C-ABI group: the line is out, nothing else of value can happen
+    # A rank whose C-ABI trial timed out has a thread stuck in a GPU collective: it cannot enter the teardown's barrier on the
+    # same device queue, and the ranks whose trial finished would wait there for it until --rank-timeout. The ranks
+    # AGREE on the outcome over the gloo side group (CPU tensors; made before the trial): if any rank hung, every rank leaves
+    # without the barrier - the line is out, nothing else of value can happen.
+    if on_exit:   # (test engine: a rank that hangs in the teardown, after rank 0's line is out)
+        on_exit(ctx)
+    hung = ctx.any_rank(getattr(ctx, "native_hung", False))
+    if hung:
+        if ctx.rank == 0:
+            print("bench.py: a rank's C-ABI group trial timed out (native_group_trial.status): every rank exits without the teardown barrier", file=sys.stderr)
         sys.stdout.flush()
         sys.stderr.flush()
         os._exit(0)

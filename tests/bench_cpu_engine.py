@@ -80,3 +80,22 @@ def sharded_factory(index):
         s, i = index.search(qs, k)
         return s, i, index.lookup_levels(i)
     return ShardedSearch(ROW_SHARD, search_fn=search_fn, merge_fn=merge_cpu)
+
+
+def on_start(ctx):
+    """fault injection for the tests of bench.py's parent / watchdog (tests/test_bench_cpu.py): a rank that dies must fail the
+    whole run, a rank that never returns must not hang the parent. Lives HERE, in the test engine, not in bench.py."""
+    import time
+    if os.environ.get("ICD_BENCH_TEST_FAIL_RANK") == str(ctx.rank):
+        raise RuntimeError(f"rank {ctx.rank}: forced failure (ICD_BENCH_TEST_FAIL_RANK)")
+    if os.environ.get("ICD_BENCH_TEST_HANG_RANK") == str(ctx.rank):
+        time.sleep(10 ** 6)
+    if os.environ.get("ICD_BENCH_TEST_TRIAL_HUNG_RANK") == str(ctx.rank):   # as if this rank's C-ABI trial had timed out
+        ctx.native_hung = True
+
+
+def on_exit(ctx):
+    """a rank that hangs in the teardown, AFTER rank 0 has printed its line: the parent's watchdog must still relay the line"""
+    import time
+    if os.environ.get("ICD_BENCH_TEST_HANG_AT_EXIT_RANK") == str(ctx.rank):
+        time.sleep(10 ** 6)

@@ -145,6 +145,50 @@ def test_bench_hung_rank_fails_the_parent_within_the_limit():
     assert not [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
 
 
+def test_bench_gpus_8_dry_run_on_cpu():
+    """the driver's one-shot `python bench.py --gpus 8`, rehearsed on the CPU engine at reduced sizes: eight gloo ranks, ONE line
+    with value / config3 / rowshard whose collectives span 8 ranks, parent and ranks gone inside the limit"""
+    import time
+    t0 = time.time()
+    p = _run_bench(["--gpus", "8", "--rank-timeout", "400"], timeout=500)
+    took = time.time() - t0
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["value"] > 0 and line["config"]["collective_ranks"] == 8 and line["ids_exact"]
+    assert line["parity_checked_queries"] == 5                   # every 8th of rank 0's 40 queries
+    c3, rs = line["config3"], line["rowshard"]
+    assert c3["n_gpus"] == 8 and c3["config"]["queries_total"] == 8 * 70 and c3["ids_exact"] and c3["value"] > 0
+    assert rs["n_gpus"] == 8 and rs["config"]["collective_ranks"] == 8 and rs["config"]["corpus_rows_total"] == 8 * 700
+    assert rs["ids_exact_on_sample"] and rs["raw_scores_exact_on_sample"] and rs["adjusted_scores_exact_on_sample"] and rs["value"] > 0
+    assert rs["config"]["engine"] == "torch.distributed" and rs["sample_slices"] == 2 and rs["sample_queries"] == 8   # 4 per slice above two ranks
+    assert took < 400, took
+
+
+def test_bench_rank_with_a_hung_native_trial_does_not_strand_the_others():
+    """ONE rank's C-ABI trial timed out (a thread stuck in a GPU collective) - the ranks agree on that over the gloo
+    side channel and ALL leave without the teardown barrier; the line is out, the parent exits 0 at once, nobody waits for
+    --rank-timeout"""
+    import time
+    t0 = time.time()
+    p = _run_bench(["--gpus", "2", "--no-config3", "--rank-timeout", "120"], {"ICD_BENCH_TEST_TRIAL_HUNG_RANK": "1"}, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert time.time() - t0 < 100
+    line = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    assert line["n_gpus"] == 2 and line["rowshard"]["ids_exact_on_sample"]
+    assert "exits without the teardown barrier" in p.stderr
+
+
+def test_bench_watchdog_relays_a_line_that_was_already_printed():
+    """a rank that hangs AFTER rank 0 printed its line (the teardown): the watchdog kills the tree, the parent exits 124 AND relays
+    the measurement it had already read"""
+    p = _run_bench(["--gpus", "2", "--no-rowshard", "--no-config3", "--rank-timeout", "40"], {"ICD_BENCH_TEST_HANG_AT_EXIT_RANK": "1"}, timeout=200)
+    assert p.returncode == 124 and "rank-timeout" in p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     """`python bench.py --gpus N` on a box with fewer than N GPUs (none here) must not print an N = 1 line: it exits non-zero
     before starting anything"""
@@ -169,6 +213,10 @@ def test_visible_gpus_counts_without_touching_the_runtime(monkeypatch, tmp_path)
     monkeypatch.delenv("HIP_VISIBLE_DEVICES")
     monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
     assert bench.visible_gpus() == 1
+    # both kinds set: HIP indices are relative to the ROCR subset, the smaller list bounds the count
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    assert bench.visible_gpus() == 1
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
     monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
     # no variable: the topology directory (absent in this container -> None, and spawn_ranks asks torch instead)
     got = bench.visible_gpus()
