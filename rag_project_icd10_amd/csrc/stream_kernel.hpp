@@ -17,7 +17,21 @@
 // The candidate buffer of a (wave, query) holds 64 E entries with E one larger than the exact MFMA
 // kernel uses for the same KP: a 64-row step can append 64 entries at once.
 // Output: one best-first list per (query slot, wave) -> reduce_lists_kernel -> finalize_kernel<false>.
+//
+// ONE = true: the reference's own call shape (ONE query per MilvusService.search call, services/milvus_service.py:280-285;
+// also two) as ONE launch. Three differences from the form above:
+//   * the rows are spread over EVERY CU: a wave takes rows_per_step <= 64 rows per step (a multiple of 8: a stage is
+//     rows_per_step / 8 LDS-DMA pieces), so that 40 474 rows are 256 work-groups x 4 waves x 40 rows instead of 159 x 4 x 64;
+//     the ring gets the stages the smaller slices leave room for (up to 8);
+//   * the list reduction is folded in: a work-group merges its four waves' lists in LDS, publishes ONE list of KP keys
+//     (plain stores -> every wave's vmcnt(0) -> barrier -> agent-scope release -> ticket), and the work-group that draws
+//     the last ticket (agent-scope acquire) merges the <= 256 lists per query and
+//   * writes the FINAL outputs itself (emit_outputs of finalize.hpp: raw order, level reweight in double, stable re-sort,
+//     services/milvus_service.py:290-295,314): no reduce_lists launch, no finalize launch, no memset in front.
+// The ticket is a 64-bit counter that only ever counts up (work-groups per launch is a constant of the index): the last
+// arriver is the one whose ticket is = nwg - 1 modulo nwg, nothing is reset, a replayed graph needs no memset node.
 #pragma once
+#include "finalize.hpp"
 #include "topk_select.hpp"
 
 namespace icd {
@@ -42,11 +56,24 @@ struct StreamArgs {
     int ring_stages;      // 2..4 wave-private LDS stages
     float *list_scores;   // [slot][4 * nwg][KP]
     int *list_rows;
+    // ONE = true only
+    int rows_per_step;    // rows a wave takes per step (multiple of 8, <= 64); rows_per_wg is a multiple of 4 * rows_per_step
+    u64 *wg_keys;         // [slot][nwg][KP] one merged best-first list per work-group (keys, 0 = empty)
+    u64 *ticket;          // monotonic arrival counter (zeroed once, at index create)
+    FinArgs fin;          // the outputs, levels, id_base and k of the search (emit_outputs), counters / host_counters
 };
 
 template <int KP, int E, int QB>
 __host__ __device__ constexpr size_t stream_lds_bytes(int dim, int ring_stages) {
     return (size_t)QB * dim * 4 + (size_t)4 * ring_stages * ST_STAGE_BYTES + (size_t)4 * QB * 64 * E * 8;
+}
+// ONE = true: stages of rows_per_step x 128 B; the tail (merge of <= 256 lists per query: 64 KP keys per wave, + 4 KP merged
+// keys, + sorted / adjusted buffers of emit_outputs) reuses the same memory once the ring has drained
+__host__ __device__ constexpr size_t stream_one_tail_bytes(int kp) { return (size_t)4 * 64 * kp * 8 + (size_t)4 * kp * 8 + 128 * 8 + 128 * 8 + 64; }
+template <int KP, int E, int QB>
+__host__ __device__ constexpr size_t stream_one_lds_bytes(int dim, int ring_stages, int rows_per_step) {
+    const size_t body = (size_t)QB * dim * 4 + (size_t)4 * ring_stages * rows_per_step * 128 + (size_t)4 * QB * 64 * E * 8;
+    return body > stream_one_tail_bytes(KP) ? body : stream_one_tail_bytes(KP);
 }
 
 typedef float st_f32x4 __attribute__((ext_vector_type(4)));
@@ -89,9 +116,23 @@ __device__ __forceinline__ void stream_fma4(float (&acc)[QB], const float (&q)[Q
 }
 #undef ICD_F
 
-template <int KP, int E, int QB>
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate): ONE = true, whose stages hold 1-8 pieces
+__device__ __forceinline__ void wait_vmcnt_uniform(int n) {
+#define ICD_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    switch (n) {
+        ICD_VM(0) ICD_VM(1) ICD_VM(2) ICD_VM(3) ICD_VM(4) ICD_VM(5) ICD_VM(6) ICD_VM(7) ICD_VM(8) ICD_VM(9) ICD_VM(10) ICD_VM(11) ICD_VM(12)
+        ICD_VM(13) ICD_VM(14) ICD_VM(15) ICD_VM(16) ICD_VM(17) ICD_VM(18) ICD_VM(19) ICD_VM(20) ICD_VM(21) ICD_VM(22) ICD_VM(23) ICD_VM(24)
+        ICD_VM(25) ICD_VM(26) ICD_VM(27) ICD_VM(28) ICD_VM(29) ICD_VM(30) ICD_VM(31) ICD_VM(32) ICD_VM(33) ICD_VM(34) ICD_VM(35) ICD_VM(36)
+        ICD_VM(37) ICD_VM(38) ICD_VM(39) ICD_VM(40) ICD_VM(41) ICD_VM(42) ICD_VM(43) ICD_VM(44) ICD_VM(45) ICD_VM(46) ICD_VM(47) ICD_VM(48)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef ICD_VM
+}
+
+template <int KP, int E, int QB, bool ONE = false>
 __global__ __launch_bounds__(256) void stream_topk_kernel(StreamArgs a) {
     constexpr int CAP = 64 * E;
+    static_assert(!ONE || (QB <= 2 && KP <= 32), "the single-launch form serves one or two queries at k <= 32");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // (the gate looks at the device's count itself: a.nq is already clamped to max_active by the host, and a list longer
     //  than that belongs to the MFMA kernel alone - round 3: the clamped count used to pass the gate and cost 24 sweeps)
@@ -101,13 +142,16 @@ __global__ __launch_bounds__(256) void stream_topk_kernel(StreamArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int dim = a.dim, nsl = dim >> 5, D = a.ring_stages;
+    const int RPS = ONE ? a.rows_per_step : 64;            // rows of a wave per step
+    const int NP = RPS >> 3;                               // LDS-DMA pieces (8 rows x 128 B) per stage
+    const uint32_t stage_bytes = ONE ? (uint32_t)RPS * 128u : (uint32_t)ST_STAGE_BYTES;
     float *qs = reinterpret_cast<float *>(smem);                                   // [QB][dim]
-    const uint32_t ring_off = (uint32_t)QB * dim * 4 + (uint32_t)(wave * D) * ST_STAGE_BYTES;   // wave-private ring
-    u64 *bufs = reinterpret_cast<u64 *>(smem + (size_t)QB * dim * 4 + (size_t)4 * D * ST_STAGE_BYTES) +
+    const uint32_t ring_off = (uint32_t)QB * dim * 4 + (uint32_t)(wave * D) * stage_bytes;   // wave-private ring
+    u64 *bufs = reinterpret_cast<u64 *>(smem + (size_t)QB * dim * 4 + (size_t)4 * D * stage_bytes) +
                 (size_t)wave * QB * CAP;                                           // [QB][CAP]
     const int row_begin = blockIdx.x * a.rows_per_wg;
     const int row_end = min(a.n, row_begin + a.rows_per_wg);
-    const int nsteps = (row_end - row_begin + 255) >> 8;   // 256-row steps of the work-group, 64 rows per wave
+    const int nsteps = ONE ? (row_end - row_begin + 4 * RPS - 1) / (4 * RPS) : (row_end - row_begin + 255) >> 8;   // steps of the work-group: 4 waves x RPS rows
     const int nlists = 4 * a.nwg;
 
     // LDS-DMA source: lane L of piece i brings 16 B of row 8 i + (L >> 3); the 16-B pieces of a row are
@@ -117,7 +161,7 @@ __global__ __launch_bounds__(256) void stream_topk_kernel(StreamArgs a) {
     const uint32_t voff_even = (uint32_t)(lane >> 3) * row_bytes + (uint32_t)(((lane & 7) ^ (lane >> 4)) * 16);
     const uint32_t voff_odd = (uint32_t)(lane >> 3) * row_bytes + (uint32_t)(((lane & 7) ^ (4 + (lane >> 4))) * 16);
     const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.corpus) + (size_t)row_begin * dim, 0, (int)((size_t)nsteps * 256 * row_bytes), 0x00020000);
+        const_cast<float *>(a.corpus) + (size_t)row_begin * dim, 0, (int)((size_t)nsteps * (4 * RPS) * row_bytes), 0x00020000);
     const uint32_t rd_base = (uint32_t)lane * 128u + (uint32_t)(((lane >> 1) & 7) * 16);
     const uint32_t q_lane = (uint32_t)(lane & 15) * 4u;
 
@@ -141,12 +185,13 @@ __global__ __launch_bounds__(256) void stream_topk_kernel(StreamArgs a) {
         // Past the last stage it re-reads the last step (valid memory, never consumed).
         int is_t = 0, is_s = 0, is_slot = 0;
         auto issue = [&]() {
-            const uint32_t soff = (uint32_t)(wave * 64 + 256 * min(is_t, nsteps - 1)) * row_bytes + (uint32_t)is_s * 128u;
-            const uint32_t dst = ring_off + (uint32_t)is_slot * ST_STAGE_BYTES;
+            const uint32_t soff = (uint32_t)(wave * RPS + 4 * RPS * min(is_t, nsteps - 1)) * row_bytes + (uint32_t)is_s * 128u;
+            const uint32_t dst = ring_off + (uint32_t)is_slot * stage_bytes;
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, (__attribute__((address_space(3))) void *)(smem + dst + i * 1024),
-                                                         16, (i & 1) ? voff_odd : voff_even, soff + (uint32_t)i * 8u * row_bytes, 0, 0);
+                if (!ONE || i < NP)   // (wave-uniform)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(crsrc, (__attribute__((address_space(3))) void *)(smem + dst + i * 1024),
+                                                             16, (i & 1) ? voff_odd : voff_even, soff + (uint32_t)i * 8u * row_bytes, 0, 0);
             if (++is_s == nsl) { is_s = 0; ++is_t; }
             if (++is_slot == D) is_slot = 0;
         };
@@ -155,17 +200,18 @@ __global__ __launch_bounds__(256) void stream_topk_kernel(StreamArgs a) {
         int rslot = 0;
 
         for (int t = 0; t < nsteps; ++t) {
-            const int r0 = row_begin + wave * 64 + 256 * t;
+            const int r0 = row_begin + wave * RPS + 4 * RPS * t;
             float acc[QB];
 #pragma unroll
             for (int qi = 0; qi < QB; ++qi) acc[qi] = 0.0f;
             for (int s = 0; s < nsl; ++s) {
                 // stage (t, s) has landed when at most D - 2 younger stages are outstanding
-                if (D == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if constexpr (ONE) wait_vmcnt_uniform((D - 2) * NP);
+                else if (D == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else if (D == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 issue();   // into the slot read one slice ago (those reads completed before its fmas)
-                const uint32_t ad = ring_off + (uint32_t)rslot * ST_STAGE_BYTES + rd_base;
+                const uint32_t ad = ring_off + (uint32_t)rslot * stage_bytes + (ONE && lane >= RPS ? 0u : rd_base);   // (idle lanes of a short stage read row 0's bytes: in bounds, never used)
                 if (++rslot == D) rslot = 0;
                 st_f32x4 c0, c1, c2, c3, c4, c5, c6, c7;
                 asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"
@@ -194,7 +240,7 @@ __global__ __launch_bounds__(256) void stream_topk_kernel(StreamArgs a) {
             }
             // exact select: (score desc, row asc); NaN and -inf never enter
             const uint32_t row = (uint32_t)(r0 + lane);
-            const bool rvalid = (int)row < row_end;
+            const bool rvalid = (int)row < row_end && (!ONE || lane < RPS);
 #pragma unroll
             for (int qi = 0; qi < QB; ++qi) {
                 const float v = acc[qi];
