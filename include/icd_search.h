@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define ICD_ABI_VERSION 5   /* 5: icd_debug_unpack_query_slices (round 5). 4: icd_debug_set_family_order, icd_debug_set_center, icd_stats.centered / mean_share appended, icd_group_prepare / icd_group_connect (round 4). 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
+#define ICD_ABI_VERSION 5   /* 5: icd_debug_unpack_query_slices, icd_debug_set_stream_one (round 5). 4: icd_debug_set_family_order, icd_debug_set_center, icd_stats.centered / mean_share appended, icd_group_prepare / icd_group_connect (round 4). 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
 #define ICD_MAX_K 128
 
 typedef struct icd_index icd_index;
@@ -291,6 +291,11 @@ int icd_debug_set_family_order(int32_t enabled);
 /* Test switch, process-wide, read by icd_index_create (default 1): 0 keeps the fp16 corpus image uncentred whatever the
  * rows look like (icd_stats.centered). A performance decision only: results are identical either way. */
 int icd_debug_set_center(int32_t enabled);
+
+/* Test / A-B switch, process-wide, read by every search (default 1): 0 sends calls of one or two queries (the reference's own
+ * call shape, services/milvus_service.py:280-285) through the general streaming path - memset, stream_topk, reduce_lists,
+ * finalize: four operations - instead of the single-launch kernel that folds all of it. Results are identical either way. */
+int icd_debug_set_stream_one(int32_t enabled);
 
 /* Test entry: the unpack step of a query-sharded icd_group_search (one kernel: the all-gathered PADDED slices -> the
  * contiguous [nq][k] outputs) on a caller-made receive buffer, so that its index arithmetic can be checked for any world

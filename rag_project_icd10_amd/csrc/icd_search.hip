@@ -40,6 +40,7 @@ thread_local std::string g_err = "";
 bool g_permute = true;   // test switch (icd_debug_set_permute): row order of the fp16 corpus copy
 bool g_probe = true;     // test switch (icd_debug_set_create_probe): the corpus-shape probe of icd_index_create
 bool g_center = true;         // test switch (icd_debug_set_center): the fp16 corpus image is centred when the rows share a large common component
+bool g_stream_one = true;     // test switch (icd_debug_set_stream_one): one or two queries per call take the single-launch streaming kernel
 bool g_family_order = true;   // test switch (icd_debug_set_family_order): the wide-window finalize visits the queries in family order
 
 int fail(int code, const char *fmt, ...) {
@@ -183,6 +184,11 @@ struct icd_index {
     // output staging (used when the caller's buffers are host memory)
     float *o_scores = nullptr; long long *o_ids = nullptr;
     double *o_adj = nullptr; float *o_adj_raw = nullptr; long long *o_adj_ids = nullptr; int *o_adj_lv = nullptr;
+    // small host calls (the reference's one-query-per-call shape): ONE pinned, mapped block - the query goes through its first
+    // part (CPU copy + a true asynchronous H2D copy; a pageable source makes hipMemcpyAsync stage and wait), the kernels write
+    // the results straight into its second part (zero-copy stores over PCIe) and the host copies them out after the stream
+    // synchronisation: no D2H memcpy call at all (six of them to pageable memory cost ~60 us of a 113-us call)
+    char *h_pin = nullptr, *h_pin_dev = nullptr;
     size_t bytes_ws = 0;
     // knobs / counters
     int chunks_override = 0;
@@ -243,6 +249,7 @@ void free_all(icd_index *x) {
     hipFree(x->o_adj_ids); hipFree(x->o_adj_lv);
     hipFree(x->dbg);
     if (x->h_nflag) hipHostFree(x->h_nflag);
+    if (x->h_pin) hipHostFree(x->h_pin);
     if (x->ev_nflag) hipEventDestroy(x->ev_nflag);
     for (int r = 0; r < EV_RING; ++r)
         for (int i = 0; i <= NUM_EV; ++i)
@@ -376,6 +383,8 @@ int launch_coarse_w8(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream_t
 // streaming exact kernel + list reduction for a sparse query set (device-side gated when nq_ptr is given).
 // p_out = 0: choose the smallest number of output lists (direct tiny-batch path); returns it in *p_used.
 constexpr int LDS_LIMIT = 160 * 1024;   // LDS per CU (MI355X_MICROARCH.md)
+constexpr size_t PIN_Q_BYTES = 64 * 1024;     // queries of a small host call (16 x 1024 floats)
+constexpr size_t PIN_OUT_BYTES = 96 * 1024;   // their results: nq * k * 36 bytes over the six output arrays (nq * k <= 2730)
 
 // does a pass of qb queries fit LDS with the minimum ring of two stages per wave?
 inline bool stream_fits(int kp, int qb, int dim) {
@@ -428,6 +437,45 @@ int launch_stream(icd_index *x, const float *dq, const int *qlist, const int *nq
         HIP_TRY(hipGetLastError());
         nlists = plan[l];
     }
+    return ICD_OK;
+}
+
+// The reference's call shape - ONE query per MilvusService.search call (services/milvus_service.py:280-285), or two - as ONE
+// launch: stream_topk_kernel<..., ONE = true> (stream_kernel.hpp) spreads the rows over every CU, merges the lists in the
+// kernel (last-arriver ticket) and writes the final outputs itself. Geometry: rows per wave and step = the CU's share / 4,
+// rounded up to whole 8-row LDS-DMA pieces (at most 64); the ring takes the stages that fit next to the candidate buffers.
+struct StreamOnePlan { int rps, rows_per_wg, nwg, stages; };
+inline bool plan_stream_one(int n, int dim, int num_cu, int qb, int cap_entries, StreamOnePlan *p) {
+    const int ncu = std::max(1, std::min(num_cu, 256));
+    const int per_cu = (n + ncu - 1) / ncu;
+    const int rps = std::min(64, ((per_cu + 3) / 4 + 7) / 8 * 8);
+    const int steps = (per_cu + 4 * rps - 1) / (4 * rps);
+    p->rps = rps; p->rows_per_wg = 4 * rps * steps; p->nwg = (n + p->rows_per_wg - 1) / p->rows_per_wg;
+    const size_t fixed = (size_t)qb * dim * 4 + (size_t)4 * qb * cap_entries * 8;
+    if (fixed + (size_t)4 * 2 * rps * 128 > (size_t)LDS_LIMIT) return false;
+    p->stages = (int)std::min<size_t>(8, ((size_t)LDS_LIMIT - fixed) / ((size_t)4 * rps * 128));
+    return p->nwg >= 1 && p->nwg <= 256 && p->stages >= 2;
+}
+
+template <int KP, int E, int QB>
+int launch_stream_one(icd_index *x, const float *dq, int nq, const FinArgs &f, hipStream_t s) {
+    StreamOnePlan pl;
+    if (!plan_stream_one((int)x->n, x->dim, x->num_cu, QB, 64 * E, &pl)) return fail(ICD_ERR_INVALID, "single-launch stream kernel: no plan for n=%lld dim=%d", (long long)x->n, x->dim);
+    if ((size_t)nq * pl.nwg * KP * 2 > x->lists_cap) return fail(ICD_ERR_INVALID, "stream workspace too small");
+    StreamArgs a{};
+    a.corpus = x->corpus; a.queries = dq; a.qlist = nullptr; a.nq_ptr = nullptr; a.nq = nq; a.max_active = nq;
+    a.n = (int)x->n; a.dim = x->dim; a.rows_per_wg = pl.rows_per_wg; a.nwg = pl.nwg; a.ring_stages = pl.stages;
+    a.rows_per_step = pl.rps;
+    a.wg_keys = reinterpret_cast<u64 *>(x->lists_s);                    // (the per-wave lists' workspace: unused by this form)
+    a.ticket = reinterpret_cast<u64 *>(x->nflag + 6);                   // nflag[6..7]: 8-byte aligned, zeroed at create, only ever counts up
+    a.fin = f;
+    a.fin.counters = x->nflag; a.fin.host_counters = x->h_nflag_dev;
+    auto kern = stream_topk_kernel<KP, E, QB, true>;
+    const size_t lds = stream_one_lds_bytes<KP, E, QB>(x->dim, pl.stages, pl.rps);
+    static int configured[MAX_DEVICES] = {};
+    HIP_TRY(ensure_dynamic_lds(kern, x->device, (size_t)LDS_LIMIT, configured));
+    hipLaunchKernelGGL(kern, dim3(pl.nwg), dim3(256), lds, s, a);
+    HIP_TRY(hipGetLastError());
     return ICD_OK;
 }
 
@@ -611,9 +659,19 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     // (the fallback counter starts every search at zero: the exact-only paths clear it here, the fast path in its
     //  query-prep launch - one launch less per step)
     if (tiny) {
-        HIP_TRY(hipMemsetAsync(x->nflag, 0, sizeof(int), s));
         x->last_mode = ICD_MODE_EXACT;
         x->last_chunks = p_sparse;
+        StreamOnePlan pl;
+        bool one = nq <= 2 && kpx == 16 && g_stream_one && plan_stream_one((int)x->n, x->dim, x->num_cu, (int)nq, 64 * 2, &pl) &&
+                   (size_t)nq * pl.nwg * kpx * 2 <= x->lists_cap;
+        if (one) {   // one or two queries (the reference's call shape): ONE launch, no memset, no reduction, no finalize
+            rec(x, 3, s);
+            const int rc1 = nq == 1 ? launch_stream_one<16, 2, 1>(x, dq, 1, f, s) : launch_stream_one<16, 2, 2>(x, dq, 2, f, s);
+            rec(x, 4, s);
+            rec(x, 5, s);
+            return rc1;
+        }
+        HIP_TRY(hipMemsetAsync(x->nflag, 0, sizeof(int), s));
         rec(x, 3, s);
         return run_exact(nullptr, nullptr, p_sparse, false, true);
     }
@@ -1127,6 +1185,8 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     memset(x->h_nflag, 0, 8 * sizeof(int));
     CR_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&x->h_nflag_dev), x->h_nflag, 0));
     CR_TRY(hipEventCreateWithFlags(&x->ev_nflag, hipEventDisableTiming));
+    CR_TRY(hipHostMalloc(reinterpret_cast<void **>(&x->h_pin), PIN_Q_BYTES + PIN_OUT_BYTES, hipHostMallocMapped));
+    CR_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&x->h_pin_dev), x->h_pin, 0));
     CR_TRY(wsalloc(&x->dbg, (size_t)8192 * 16));
     CR_TRY(hipMemset(x->dbg, 0, (size_t)8192 * 16 * 8));
     CR_TRY(wsalloc(&x->flagged, (size_t)3 * x->max_nq_pad));
@@ -1193,11 +1253,27 @@ static int search_common(icd_index *x, const float *queries, int64_t nq, int32_t
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const float *dq = queries;
     if (!q_on_device) {
-        HIP_TRY(hipMemcpyAsync(x->qdev, queries, (size_t)nq * x->dim * sizeof(float), hipMemcpyHostToDevice, s));
+        const size_t qbytes = (size_t)nq * x->dim * sizeof(float);
+        if (qbytes <= PIN_Q_BYTES) {
+            memcpy(x->h_pin, queries, qbytes);
+            HIP_TRY(hipMemcpyAsync(x->qdev, x->h_pin, qbytes, hipMemcpyHostToDevice, s));
+        } else {
+            HIP_TRY(hipMemcpyAsync(x->qdev, queries, qbytes, hipMemcpyHostToDevice, s));
+        }
         dq = x->qdev;
     }
     Outs dev = user;
-    if (!out_on_device) {
+    const size_t no_small = (size_t)nq * k;
+    const bool pinned_out = !out_on_device && no_small * 36 <= PIN_OUT_BYTES;
+    if (pinned_out) {   // the six arrays back to back in the mapped block, 8-byte ones first
+        char *d = x->h_pin_dev + PIN_Q_BYTES;
+        dev.adj = user.adj ? reinterpret_cast<double *>(d) : nullptr;                          d += no_small * 8;
+        dev.ids = user.ids ? reinterpret_cast<long long *>(d) : nullptr;                       d += no_small * 8;
+        dev.adj_ids = user.adj_ids ? reinterpret_cast<long long *>(d) : nullptr;               d += no_small * 8;
+        dev.scores = user.scores ? reinterpret_cast<float *>(d) : nullptr;                     d += no_small * 4;
+        dev.adj_raw = user.adj_raw ? reinterpret_cast<float *>(d) : nullptr;                   d += no_small * 4;
+        dev.adj_lv = user.adj_lv ? reinterpret_cast<int *>(d) : nullptr;
+    } else if (!out_on_device) {
         dev.scores = user.scores ? x->o_scores : nullptr;
         dev.ids = user.ids ? x->o_ids : nullptr;
         dev.adj = user.adj ? x->o_adj : nullptr;
@@ -1211,6 +1287,17 @@ static int search_common(icd_index *x, const float *queries, int64_t nq, int32_t
     // the search's last kernel has written the fallback counters to pinned host memory: icd_index_stats reads them after
     // waiting for THIS event only (no device-wide synchronisation: other streams - an encoder - keep running)
     HIP_TRY(hipEventRecord(x->ev_nflag, s));
+    if (pinned_out) {
+        HIP_TRY(hipStreamSynchronize(s));   // (the kernels' stores to the mapped block are visible behind it, like the counters')
+        const char *h = x->h_pin + PIN_Q_BYTES;
+        if (user.adj) memcpy(user.adj, h, no_small * 8);              h += no_small * 8;
+        if (user.ids) memcpy(user.ids, h, no_small * 8);              h += no_small * 8;
+        if (user.adj_ids) memcpy(user.adj_ids, h, no_small * 8);      h += no_small * 8;
+        if (user.scores) memcpy(user.scores, h, no_small * 4);        h += no_small * 4;
+        if (user.adj_raw) memcpy(user.adj_raw, h, no_small * 4);      h += no_small * 4;
+        if (user.adj_lv) memcpy(user.adj_lv, h, no_small * 4);
+        return ICD_OK;
+    }
     if (!out_on_device) {
         const size_t no = (size_t)nq * k;
         if (user.scores) HIP_TRY(hipMemcpyAsync(user.scores, dev.scores, no * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -1403,6 +1490,11 @@ int icd_debug_unpack_query_slices(int32_t device, const void *gathered, int32_t 
     if (icd_internal_unpack_query_slices(rb, rb + per * world * 8, rb + per * world * 16, rb + per * world * 20, world, nq, k,
                                          (long long)width, out_adj, out_raw, out_ids, out_levels, stream))
         return fail(ICD_ERR_HIP, "the unpack launch failed");
+    return ICD_OK;
+}
+
+int icd_debug_set_stream_one(int32_t enabled) {
+    g_stream_one = enabled != 0;
     return ICD_OK;
 }
 

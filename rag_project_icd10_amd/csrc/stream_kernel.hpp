@@ -69,7 +69,7 @@ __host__ __device__ constexpr size_t stream_lds_bytes(int dim, int ring_stages) 
 }
 // ONE = true: stages of rows_per_step x 128 B; the tail (merge of <= 256 lists per query: 64 KP keys per wave, + 4 KP merged
 // keys, + sorted / adjusted buffers of emit_outputs) reuses the same memory once the ring has drained
-__host__ __device__ constexpr size_t stream_one_tail_bytes(int kp) { return (size_t)4 * 64 * kp * 8 + (size_t)4 * kp * 8 + 128 * 8 + 128 * 8 + 64; }
+__host__ __device__ constexpr size_t stream_one_tail_bytes(int kp) { return (size_t)4 * kp * kp * 8 + 16 + 128 * 8 + 128 * 8; }
 template <int KP, int E, int QB>
 __host__ __device__ constexpr size_t stream_one_lds_bytes(int dim, int ring_stages, int rows_per_step) {
     const size_t body = (size_t)QB * dim * 4 + (size_t)4 * ring_stages * rows_per_step * 128 + (size_t)4 * QB * 64 * E * 8;
@@ -77,6 +77,7 @@ __host__ __device__ constexpr size_t stream_one_lds_bytes(int dim, int ring_stag
 }
 
 typedef float st_f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) u64 gu64;   // a GLOBAL (never flat) word of an inter-work-group hand-off
 
 // acc[qi] = fma(q[qi][d], c[d], acc[qi]) for the four d of one 16-B piece, d ascending, as QB independent
 // chains. The query values live one per lane (lane & 15 = d & 15, replicated in the four DPP rows), and
@@ -263,6 +264,138 @@ __global__ __launch_bounds__(256) void stream_topk_kernel(StreamArgs a) {
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the run-ahead stages before the ring is reused
+        if constexpr (ONE) {
+            // ---- single-launch form: work-group merge -> publish -> the last arriver merges and writes the outputs ------------
+            constexpr int NE4 = (4 * KP + 63) / 64;   // keys per lane of a 4 x KP merge
+            const uint32_t ring_base = (uint32_t)QB * dim * 4;
+            u64 *bufs_all = reinterpret_cast<u64 *>(smem + (size_t)QB * dim * 4 + (size_t)4 * D * stage_bytes);
+            int nb_mine[QB];
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi) {   // every wave: its buffers sorted best-first
+                nb_mine[qi] = 0;
+                if (qi < nqp) {
+                    u64 kth;
+                    if (cnt[qi] > 0) compact_one<KP, E>(bufs + (size_t)qi * CAP, cnt[qi], lane, kth);
+                    nb_mine[qi] = min(cnt[qi], KP);
+                }
+            }
+            __syncthreads();   // every wave is past its loop (and drained its own LDS-DMA): the ring's memory is free
+            int *nbw = reinterpret_cast<int *>(smem + ring_base + 4096);   // [4][QB] (the ring is >= 8 KB: 4 waves x >= 2 stages x >= 1 KB)
+            int *flag = nbw + 16;
+            if (lane == 0) {
+#pragma unroll
+                for (int qi = 0; qi < QB; ++qi) nbw[wave * QB + qi] = nb_mine[qi];
+            }
+            __syncthreads();
+            if (wave < nqp) {   // wave qi merges query qi's four lists into the work-group's one
+                const int qi = wave;
+                u64 *keysA = reinterpret_cast<u64 *>(smem + ring_base) + (size_t)qi * (64 * NE4);
+                u64 key[NE4];
+                int rank[NE4];
+#pragma unroll
+                for (int e = 0; e < NE4; ++e) {
+                    const int i = lane + 64 * e, sw = i / KP, j = i - sw * KP;
+                    key[e] = (i < 4 * KP && j < nbw[sw * QB + qi]) ? bufs_all[((size_t)sw * QB + qi) * CAP + j] : 0ull;
+                    keysA[i] = key[e];
+                }
+                rank_top<NE4>(key, rank, 4 * KP, KP, keysA, lane);   // (<= 128 candidates: plain counting, every rank exact)
+                int nvalid = 0;
+#pragma unroll
+                for (int e = 0; e < NE4; ++e) nvalid += __popcll(__ballot(key[e] != 0ull));
+                // write-through (sc1) stores: the list leaves this XCD's L2 without a release fence (MI355X_MICROARCH.md,
+                // visibility: the form "sc1 stores + every storing wave's vmcnt(0) + barrier + ONE lane's agent-scope atomic add;
+                // the work-group whose add came last reads with sc1 loads", one work-group per CU, 8-byte accesses)
+                gu64 *dst = (gu64 *)(a.wg_keys) + ((size_t)(q0 + qi) * gridDim.x + blockIdx.x) * KP;
+                for (int j = lane; j < KP; j += 64)
+                    if (j >= nvalid) __hip_atomic_store(dst + j, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int e = 0; e < NE4; ++e)
+                    if (key[e] != 0ull && rank[e] < KP) __hip_atomic_store(dst + rank[e], key[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // publish: every storing wave's vmcnt(0) -> barrier -> ONE lane's ticket (agent-scope atomic add)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const u64 t = __hip_atomic_fetch_add((gu64 *)(a.ticket), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *flag = (t % (u64)gridDim.x) == (u64)gridDim.x - 1ull ? 1 : 0;   // (written after the add has returned)
+            }
+            __syncthreads();
+            if (*flag == 0) return;   // (work-group-uniform; ONE = true runs a single pass: nq <= QB)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: keeps the compiler from moving the sc1 loads up)
+            // ---- the last arriver: <= 256 lists per query, lane = list (best first) ------------------------------------------
+            // A list's head is its best key. The KP-th largest of a wave's 64 heads bounds the wave's KP-th best from below (KP
+            // distinct keys reach it); only keys at or above that bound can rank: the four waves compact theirs into one LDS list
+            // (tens of keys for Gaussian data, at most 4 KP KP) and wave 0 ranks that list alone.
+            const int nl = (int)gridDim.x;
+            u64 *surv = reinterpret_cast<u64 *>(smem);              // [4][KP * KP] survivors of the four waves
+            int *nsurv = reinterpret_cast<int *>(surv + 4 * KP * KP);   // [4]
+            u64 *sorted = reinterpret_cast<u64 *>(nsurv + 4);       // [128]
+            double *adjbuf = reinterpret_cast<double *>(sorted + 128);   // [128]
+            for (int qi = 0; qi < nqp; ++qi) {
+                const int li = wave * 64 + lane;
+                u64 key[KP];
+                // (sc1 on EVERY load of the handed-off bytes: 16-byte buffer loads, aux 16 = sc1)
+                const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(a.wg_keys + (size_t)(q0 + qi) * nl * KP, 0, nl * KP * 8, 0x00020000);
+#pragma unroll
+                for (int e = 0; e < KP; e += 2) {
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b128(krsrc, (uint32_t)(min(li, nl - 1) * KP + e) * 8u, 0, 16);
+                    key[e] = li < nl ? (((u64)v[1] << 32) | (u64)v[0]) : 0ull;
+                    key[e + 1] = li < nl ? (((u64)v[3] << 32) | (u64)v[2]) : 0ull;
+                }
+                const u64 head = key[0];
+                int above = 0;   // lanes whose head beats this lane's (keys are unique; empty lists hold 0)
+                for (int l = 0; l < 64; ++l) above += (readlane_u64(head, l) > head) ? 1 : 0;
+                const u64 hit = __ballot(head != 0ull && above == KP - 1);
+                const u64 bound = hit ? readlane_u64(head, __ffsll((long long)hit) - 1) : 0ull;   // fewer than KP lists: keep all
+                const u64 lt = (1ull << lane) - 1ull;
+                int ns = 0;
+                u64 *mine = surv + (size_t)wave * (KP * KP);
+#pragma unroll
+                for (int e = 0; e < KP; ++e) {   // (a list is sorted: once a key falls below the bound the rest do; at most KP lanes hold any)
+                    const bool keep = key[e] != 0ull && key[e] >= bound;
+                    const u64 m = __ballot(keep);
+                    if (m == 0ull) break;   // wave-uniform
+                    if (keep) mine[ns + __popcll(m & lt)] = key[e];
+                    ns += __popcll(m);
+                }
+                if (lane == 0) nsurv[wave] = ns;
+                __syncthreads();
+                // the union of the four waves' survivors, ranked by counting among themselves: the overall top KP is in it (each
+                // wave's top KP is, and a key outside its wave's top KP is outside the overall one). Tens of keys: every wave
+                // ranks a 64-key slice of the union against all of it (wave-uniform LDS addresses: broadcasts).
+                const int n0 = nsurv[0], n1 = nsurv[1], n2 = nsurv[2], n3 = nsurv[3];
+                const int tot = n0 + n1 + n2 + n3;
+                for (int base = wave * 64; base < tot; base += 256) {
+                    const int i = base + lane;
+                    u64 ku = 0ull;
+                    if (i < tot) {
+                        const int w = i < n0 ? 0 : (i < n0 + n1 ? 1 : (i < n0 + n1 + n2 ? 2 : 3));
+                        const int j = i - (w == 0 ? 0 : (w == 1 ? n0 : (w == 2 ? n0 + n1 : n0 + n1 + n2)));
+                        ku = surv[(size_t)w * (KP * KP) + j];
+                    }
+                    int ru = 0;
+                    for (int w = 0; w < 4; ++w) {
+                        const int nw = nsurv[w];
+                        const u64 *sw = surv + (size_t)w * (KP * KP);
+                        for (int j = 0; j < nw; ++j) ru += (sw[j] > ku) ? 1 : 0;
+                    }
+                    if (ku != 0ull && ru < 128) sorted[ru] = ku;
+                }
+                __syncthreads();
+                if (wave == 0) {
+                    const int slot = q0 + qi;
+                    const int qidx = a.qlist ? a.qlist[slot] : slot;
+                    emit_outputs(a.fin, qidx, sorted, min(min(tot, KP), a.fin.k), adjbuf, lane);
+                }
+                __syncthreads();
+            }
+            if (tid == 0 && a.fin.host_counters) {   // what the memset in front and finalize<false>'s block 0 did for this path
+                a.fin.counters[0] = 0;
+                a.fin.host_counters[0] = 0;
+                for (int i = 1; i < 5; ++i) a.fin.host_counters[i] = a.fin.counters[i];
+            }
+            return;
+        } else {
         // this wave's best-first list of every query of the pass
 #pragma unroll
         for (int qi = 0; qi < QB; ++qi) {
@@ -280,6 +413,7 @@ __global__ __launch_bounds__(256) void stream_topk_kernel(StreamArgs a) {
                     a.list_rows[o + j] = r;
                 }
             }
+        }
         }
     }
 }

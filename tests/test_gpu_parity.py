@@ -1121,3 +1121,40 @@ def test_query_sharded_unpack_kernel_matches_the_host_concatenation(world):
         torch.cuda.synchronize()
         assert _bits(o_adj.cpu().numpy()) == _bits(adj) and _bits(o_raw.cpu().numpy()) == _bits(raw), (world, nq, k)
         assert np.array_equal(o_ids.cpu().numpy(), ids) and np.array_equal(o_lv.cpu().numpy(), lv), (world, nq, k)
+
+
+@pytest.mark.parametrize("n", [7, 100, 129, 1000, 40474, 300000])
+def test_one_and_two_queries_take_the_single_launch_kernel_and_match_the_oracle(oracle, n):
+    """The reference's call shape - ONE query per MilvusService.search call (services/milvus_service.py:280-285) - and two:
+    stream_topk_kernel<ONE> folds the list reduction and finalize into the streaming launch (last-arriver ticket). Bit-equal
+    to the oracle and to the general four-operation path (icd_debug_set_stream_one(0)), over corpus sizes from one
+    work-group to multi-step sweeps, k = 1 ... 16, exact ties (duplicate rows) included; repeated calls (the ticket only
+    ever counts up)."""
+    dim = 768
+    corpus, levels = unit_rows(n, dim, 41 + n), icd_levels(n, 42 + n)
+    if n >= 100:
+        corpus[5::7] = corpus[2]          # duplicate rows: exact score ties, broken by row id
+    queries = unit_rows(6, dim, 43 + n)
+    queries[5] = corpus[2]                # a query that IS the duplicated row
+    idx = IcdIndex(corpus, levels, max_nq=64, max_k=16)
+    lib = _native.load_library()
+    try:
+        for k in (1, 5, 10, 16):
+            for lo, hi in ((0, 1), (1, 2), (2, 4), (4, 6), (5, 6)):
+                q = queries[lo:hi]
+                os_, oi = oracle.flat_ip_topk(corpus, q, k)
+                want = oracle.reweight(os_, oi, levels)
+                lib.icd_debug_set_stream_one(1)
+                for rep in range(2):
+                    s, i = idx.search(q, k)
+                    got = idx.search_reweighted(q, k)
+                    assert np.array_equal(i, oi) and _bits(s) == _bits(os_), (n, k, lo, hi, rep)
+                    assert np.array_equal(got[2], want[2]) and _bits(got[0]) == _bits(want[0]) and _bits(got[1]) == _bits(want[1])
+                    assert np.array_equal(got[3], want[3])
+                assert idx.stats()["last_mode"] == MODE_EXACT and idx.stats()["last_fallback"] == 0
+                lib.icd_debug_set_stream_one(0)
+                old = idx.search_reweighted(q, k)
+                assert all(_bits(a) == _bits(b) for a, b in zip(old, got))
+    finally:
+        lib.icd_debug_set_stream_one(1)
+        idx.close()
