@@ -339,6 +339,94 @@ def side_workload(*a, **kw):
         return {"workload": a[3] if len(a) > 3 else "?", "error": f"{type(exc).__name__}: {exc}", "traceback": traceback.format_exc()[-1500:]}
 
 
+def single_query_extra(ctx, args, index_factory):
+    """The reference's own call shape (services/milvus_service.py:280-285: ONE query per MilvusService.search call) at the real
+    CSV's size, k = 5 (the /query default top_k) and 10 (search's default): what the GPU needs per call (hipEvents of the
+    library around its kernels; bytes of the fp32 corpus / that time against 8 TB/s), what a host caller of icd_index_search
+    pays per call (numpy in, numpy out, one call at a time), and the same through MilvusService.search (vector in, hit dicts
+    out). Every timed call's result is checked against the oracle afterwards (64 distinct queries)."""
+    import tempfile
+    torch = ctx.torch
+    n, dim = 40474, 768
+    corpus, levels = unit_rows(n, dim, 1234), icd_levels(n, 1235)
+    queries = unit_rows(64, dim, 777)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    index = index_factory(corpus, levels, ctx.local_rank, 64, 10)
+    dq = torch.from_numpy(queries).to(ctx.dev)
+    out = {"workload": f"ONE query per call (the reference's call shape), {n}x{dim} fp32 rows", "corpus_rows": n, "by_k": {}}
+    bytes_per_call = float(n) * dim * 4
+    for k in (5, 10):
+        os_, oi = orc.flat_ip_topk(corpus, queries, k)
+        want = orc.reweight(os_, oi, levels)
+        for _ in range(30):
+            index.search_reweighted(dq[:1], k)
+        ctx.sync()
+        index.set_profiling(True)
+        index.profile_summary()
+        got = [index.search_reweighted(dq[i:i + 1], k) for i in range(64)]
+        ctx.sync()
+        prof = index.profile_summary()
+        index.set_profiling(False)
+        dev_ok = all(np.array_equal(got[i][2].cpu().numpy()[0], want[2][i]) and got[i][0].cpu().numpy().tobytes() == want[0][i].tobytes() for i in range(64))
+        lat, host_ok = [], True
+        for i in range(20):
+            index.search_reweighted(queries[i:i + 1], k)
+        for i in range(192):
+            t0 = time.perf_counter()
+            r = index.search_reweighted(queries[i & 63:(i & 63) + 1], k)
+            lat.append((time.perf_counter() - t0) * 1e6)
+            host_ok = host_ok and np.array_equal(r[2][0], want[2][i & 63]) and r[0].tobytes() == want[0][i & 63].tobytes()
+        lat.sort()
+        kernel_us = float(prof.get("ms_total", 0.0)) * 1e3
+        out["by_k"][str(k)] = {"top_k": k, "gpu_us_per_call": kernel_us, "kernel_us_per_call": (float(prof.get("ms_exact", 0.0)) + float(prof.get("ms_exact_finalize", 0.0))) * 1e3,
+                               "bytes_per_call": bytes_per_call,
+                               "roofline": {"bound": "hbm", "kernel": "stream_topk_kernel", "achieved": bytes_per_call / (kernel_us * 1e-6) / 1e9 if kernel_us > 0 else 0.0,
+                                            "peak": 8000.0, "unit": "GB/s", "frac": bytes_per_call / (kernel_us * 1e-6) / 8e12 if kernel_us > 0 else 0.0,
+                                            "calls_averaged": int(prof.get("count", 0))},
+                               "icd_index_search_host_call_us": {"median": lat[len(lat) // 2], "p10": lat[len(lat) // 10], "p90": lat[len(lat) * 9 // 10], "calls": len(lat)},
+                               "ids_exact": bool(dev_ok and host_ok), "parity_checked_calls": 64 + len(lat)}
+    index.close()
+    try:   # the service on top: MilvusService.search(vector, top_k) -> list of hit dicts
+        tmp = tempfile.mkdtemp(prefix="icd_bench_store_")
+        saved = {v: os.environ.get(v) for v in ("MILVUS_MODE", "MILVUS_DB_PATH", "MILVUS_COLLECTION_NAME")}
+        os.environ.update({"MILVUS_MODE": "local", "MILVUS_DB_PATH": tmp, "MILVUS_COLLECTION_NAME": "icd10_bench"})
+        from rag_project_icd10_amd.services.milvus_service import MilvusService
+
+        class _Dim:
+            def encode_query(self, text):
+                return np.zeros(dim, np.float32)
+        svc = MilvusService(_Dim())
+        recs = [{"code": f"X{i:05d}", "preferred_zh": "", "level": int(levels[i])} for i in range(n)]
+        for b in range(0, n, 8192):
+            svc.insert_records(recs[b:b + 8192], [corpus[i] for i in range(b, min(n, b + 8192))])
+        for k in (5, 10):
+            os_, oi = orc.flat_ip_topk(corpus, queries, k)
+            want = orc.reweight(os_, oi, levels)
+            for i in range(20):
+                svc.search(queries[i], k)
+            lat, ok = [], True
+            for i in range(192):
+                t0 = time.perf_counter()
+                hits = svc.search(queries[i & 63], k)
+                lat.append((time.perf_counter() - t0) * 1e6)
+                ok = ok and [h["code"] for h in hits] == [f"X{j:05d}" for j in want[2][i & 63]] and [h["score"] for h in hits] == list(want[0][i & 63])
+            lat.sort()
+            out["by_k"][str(k)]["milvus_service_search_us"] = {"median": lat[len(lat) // 2], "p10": lat[len(lat) // 10], "p90": lat[len(lat) * 9 // 10], "calls": len(lat)}
+            out["by_k"][str(k)]["service_hits_exact"] = bool(ok)
+        svc.disconnect()
+        for v, old in saved.items():
+            if old is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = old
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    except Exception as exc:   # pragma: no cover - reported in place
+        out["milvus_service_error"] = f"{type(exc).__name__}: {exc}"
+    return out
+
+
 def _side_workload(ctx, args, index_factory, name, corpus, levels, queries, k, mode, steps, first_batch=False):
     """one of the line's `extra` objects: the same step on other data / another size / the exact kernel alone, timed
     over `steps` steps after a short warm-up and checked against the oracle on every query, in this run.
@@ -483,6 +571,18 @@ def run_replicated(ctx, args, index_factory=hip_index_factory):
             ex["family"] = side_workload(ctx, args, index_factory, f"ICD-shaped corpus: {args.family_families} families x {args.family_rows} near-identical rows in code order "
                                          f"(mutual cosine 0.99), {nq} queries, k = {k}; a fresh index: first batch, then the steady state",
                                          fam_c, icd_levels(len(fam_c), 8), fam_q, k, mode, steps_x, first_batch=True)
+        if mode == MODE_AUTO and not args.no_family:
+            # the rest of the reference's parameter range: /query searches top_k * 2 with top_k <= 50 (models/icd_models.py:138,
+            # services/multi_diagnosis_service.py:153) -> k = 100; the code-default encoder is 1024-d (services/embedding_service.py:26)
+            ex["k100"] = side_workload(ctx, args, index_factory, f"the headline data at k = 100 (the largest k /query can ask for): {nq} x {n}x768",
+                                       corpus, levels, queries, 100, mode, max(3, steps_x // 2))
+            ex["dim1024"] = side_workload(ctx, args, index_factory, f"1024-d (the reference's code-default encoder): {nq} x {n}x1024, k = {k}",
+                                          unit_rows(n, 1024, 2234), levels, unit_rows(nq, 1024, 6321), k, mode, max(3, steps_x // 2))
+            if not ctx.cpu_only:   # (the host-call and service latencies are the library's: nothing to measure on the CPU test engine)
+                try:
+                    ex["single_query"] = single_query_extra(ctx, args, index_factory)
+                except Exception as exc:   # pragma: no cover - reported, never fatal
+                    ex["single_query"] = {"error": f"{type(exc).__name__}: {exc}"}
         if mode == MODE_AUTO:
             ex["exact_mode"] = side_workload(ctx, args, index_factory, f"--mode exact: the fp32-MFMA kernel alone, {nq} x {n}x768",
                                              corpus, levels, queries, k, MODE_EXACT, max(3, steps_x // 4))

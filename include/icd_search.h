@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define ICD_ABI_VERSION 5   /* 5: icd_debug_unpack_query_slices, icd_debug_set_stream_one (round 5). 4: icd_debug_set_family_order, icd_debug_set_center, icd_stats.centered / mean_share appended, icd_group_prepare / icd_group_connect (round 4). 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
+#define ICD_ABI_VERSION 5   /* 5: icd_debug_unpack_query_slices, icd_debug_set_stream_one, icd_debug_set_pacing (round 5). 4: icd_debug_set_family_order, icd_debug_set_center, icd_stats.centered / mean_share appended, icd_group_prepare / icd_group_connect (round 4). 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
 #define ICD_MAX_K 128
 
 typedef struct icd_index icd_index;
@@ -296,6 +296,12 @@ int icd_debug_set_center(int32_t enabled);
  * call shape, services/milvus_service.py:280-285) through the general streaming path - memset, stream_topk, reduce_lists,
  * finalize: four operations - instead of the single-launch kernel that folds all of it. Results are identical either way. */
 int icd_debug_set_stream_one(int32_t enabled);
+
+/* Test / A-B switch, process-wide, read by every search (default 3, 2: epochs of 8 tiles, classes within 16 tiles): the coarse sweep over an fp16 image that does not stay
+ * in the Infinity Cache (a row shard) paces the work-groups that sweep the same corpus tiles: epochs of 2^shift tiles, a
+ * class stays within `lead` epochs, so that a tile is fetched once per XCD (csrc/coarse_flat_kernel.hpp, VAR 67108864).
+ * shift < 0 turns pacing off. A performance decision only: results are identical either way. No reference counterpart. */
+int icd_debug_set_pacing(int32_t shift, int32_t lead);
 
 /* Test entry: the unpack step of a query-sharded icd_group_search (one kernel: the all-gathered PADDED slices -> the
  * contiguous [nq][k] outputs) on a caller-made receive buffer, so that its index arithmetic can be checked for any world

@@ -44,11 +44,18 @@ struct CoarseFlatArgs {
     int nwg_virtual;         // logical work-groups of a full batch (PERSIST launches size their own count from *nq_ptr)
     int skip_below;          // PERSIST: nothing to do when at most this many slots are active (the streaming kernel is cheaper there)
     unsigned long long *dbg;  // diagnostic builds only (VAR & 1024): [block][wave][8] cycle sums
+    // (VAR & 67108864) pacing of the work-groups that sweep the same corpus tiles (see the VAR list); pace == nullptr: off
+    unsigned int *pace;      // [pace_period][pace_epochs] arrivals per (class, epoch), zeroed before the launch
+    int pace_period;         // work-groups l and l + pace_period start on the same corpus tile (flat_class_period: BEFORE the placement split)
+    int pace_epochs;         // epochs per class (row stride of `pace`)
+    int pace_shift;          // an epoch = 2^pace_shift tiles
+    int pace_lead;           // a work-group starts epoch e only when every member of its class has finished epoch e - pace_lead
 };
 
 constexpr int CO_BOOT_MIN_TILES = 6;   // lists at least this long bootstrap their threshold ...
 constexpr int CO_KP_WIDE = 24;         // candidates per list of the instantiation for larger k (see icd_search.hip)
 constexpr int CO_BOOT_TILES = 8;       // ... over their first tiles
+constexpr int PACE_SPIN_LIMIT = 20000;   // polls (s_sleep 16 + one sc1 load each, ~1 us) before a work-group gives pacing up: ~20 ms
 constexpr int CO_SPARSE_FROM = 40;     // (VAR & 16777216) tiles of a list before its 8-register groups are pre-filtered by their maximum
 
 // End of a list, all 32 queries of the wave at once (lane = half a query; the one-query-at-a-time compaction of
@@ -288,6 +295,15 @@ __device__ __forceinline__ void compact_all_parallel(char *smem, Sel2 &st, uint3
 //        maximum (three v_max3 + one v_max) and tests THAT against the threshold: one compare and one scalar branch per 8
 //        registers while nothing passes, the two quads' own tests only behind it. A warm list passes most groups untouched
 //        (a 1.25 M-row shard's lists are 4 900 tiles long and append a handful of rows per hundred tiles)
+//   67108864  PACING of a class (the work-groups that start on the same corpus tile and sweep the same tiles in the same order:
+//        l, l + T, l + 2 T, ...). On a 1.25 M-row shard a sweep is 4 900 tiles long and the members drift apart by more tiles
+//        than an XCD's L2 holds (20 tiles of 196 KB): every work-group then fetches the image for itself - 20 to 70 GB of
+//        fabric traffic per launch against 1.96 GB algorithmic, different from run to run (profiles/r04_pmc_traffic_rowshard.json).
+//        Every 2^pace_shift tiles a work-group reports the epoch it has finished (one no-return agent-scope atomic add per
+//        class and epoch) and may start the next one only when ALL members have finished the epoch pace_lead back: the class
+//        stays within pace_lead epochs. The counter is polled with the early threshold load (same place, same counted
+//        wait: no extra latency when the class is in step); a work-group that is ahead spins with s_sleep, BOUNDED - after
+//        PACE_SPIN_LIMIT polls it gives pacing up for the rest of the launch (speed only: results never depend on it)
 //   33554432  diagnostic: every wave stamps s_memtime / s_memrealtime once at its start and once at its end and leaves the two
 //        differences in CoarseFlatArgs::dbg: the in-kernel clock the chip holds under this kernel (MI355X_MICROARCH.md,
 //        DVFS give-back item 6); nothing inside the loops changes
@@ -304,6 +320,8 @@ constexpr int CF_PRODUCT_VAR = 1 + 2 + 8 + 128 + 16 + 2048 + 32768;   // measure
 // list's tiles are bootstrap tiles) -3 %; on a 1.25 M-row shard streamed from HBM the later issue of half the pieces costs
 // +6 % (less run-ahead for a longer latency), so shards keep CF_PRODUCT_VAR (icd_search.hip picks by the image's size).
 constexpr int CF_CACHED_VAR = CF_PRODUCT_VAR + 2097152 + 4194304;
+// images streamed from HBM (row shards): the classes are paced (VAR list, 67108864)
+constexpr int CF_PACED_VAR = CF_PRODUCT_VAR + 67108864;
 __host__ __device__ constexpr int cf_ring_stages(int var) { return (var & 1048576) ? 6 : CO_S; }
 __host__ __device__ constexpr int cf_lds_bytes(int var) { return cf_ring_stages(var) * CO_STAGE_BYTES + CO_BM * CO_CAP * 8 + ((var & 1048576) ? 0 : 4 * 256); }
 #define ICD_CF_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); \
@@ -340,6 +358,8 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     // (only the 16x16x32 branch of mfma4 honours the half-calls the wide spread splits a k-step into)
     static_assert(!DMA_WIDE || (X16 && DMA_SPREAD && PF2 && !NODMA), "the wide spread is built on the product's 16x16x32 stage");
     constexpr bool CLOCKS = (VAR & 33554432) != 0;
+    constexpr bool PACE = (VAR & 67108864) != 0;
+    static_assert(!PACE || (EARLY_THR && EXCH == 1 && !PERSIST), "the pace poll rides on the early threshold load of every tile");
     static_assert(!(CLOCKS && STAMPS), "one use of the debug buffer at a time");
     constexpr int S = cf_ring_stages(VAR);            // ring slots
     constexpr int VM_MID = NOVM ? 63 : (PAIRBAR ? 4 : 4 * (S - 3));   // LDS-DMA pieces that may stay in flight at the mid-stage wait
@@ -420,6 +440,21 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
     const int u_end = min(total_units, u_begin + a.units_per_wg);
     if (u_begin >= u_end) continue;
     int u = u_begin;
+    // pacing state (wave-uniform): class, members that take part in an epoch, whether this work-group still paces
+    [[maybe_unused]] bool pacing = false;
+    [[maybe_unused]] int pace_cls = 0, pace_members = 0, pace_last_epochs = 0;
+    [[maybe_unused]] bool pace_last_mine = false;
+    if constexpr (PACE) {
+        if (a.pace && a.pace_period > 0) {
+            pacing = true;
+            pace_cls = wg % a.pace_period;
+            pace_members = (nwg_logical - pace_cls + a.pace_period - 1) / a.pace_period;
+            // the last work-group holds fewer units: it takes part in fewer epochs
+            const int last_units = total_units - (nwg_logical - 1) * a.units_per_wg;
+            pace_last_mine = ((nwg_logical - 1) % a.pace_period) == pace_cls;
+            pace_last_epochs = last_units >> a.pace_shift;
+        }
+    }
     while (u < u_end) {
         // ---- the list [t0, t1) of query tile mtile, and its ordinal ---------------------------------------
         const int mtile = u / a.ctiles;
@@ -595,6 +630,17 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
 
         for (int tile = 0; tile < ntiles; ++tile) {
             uint32_t seen_early = 0u;
+            [[maybe_unused]] uint32_t pace_seen = 0u;
+            [[maybe_unused]] bool pace_due = false;
+            [[maybe_unused]] int pace_need = -1, pace_done_epoch = 0;
+            if constexpr (PACE) {
+                if (pacing) {
+                    const int done_after = (u - u_begin) + tile + 1;   // units this work-group will have finished at the end of this tile
+                    pace_due = (done_after & ((1 << a.pace_shift) - 1)) == 0;
+                    pace_done_epoch = (done_after >> a.pace_shift) - 1;   // the epoch that ends with this tile
+                    pace_need = pace_done_epoch + 1 - a.pace_lead;        // ... and the one the next epoch waits for
+                }
+            }
             f32x16 acc[X16 ? 1 : 4];
             f32x4 xs[X16 ? 16 : 1];   // X16: accumulator of row group rg and query group gr at xs[2 rg + gr]
             if constexpr (!X16) {
@@ -693,6 +739,14 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                     if (EXCH == 1 || (tile & (EXCH - 1)) == EXCH - 1) {
                         asm volatile("global_load_dword %0, %1, off sc1" : "=v"(seen_early) : "v"(my_shared) : "memory");
                     }
+                    if constexpr (PACE) {
+                        // the epoch whose completion this work-group needs before it starts its next epoch: polled HERE, next to the
+                        // threshold load (the same counted wait at the tile end covers both)
+                        if (pacing && pace_due && pace_need >= 0 && wave == 0) {
+                            const unsigned int *pp = a.pace + (size_t)pace_cls * a.pace_epochs + pace_need;
+                            asm volatile("global_load_dword %0, %1, off sc1" : "=v"(pace_seen) : "v"(pp) : "memory");
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (!NODMA && !PAIRBAR) {   // every wave is past stage g-1: its slot takes stage g+S-1
@@ -777,6 +831,22 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
                     seen = seen_early;
                 } else {
                     seen = __hip_atomic_load(my_shared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if constexpr (PACE) {
+                    if (pacing && pace_due && wave == 0) {   // (the wait above has covered the pace poll too)
+                        if (pace_done_epoch < a.pace_epochs && lane == 0)
+                            __hip_atomic_fetch_add(a.pace + (size_t)pace_cls * a.pace_epochs + pace_done_epoch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (pace_need >= 0 && pace_need < a.pace_epochs) {
+                            const uint32_t want = (uint32_t)(pace_members - ((pace_last_mine && pace_need >= pace_last_epochs) ? 1 : 0));
+                            uint32_t got = (uint32_t)__builtin_amdgcn_readfirstlane((int)pace_seen);
+                            int spins = 0;
+                            while (got < want) {   // this work-group is ahead of its class: wait for the slowest member, BOUNDED
+                                if (++spins > PACE_SPIN_LIMIT) { pacing = false; break; }
+                                __builtin_amdgcn_s_sleep(16);
+                                got = __hip_atomic_load(a.pace + (size_t)pace_cls * a.pace_epochs + pace_need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
+                    }
                 }
                 const uint32_t mine_key = order_f32(st.thr);
                 if (seen > mine_key) st.thr = unorder_f32(seen);

@@ -40,6 +40,7 @@ thread_local std::string g_err = "";
 bool g_permute = true;   // test switch (icd_debug_set_permute): row order of the fp16 corpus copy
 bool g_probe = true;     // test switch (icd_debug_set_create_probe): the corpus-shape probe of icd_index_create
 bool g_center = true;         // test switch (icd_debug_set_center): the fp16 corpus image is centred when the rows share a large common component
+int g_pace_shift = 3, g_pace_lead = 2;   // test switch (icd_debug_set_pacing): epochs of 2^shift tiles, classes kept within `lead` epochs; shift < 0: no pacing
 bool g_stream_one = true;     // test switch (icd_debug_set_stream_one): one or two queries per call take the single-launch streaming kernel
 bool g_family_order = true;   // test switch (icd_debug_set_family_order): the wide-window finalize visits the queries in family order
 
@@ -109,6 +110,7 @@ namespace {
     } while (0)
 
 constexpr float EPS_REL = 1.2e-3f;
+constexpr size_t PACE_WORDS = (size_t)1 << 18;   // arrival counters of a paced coarse sweep: classes x epochs (1 MB)
 constexpr size_t COARSE_CACHED_IMAGE_BYTES = (size_t)96 << 20;   // fp16 images up to this size take CF_CACHED_VAR (both corpus copies then fit the 256 MiB Infinity Cache)
 constexpr int FAST_MAX_K = 100;      // the rescoring window holds up to 256 candidates (four per lane): k + the rows inside 2 eps of the k-th
 constexpr int COARSE_MAX_P = 32;     // P * KP <= FIN_MAX_CAND
@@ -232,6 +234,7 @@ struct icd_index {
     int last_chunks = 0, last_mode = 0;
     int last_p2 = 0, last_p2_word = 0;   // lists per query of the last search's second pass (0: none) and the counter that fed it
     unsigned long long *dbg = nullptr;  // diagnostic cycle counters [8192][4][4]
+    unsigned int *pace = nullptr;       // [PACE_WORDS] arrival counters of the paced coarse sweep (coarse_flat_kernel.hpp, 67108864)
 };
 
 namespace {
@@ -248,6 +251,7 @@ void free_all(icd_index *x) {
     hipFree(x->o_scores); hipFree(x->o_ids); hipFree(x->o_adj); hipFree(x->o_adj_raw);
     hipFree(x->o_adj_ids); hipFree(x->o_adj_lv);
     hipFree(x->dbg);
+    hipFree(x->pace);
     if (x->h_nflag) hipHostFree(x->h_nflag);
     if (x->h_pin) hipHostFree(x->h_pin);
     if (x->ev_nflag) hipEventDestroy(x->ev_nflag);
@@ -922,7 +926,18 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
 #endif
         else if (wide_lists) rc = launch_coarse_flat<768, CF_PRODUCT_VAR, CO_KP_WIDE>(x, a, nwg, s);
         else if ((size_t)x->n_pad * x->dim * 2 <= COARSE_CACHED_IMAGE_BYTES) rc = launch_coarse_flat<768, CF_CACHED_VAR>(x, a, nwg, s);   // (the image stays in the Infinity Cache)
-        else rc = launch_coarse_flat<768>(x, a, nwg, s);
+        else {
+            // an image streamed from HBM (a row shard): the classes of work-groups that sweep the same tiles are paced so that a
+            // tile is fetched once per XCD instead of once per work-group (coarse_flat_kernel.hpp, VAR 67108864)
+            const int t0 = flat_class_period(U, ctiles);
+            const int members0 = t0 > 0 ? nwg / t0 : 0;
+            const int epochs = g_pace_shift >= 0 ? (U >> g_pace_shift) + 1 : 0;
+            if (g_pace_shift >= 0 && members0 >= 4 && (size_t)t0 * epochs <= PACE_WORDS) {
+                a.pace = x->pace; a.pace_period = t0; a.pace_epochs = epochs; a.pace_shift = g_pace_shift; a.pace_lead = std::max(1, g_pace_lead);
+                HIP_TRY(hipMemsetAsync(x->pace, 0, (size_t)t0 * epochs * sizeof(unsigned int), s));
+            }
+            rc = launch_coarse_flat<768, CF_PACED_VAR>(x, a, nwg, s);
+        }
         if (rc) return rc;
     }
     rec(x, 2, s);
@@ -1187,6 +1202,7 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     CR_TRY(hipEventCreateWithFlags(&x->ev_nflag, hipEventDisableTiming));
     CR_TRY(hipHostMalloc(reinterpret_cast<void **>(&x->h_pin), PIN_Q_BYTES + PIN_OUT_BYTES, hipHostMallocMapped));
     CR_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&x->h_pin_dev), x->h_pin, 0));
+    CR_TRY(wsalloc(&x->pace, PACE_WORDS));
     CR_TRY(wsalloc(&x->dbg, (size_t)8192 * 16));
     CR_TRY(hipMemset(x->dbg, 0, (size_t)8192 * 16 * 8));
     CR_TRY(wsalloc(&x->flagged, (size_t)3 * x->max_nq_pad));
@@ -1490,6 +1506,12 @@ int icd_debug_unpack_query_slices(int32_t device, const void *gathered, int32_t 
     if (icd_internal_unpack_query_slices(rb, rb + per * world * 8, rb + per * world * 16, rb + per * world * 20, world, nq, k,
                                          (long long)width, out_adj, out_raw, out_ids, out_levels, stream))
         return fail(ICD_ERR_HIP, "the unpack launch failed");
+    return ICD_OK;
+}
+
+int icd_debug_set_pacing(int32_t shift, int32_t lead) {
+    g_pace_shift = shift > 12 ? 12 : shift;
+    g_pace_lead = lead < 1 ? 1 : lead;
     return ICD_OK;
 }
 

@@ -123,9 +123,10 @@ def test_bench_gpus_1_is_a_single_process_line_with_the_extras():
     assert "configs[1]" in line["config"]["workload"]
     ex = line["extra"]
     assert ex["windows"]["min"] <= ex["windows"]["median"] <= ex["windows"]["max"]
-    for key, rows in (("real_size", 40474), ("clustered", 900), ("exact_mode", 900), ("k20", 900), ("family", 120)):
+    for key, rows in (("real_size", 40474), ("clustered", 900), ("exact_mode", 900), ("k20", 900), ("family", 120), ("k100", 900), ("dim1024", 900)):
         assert ex[key]["corpus_rows"] == rows and ex[key]["ids_exact"] and ex[key]["ms_per_step"] > 0 and "fallback_queries" in ex[key]
         assert "last_second_pass" in ex[key]
+    assert ex["k100"]["top_k"] == 100 and "single_query" not in ex   # (the single-query latencies are the library's: GPU runs only)
     assert ex["k20"]["top_k"] == 20 and ex["family"]["first_batch"]["ms"] > 0 and "config3" not in line
 
 
