@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define ICD_ABI_VERSION 5   /* 5: icd_debug_unpack_query_slices, icd_debug_set_stream_one, icd_debug_set_pacing (round 5). 4: icd_debug_set_family_order, icd_debug_set_center, icd_stats.centered / mean_share appended, icd_group_prepare / icd_group_connect (round 4). 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
+#define ICD_ABI_VERSION 5   /* 5: icd_debug_unpack_query_slices, icd_debug_set_stream_one, icd_debug_set_pacing, icd_debug_set_exact_narrow (round 5). 4: icd_debug_set_family_order, icd_debug_set_center, icd_stats.centered / mean_share appended, icd_group_prepare / icd_group_connect (round 4). 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
 #define ICD_MAX_K 128
 
 typedef struct icd_index icd_index;
@@ -302,6 +302,12 @@ int icd_debug_set_stream_one(int32_t enabled);
  * class stays within `lead` epochs, so that a tile is fetched once per XCD (csrc/coarse_flat_kernel.hpp, VAR 67108864).
  * shift < 0 turns pacing off. A performance decision only: results are identical either way. No reference counterpart. */
 int icd_debug_set_pacing(int32_t shift, int32_t lead);
+
+/* Test / A-B switch, process-wide, read by every search (default 1): 0 makes ICD_MODE_EXACT at k > 32 keep lists of KP >= k
+ * (64- / 128-entry candidate buffers, one work-group per CU) instead of certified lists of 32 over row-strided chunks with a
+ * re-search of the queries the certificate cannot clear. Results are identical either way (the k range is the reference's:
+ * /query searches top_k * 2 with top_k <= 50, models/icd_models.py:138, services/multi_diagnosis_service.py:153). */
+int icd_debug_set_exact_narrow(int32_t enabled);
 
 /* Test entry: the unpack step of a query-sharded icd_group_search (one kernel: the all-gathered PADDED slices -> the
  * contiguous [nq][k] outputs) on a caller-made receive buffer, so that its index arithmetic can be checked for any world

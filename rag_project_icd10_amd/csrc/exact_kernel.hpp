@@ -34,6 +34,10 @@ struct ExactArgs {
                            // instead of -inf: a chunk keeps only rows that can be in the top-k (ties with thr0 pass), and the
                            // compaction storms of a list's first tiles - every row passes an empty list's threshold, 32 queries
                            // are compacted every other 32-row group: more than the tiles' MFMA time - do not happen.
+    int strided;           // 1: chunk c holds the rows c, c + P, c + 2 P, ... instead of a contiguous range (P = this->P, not
+                           // adaptive). Neighbouring rows - an ICD family sits in code order, tools/build_database.py:156-171 - then
+                           // spread evenly over a query's lists, which is what lets lists NARROWER than k be certified
+                           // (finalize.hpp, narrow_check). Lists carry global row ids either way.
     float *part_scores;    // [slot][P][KP]
     int *part_rows;        // [slot][P][KP]
 };
@@ -92,8 +96,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void exact_topk_kernel(ExactArgs a) {
     const int mtile = blockIdx.x / P, chunk = blockIdx.x % P;
     const int slot0 = mtile * BMQ;
     if (slot0 >= nq) return;
-    const int row_begin = chunk * rows_per_chunk;
-    const int row_end = min(a.n, row_begin + rows_per_chunk);
+    // (strided: the tile loop, the select and the keys run over LOCAL row numbers 0 .. nloc - 1 of the chunk; local order is global order)
+    const bool strided = a.strided != 0;
+    const int row_begin = strided ? 0 : chunk * rows_per_chunk;
+    const int row_end = strided ? (chunk < a.n ? (a.n - chunk + P - 1) / P : 0) : min(a.n, row_begin + rows_per_chunk);
     if (row_begin >= row_end) {   // (more chunks than row tiles: this work-group's lists stay empty)
         for (int b = 0; b < BMQ; ++b) {
             const int slot = slot0 + b;
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void exact_topk_kernel(ExactArgs a) {
         const float *csrc[CL];
 #pragma unroll
         for (int i = 0; i < CL; ++i) {
-            const int row = min(tile_row0 + crow_off[i], a.n - 1);
+            const int row = strided ? chunk + min(tile_row0 + crow_off[i], row_end - 1) * P : min(tile_row0 + crow_off[i], a.n - 1);
             csrc[i] = a.corpus + (size_t)row * dim + ccol[i];
         }
         float4 qreg[Q4], creg[CL];
@@ -224,29 +230,31 @@ __global__ __launch_bounds__(NW * 64, OCC) void exact_topk_kernel(ExactArgs a) {
 
         // fused select
         const bool partial = tile_row0 + BN > row_end;
-        if (KP == 16 && tile_row0 == row_begin && !partial) {
+        if (KP <= 32 && tile_row0 == row_begin && !partial) {
             // Threshold bootstrap of a chunk's first tile. Starting at -inf every row of the first tiles is appended and
             // each 16-register group ends in a compaction of all 32 queries (~1 ms per chunk: more than a 9-tile
-            // chunk's MFMAs). Exact lists need a threshold that at least KP rows reach: every lane keeps the 8 best
-            // of its 64 scores (branch-free insertion, 16 VALU per score, once per chunk) and the smaller of the two
-            // lanes' 8th best is reached by 16 distinct rows of this tile. Ties with it pass (thr_row = max).
-            float m[8];
+            // chunk's MFMAs). Exact lists need a threshold that at least KP rows reach: every lane keeps the KP / 2 best
+            // of its 64 scores (branch-free insertion, 2 VALU per kept score and score, once per chunk) and the smaller of the
+            // two lanes' (KP / 2)-th best is reached by KP distinct rows of this tile. Ties with it pass (thr_row = max).
+            // (KP = 32, round 5: the narrow lists of k > 32 run 22-tile chunks: -inf starts cost them a fifth of their time)
+            constexpr int BD = KP / 2;
+            float m[BD];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+            for (int j = 0; j < BD; ++j) m[j] = -INFINITY;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[t][r];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
+                    for (int j = 0; j < BD; ++j) {
                         const float lo = fminf(m[j], v);
                         m[j] = fmaxf(m[j], v);
                         v = lo;
                     }
                 }
-            const float other = __shfl_xor(m[7], 32);
-            const float t0 = fminf(m[7], other);
+            const float other = __shfl_xor(m[BD - 1], 32);
+            const float t0 = fminf(m[BD - 1], other);
             if (my_valid && t0 > st.thr) { st.thr = t0; st.thr_row = 0xFFFFFFFFu; }
         }
 #pragma unroll
@@ -286,6 +294,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void exact_topk_kernel(ExactArgs a) {
                 const u64 k = qb[j];
                 s = key_score(k);
                 row = (int)key_row(k);
+                if (strided) row = chunk + row * P;
             }
             a.part_scores[o + j] = s;
             a.part_rows[o + j] = row;

@@ -44,6 +44,11 @@ struct FinArgs {
     int lists_by_query; // with qlist: the lists (and bounds) of slot s belong to query qlist[s] and sit at that query's index
     int skip_below;     // with qlist + nq_ptr: at most this many slots -> this stage is skipped; the slot list is handed on
                         // unchanged to the stage behind it (flagged / nflag), which is cheaper for a handful of queries
+    int narrow_check;   // exact path (no rescoring): the lists are NARROWER than k may need (KP < the members of the top-k one list could
+                        // hold). A list that is full may have dropped rows; if its worst kept key beats the k-th best of the merge
+                        // (or the merge found fewer than k), a dropped row may belong to the top-k: the query is appended to
+                        // flagged / nflag and re-searched with lists of KP >= k. Otherwise everything any list dropped ranks below
+                        // the k-th best and the merge IS the exact top-k.
     int skip_walk;      // ablation builds only: skip the rescoring walk (timing; results are wrong)
     int wide_window;    // fast path: rescoring window as wide as the instantiation allows (second chance of a query whose
                         // first window overflowed with near-ties), not the one sized for k
@@ -593,6 +598,18 @@ __global__ __launch_bounds__(256, EWM == 1 ? ICD_FIN_OCC : 1) void finalize_kern
             if (xkey[e] != 0ull && xr[e] < k) sorted[xr[e]] = xkey[e];
         }
         nres = min(nx, k);
+    }
+    if constexpr (!RESCORE) {
+        if (a.narrow_check) {   // (kernel-uniform)
+            const u64 kth = nres >= k ? sorted[k - 1] : 0ull;
+            bool may_have_dropped = false;
+            for (int p = lane; p < P; p += 64) {
+                const size_t o = pbase + (size_t)p * a.KP + (a.KP - 1);
+                const int r = a.part_rows[o];
+                if (r >= 0) may_have_dropped = may_have_dropped || make_key(a.part_scores[o], (uint32_t)r) > kth;
+            }
+            if (__ballot(may_have_dropped) != 0ull && lane == 0) a.flagged[atomicAdd(a.nflag, 1)] = qidx;
+        }
     }
     // 6-7. outputs (raw order + level reweight / stable re-sort)
     emit_outputs(a, qidx, sorted, nres, adjbuf, lane);

@@ -41,6 +41,7 @@ bool g_permute = true;   // test switch (icd_debug_set_permute): row order of th
 bool g_probe = true;     // test switch (icd_debug_set_create_probe): the corpus-shape probe of icd_index_create
 bool g_center = true;         // test switch (icd_debug_set_center): the fp16 corpus image is centred when the rows share a large common component
 int g_pace_shift = 3, g_pace_lead = 2;   // test switch (icd_debug_set_pacing): epochs of 2^shift tiles, classes kept within `lead` epochs; shift < 0: no pacing
+bool g_exact_narrow = true;   // test switch (icd_debug_set_exact_narrow): EXACT mode at k > 32 runs certified lists of 32 over row-strided chunks
 bool g_stream_one = true;     // test switch (icd_debug_set_stream_one): one or two queries per call take the single-launch streaming kernel
 bool g_family_order = true;   // test switch (icd_debug_set_family_order): the wide-window finalize visits the queries in family order
 
@@ -678,6 +679,49 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         HIP_TRY(hipMemsetAsync(x->nflag, 0, sizeof(int), s));
         rec(x, 3, s);
         return run_exact(nullptr, nullptr, p_sparse, false, true);
+    }
+    if (!use_fast && kpx > 32 && g_exact_narrow && nq > ST_MAX_ACTIVE && row_tiles >= 64) {
+        // ---- k > 32: NARROW certified lists -----------------------------------------------------------------------------------
+        // Lists of KP >= k need 64- or 128-entry candidate buffers: one work-group of four waves per CU at k <= 64, of two above
+        // (0.39 / 0.15 of the fp32 MFMA peak at k = 50 / 100, against 0.59 at k = 20). Instead: the k <= 32 configuration (lists
+        // of 32, two work-groups per CU) over ROW-STRIDED chunks - chunk c holds rows c, c + P, ... so that neighbouring rows
+        // (an ICD family in code order) spread evenly - with P large enough that a list holds ~k / P << 32 members of the top-k,
+        // and finalize CHECKS it: a full list whose worst kept key beats the k-th best of the merge may have dropped a member
+        // of the top-k; such a query is re-searched with KP >= k lists (the flagged-list machinery of the AUTO fallback).
+        // Results are the exact top-k either way.
+        HIP_TRY(hipMemsetAsync(x->nflag, 0, sizeof(int), s));
+        const int slots = x->num_cu * 2;
+        const int p_need = std::max(2, (k + 7) / 8);          // ~8 members of the top-k per list when they spread evenly
+        int pn = p_need;
+        {   // the count at or above p_need whose last round of work-groups is fullest
+            double best = 0;
+            for (int c = p_need; c <= std::min(FIN_MAX_CAND_X / 32, std::max(p_need + 8, slots / std::max(1, mtx))); ++c) {   // (a short batch: enough chunks to fill the chip)
+                const long items = (long)mtx * c;
+                const double util = (double)items / (double)(((items + slots - 1) / slots) * slots);
+                if (util > best + 1e-9) { best = util; pn = c; }
+            }
+        }
+        if ((size_t)nq * pn * 32 <= x->partx_cap && pn * 32 <= FIN_MAX_CAND_X) {
+            x->last_chunks = pn;
+            x->fallback_word = 0;
+            rec(x, 3, s);
+            ExactArgs a{};
+            a.corpus = x->corpus; a.queries = dq; a.nq = nq; a.n = (int)x->n; a.dim = x->dim; a.P = pn; a.strided = 1;
+            a.rows_per_chunk = 128;   // (unused by the strided form)
+            a.part_scores = x->partx_s; a.part_rows = x->partx_r;
+            int rc = launch_exact<32, 1, 4, 62, 16, 2, 16>(x, a, mtx, s);
+            if (rc) return rc;
+            rec(x, 4, s);
+            FinArgs g = f;
+            g.part_scores = x->partx_s; g.part_rows = x->partx_r; g.P = pn; g.KP = 32; g.nq = nq; g.lds_cand = pn * 32;
+            g.narrow_check = 1; g.nflag = x->nflag; g.flagged = x->flagged;
+            rc = launch_finalize<false>(x, g, s);
+            if (rc) return rc;
+            rec(x, 5, s);
+            // the queries the check could not clear (none on data whose rows spread): KP >= k lists over the flagged list
+            int px = std::min(p_sparse, row_tiles);
+            return run_exact(x->flagged, x->nflag, px, true, stream_ok, true, false, nullptr);
+        }
     }
     if (!use_fast) {
         HIP_TRY(hipMemsetAsync(x->nflag, 0, sizeof(int), s));
@@ -1512,6 +1556,11 @@ int icd_debug_unpack_query_slices(int32_t device, const void *gathered, int32_t 
 int icd_debug_set_pacing(int32_t shift, int32_t lead) {
     g_pace_shift = shift > 12 ? 12 : shift;
     g_pace_lead = lead < 1 ? 1 : lead;
+    return ICD_OK;
+}
+
+int icd_debug_set_exact_narrow(int32_t enabled) {
+    g_exact_narrow = enabled != 0;
     return ICD_OK;
 }
 

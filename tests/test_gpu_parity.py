@@ -1158,3 +1158,59 @@ def test_one_and_two_queries_take_the_single_launch_kernel_and_match_the_oracle(
     finally:
         lib.icd_debug_set_stream_one(1)
         idx.close()
+
+
+@pytest.mark.parametrize("k", [33, 50, 64, 100])
+def test_exact_mode_above_k32_runs_certified_narrow_lists_and_stays_exact(oracle, k):
+    """ICD_MODE_EXACT at k > 32 (the k range /query can ask for: top_k * 2 with top_k <= 50, models/icd_models.py:138,
+    services/multi_diagnosis_service.py:153): lists of 32 over row-strided chunks + the certificate of finalize.hpp
+    (narrow_check), re-search of what it cannot clear. Bit-equal to the oracle and to the KP >= k lists
+    (icd_debug_set_exact_narrow(0)) on Gaussian rows, on families of near-identical NEIGHBOURING rows, on hundreds of exact
+    duplicates of one row, and on a corpus built so that ONE list holds more than 32 members of a query's top-k (the
+    certificate must flag it: last_fallback > 0)."""
+    import torch
+    lib = _native.load_library()
+    n, dim, nq = 9000, 768, 200
+    rng = np.random.default_rng(100 + k)
+    gauss = unit_rows(n, dim, 300 + k)
+    fam = np.repeat(rng.standard_normal((n // 120, dim)).astype(np.float32), 120, axis=0)
+    fam = fam + 0.1 * rng.standard_normal(fam.shape).astype(np.float32)
+    fam /= np.linalg.norm(fam, axis=1, keepdims=True)
+    dup = gauss.copy()
+    dup[rng.choice(n, 700, replace=False)] = gauss[17]
+    queries = unit_rows(nq, dim, 400 + k)
+    queries[:40] = fam[np.arange(40) * 120 + 5] + 0.05 * rng.standard_normal((40, dim)).astype(np.float32)
+    queries[40] = gauss[17]
+    queries /= np.linalg.norm(queries, axis=1, keepdims=True)
+    try:
+        pn = None
+        for name, corpus in (("gauss", gauss), ("families", np.ascontiguousarray(fam[:n // 120 * 120])), ("duplicates", dup)):
+            levels = icd_levels(len(corpus), 9)
+            idx = IcdIndex(corpus, levels, max_nq=nq, max_k=100)
+            os_, oi = oracle.flat_ip_topk(corpus, queries, k)
+            want = oracle.reweight(os_, oi, levels)
+            for narrow in (1, 0):
+                lib.icd_debug_set_exact_narrow(narrow)
+                s, i = idx.search(queries, k, MODE_EXACT)
+                got = idx.search_reweighted(queries, k, MODE_EXACT)
+                assert np.array_equal(i, oi) and _bits(s) == _bits(os_), (name, narrow)
+                assert np.array_equal(got[2], want[2]) and _bits(got[0]) == _bits(want[0]) and np.array_equal(got[3], want[3]), (name, narrow)
+                if narrow:
+                    st = idx.stats()
+                    pn = st["last_chunks"]
+                    assert st["last_mode"] == MODE_EXACT and st["last_fallback"] == 0, (name, st)   # rows that spread: nothing to re-search
+            idx.close()
+        # the adversarial corpus: 45 copies of query 7 at rows 3, 3 + P, 3 + 2 P, ... = ONE strided chunk holds 45 members of its top-k
+        lib.icd_debug_set_exact_narrow(1)
+        adv = gauss.copy()
+        adv[3 + pn * np.arange(45)] = queries[7]
+        levels = icd_levels(n, 9)
+        idx = IcdIndex(adv, levels, max_nq=nq, max_k=100)
+        os_, oi = oracle.flat_ip_topk(adv, queries, k)
+        s, i = idx.search(queries, k, MODE_EXACT)
+        st = idx.stats()
+        assert st["last_chunks"] == pn and st["last_fallback"] >= 1, st          # the certificate saw the full list
+        assert np.array_equal(i, oi) and _bits(s) == _bits(os_)
+        idx.close()
+    finally:
+        lib.icd_debug_set_exact_narrow(1)
