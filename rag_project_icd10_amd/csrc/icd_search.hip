@@ -1162,17 +1162,19 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
         // pass 0: the column mean; the image is centred when the rows share a large common component (coarse_common.hpp)
         if (n >= 64) {
             const int nb = (int)std::min<int64_t>(256, n);
-            float *part = nullptr, *sqp = nullptr, *out2 = nullptr;
-            CR_TRY(dmalloc(&part, (size_t)nb * dim));
-            CR_TRY(dmalloc(&sqp, (size_t)nb));
-            CR_TRY(dmalloc(&out2, 2));
+            // the three temporaries of this pass come out of ONE allocation that a scope guard frees on every way out: a failure
+            // between the allocations and the end of the pass (the next dmalloc, a launch, the copy) used to leak them, on the
+            // 1.25 M-row shards exactly when memory is tightest (CR_TRY only frees the index)
+            float *tmp3 = nullptr;
+            struct Guard { float *&p; ~Guard() { if (p) hipFree(p); p = nullptr; } } tmp3_guard{tmp3};
+            CR_TRY(dmalloc(&tmp3, (size_t)nb * dim + (size_t)nb + 2));
+            float *part = tmp3, *sqp = tmp3 + (size_t)nb * dim, *out2 = sqp + nb;
             CR_TRY(dmalloc(&x->cmean, (size_t)dim));
             hipLaunchKernelGGL(column_sum_partial_kernel, dim3(nb), dim3(256), 0, 0, x->corpus, (int)n, dim, part, sqp);
             hipLaunchKernelGGL(column_sum_final_kernel, dim3(1), dim3(256), 0, 0, part, sqp, nb, (int)n, dim, x->cmean, out2);
             CR_TRY(hipGetLastError());
             float h2[2] = {0.f, 0.f};
             CR_TRY(hipMemcpy(h2, out2, sizeof h2, hipMemcpyDeviceToHost));
-            hipFree(part); hipFree(sqp); hipFree(out2);
             x->mean_share = h2[1] > 0.f ? h2[0] / h2[1] : 0.f;
             if (!g_center || !(x->mean_share >= CENTER_MIN_SHARE) || !std::isfinite(h2[0]) || !std::isfinite(h2[1])) { hipFree(x->cmean); x->cmean = nullptr; }
         }

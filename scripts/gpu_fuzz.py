@@ -53,6 +53,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--focus", choices=["", "exact_k", "one_query"], default="",
+                    help="exact_k: mostly ICD_MODE_EXACT at k = 33 ... 100 on batches the narrow certified lists take (round 5); "
+                         "one_query: mostly one or two queries per call at k <= 16 (the single-launch streaming kernel)")
     args = ap.parse_args()
     import oracle as orc
     from rag_project_icd10_amd import _native
@@ -72,6 +75,11 @@ def main():
             dim, n, nq = int(rng.choice([768, 768, 1024])), int(rng.choice([4097, 20000, 37000])), int(rng.choice([129, 1000, 3000, 6000]))
         mode = MODE_AUTO if rng.random() < 0.8 else MODE_EXACT
         id_base = int(rng.choice([0, 0, 5_000_000_000]))
+        if args.focus == "exact_k" and rng.random() < 0.85:
+            k, mode = int(rng.integers(33, 101)), MODE_EXACT
+            n, nq = int(rng.choice([8192, 8200, 20000, 37000, 100003])), int(rng.choice([65, 129, 1000, 3000]))
+        if args.focus == "one_query" and rng.random() < 0.85:
+            k, nq = int(rng.integers(1, 17)), int(rng.choice([1, 1, 2]))
         if n * dim > 100003 * 768 or (n >= 100000 and nq > 1000):
             nq = min(nq, 1000)
         corpus = rows(rng, n, dim, "gauss" if kind in ("overflow", "zeros", "scaled", "tiny") else kind)
