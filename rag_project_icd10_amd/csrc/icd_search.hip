@@ -14,11 +14,15 @@
 
 #include "../../include/icd_search.h"
 #include "coarse_flat_kernel.hpp"
-#if defined(ICD_ABLATE) && !defined(ICD_FV_LIST)
+// The dropped coarse-kernel forms of rounds 1-4 (row groups, eight waves, 16-query groups, K-split wave pairs) live on the git
+// branch archive/experiments-r01-r04 (directory experiments/); an A/B build that wants them checks that directory out and
+// adds EXTRA=-DICD_WITH_EXPERIMENTS. The tree itself carries only the shipped kernels and the variants of the shipped stage.
+#if defined(ICD_ABLATE) && !defined(ICD_FV_LIST) && defined(ICD_WITH_EXPERIMENTS)
 #define ICD_ABLATE_EXPERIMENTS 1
 #endif
-#ifdef ICD_ABLATE
-#include "../../experiments/r04_ksplit_kernel/coarse_ksplit_kernel.hpp"   // (A/B builds only: wave pairs split K, 64 queries per wave)
+#if defined(ICD_ABLATE) && defined(ICD_WITH_EXPERIMENTS)
+#define ICD_ABLATE_KSPLIT 1
+#include "../../experiments/r04_ksplit_kernel/coarse_ksplit_kernel.hpp"   // (wave pairs split K, 64 queries per wave)
 #endif
 #ifdef ICD_ABLATE_EXPERIMENTS
 #include "../../experiments/r02_rg_kernel/coarse_rg_kernel.hpp"   // (A/B builds only: the row-group experiment)
@@ -317,7 +321,7 @@ int launch_coarse_flat(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream
     return ICD_OK;
 }
 
-#ifdef ICD_ABLATE
+#ifdef ICD_ABLATE_KSPLIT
 template <int D, int KP = CO_KP, int TV = 0>
 int launch_coarse_ksplit(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream_t s) {
     auto kern = coarse_ksplit_kernel<D, KP, TV>;
@@ -944,7 +948,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             else return fail(ICD_ERR_INVALID, "ICD_RG_VAR=%d is not built", v);
         }
 #endif
-#ifdef ICD_ABLATE
+#ifdef ICD_ABLATE_KSPLIT
         else if (getenv("ICD_KS_VAR") && !wide_lists) {   // A/B builds: the K-split pair kernel (experiments/r04_ksplit_kernel)
             const int v = atoi(getenv("ICD_KS_VAR"));
             if (v == 0) rc = launch_coarse_ksplit<768, CO_KP, 0>(x, a, nwg, s);
@@ -953,6 +957,8 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             else if (v == 5) rc = launch_coarse_ksplit<768, CO_KP, 5>(x, a, nwg, s);
             else return fail(ICD_ERR_INVALID, "ICD_KS_VAR=%d is not built", v);
         }
+#endif
+#ifdef ICD_ABLATE
         else if (const char *fv = getenv("ICD_FLAT_VAR")) {   // A/B builds: stage / select variants of the flat kernel
             const int v = atoi(fv);
             if (false) {}
