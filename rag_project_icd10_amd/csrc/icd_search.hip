@@ -671,11 +671,16 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         x->last_mode = ICD_MODE_EXACT;
         x->last_chunks = p_sparse;
         StreamOnePlan pl;
-        bool one = nq <= 2 && kpx == 16 && g_stream_one && plan_stream_one((int)x->n, x->dim, x->num_cu, (int)nq, 64 * 2, &pl) &&
+        // (up to FOUR queries: at eight the sweep is bound by the lanes' fmaf chains, not by memory - 40 of a wave's 64 lanes hold
+        //  rows in this form - and the general path is 12 us faster: profiles/r05_single_query.log)
+        const int qb1 = nq <= 1 ? 1 : (nq <= 2 ? 2 : 4);
+        bool one = nq <= 4 && kpx == 16 && g_stream_one && plan_stream_one((int)x->n, x->dim, x->num_cu, qb1, 64 * 2, &pl) &&
                    (size_t)nq * pl.nwg * kpx * 2 <= x->lists_cap;
-        if (one) {   // one or two queries (the reference's call shape): ONE launch, no memset, no reduction, no finalize
+        if (one) {   // up to four queries (the reference's call shape is ONE; a /query request batches its D diagnoses): ONE launch,
+                     // no memset, no reduction, no finalize
             rec(x, 3, s);
-            const int rc1 = nq == 1 ? launch_stream_one<16, 2, 1>(x, dq, 1, f, s) : launch_stream_one<16, 2, 2>(x, dq, 2, f, s);
+            const int rc1 = qb1 == 1 ? launch_stream_one<16, 2, 1>(x, dq, 1, f, s) : qb1 == 2 ? launch_stream_one<16, 2, 2>(x, dq, 2, f, s)
+                          : launch_stream_one<16, 2, 4>(x, dq, (int)nq, f, s);
             rec(x, 4, s);
             rec(x, 5, s);
             return rc1;

@@ -19,7 +19,7 @@
 // Output: one best-first list per (query slot, wave) -> reduce_lists_kernel -> finalize_kernel<false>.
 //
 // ONE = true: the reference's own call shape (ONE query per MilvusService.search call, services/milvus_service.py:280-285;
-// also two) as ONE launch. Three differences from the form above:
+// also up to four: the searches of one /query request's diagnoses) as ONE launch. Three differences from the form above:
 //   * the rows are spread over EVERY CU: a wave takes rows_per_step <= 64 rows per step (a multiple of 8: a stage is
 //     rows_per_step / 8 LDS-DMA pieces), so that 40 474 rows are 256 work-groups x 4 waves x 40 rows instead of 159 x 4 x 64;
 //     the ring gets the stages the smaller slices leave room for (up to 8);
@@ -69,7 +69,7 @@ __host__ __device__ constexpr size_t stream_lds_bytes(int dim, int ring_stages) 
 }
 // ONE = true: stages of rows_per_step x 128 B; the tail (merge of <= 256 lists per query: 64 KP keys per wave, + 4 KP merged
 // keys, + sorted / adjusted buffers of emit_outputs) reuses the same memory once the ring has drained
-__host__ __device__ constexpr size_t stream_one_tail_bytes(int kp) { return (size_t)4 * kp * kp * 8 + 16 + 128 * 8 + 128 * 8; }
+__host__ __device__ constexpr size_t stream_one_tail_bytes(int kp) { return (size_t)4 * ((size_t)4 * kp * kp * 8 + 128 * 8 + 128 * 8); }   // (the per-wave form of 3-8 queries; the four-wave form of 1-2 needs a quarter)
 template <int KP, int E, int QB>
 __host__ __device__ constexpr size_t stream_one_lds_bytes(int dim, int ring_stages, int rows_per_step) {
     const size_t body = (size_t)QB * dim * 4 + (size_t)4 * ring_stages * rows_per_step * 128 + (size_t)4 * QB * 64 * E * 8;
@@ -133,7 +133,7 @@ __device__ __forceinline__ void wait_vmcnt_uniform(int n) {
 template <int KP, int E, int QB, bool ONE = false>
 __global__ __launch_bounds__(256) void stream_topk_kernel(StreamArgs a) {
     constexpr int CAP = 64 * E;
-    static_assert(!ONE || (QB <= 2 && KP <= 32), "the single-launch form serves one or two queries at k <= 32");
+    static_assert(!ONE || (QB <= 4 && KP <= 16), "the single-launch form serves up to four queries at k <= 16");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // (the gate looks at the device's count itself: a.nq is already clamped to max_active by the host, and a list longer
     //  than that belongs to the MFMA kernel alone - round 3: the clamped count used to pass the gate and cost 24 sweeps)
@@ -280,15 +280,14 @@ __global__ __launch_bounds__(256) void stream_topk_kernel(StreamArgs a) {
                 }
             }
             __syncthreads();   // every wave is past its loop (and drained its own LDS-DMA): the ring's memory is free
-            int *nbw = reinterpret_cast<int *>(smem + ring_base + 4096);   // [4][QB] (the ring is >= 8 KB: 4 waves x >= 2 stages x >= 1 KB)
-            int *flag = nbw + 16;
+            int *nbw = reinterpret_cast<int *>(smem + ring_base + 6144);   // [4][QB] (the ring is >= 8 KB: 4 waves x >= 2 stages x >= 1 KB; keysA below it: QB x 512 B)
+            int *flag = nbw + 32;
             if (lane == 0) {
 #pragma unroll
                 for (int qi = 0; qi < QB; ++qi) nbw[wave * QB + qi] = nb_mine[qi];
             }
             __syncthreads();
-            if (wave < nqp) {   // wave qi merges query qi's four lists into the work-group's one
-                const int qi = wave;
+            for (int qi = wave; qi < nqp; qi += 4) {   // wave qi (mod 4) merges query qi's four lists into the work-group's one
                 u64 *keysA = reinterpret_cast<u64 *>(smem + ring_base) + (size_t)qi * (64 * NE4);
                 u64 key[NE4];
                 int rank[NE4];
@@ -322,6 +321,55 @@ __global__ __launch_bounds__(256) void stream_topk_kernel(StreamArgs a) {
             __syncthreads();
             if (*flag == 0) return;   // (work-group-uniform; ONE = true runs a single pass: nq <= QB)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: keeps the compiler from moving the sc1 loads up)
+            if constexpr (QB > 2) {
+                // ---- the last arriver, 3-4 queries: every wave takes a whole query (wave w: query w), four rounds of 64
+                // lists each; the survivors of the rounds are ranked by the same wave. No barrier between the waves.
+                const int nl = (int)gridDim.x;
+                char *wbase = smem + (size_t)wave * (4 * KP * KP * 8 + 128 * 8 + 128 * 8);
+                u64 *surv = reinterpret_cast<u64 *>(wbase);                       // [4 rounds][KP * KP]
+                u64 *sorted = surv + 4 * KP * KP;                                  // [128]
+                double *adjbuf = reinterpret_cast<double *>(sorted + 128);         // [128]
+                __syncthreads();   // (every thread has read the flag: the scratch below overlaps it)
+                for (int qi = wave; qi < nqp; qi += 4) {
+                    const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(a.wg_keys + (size_t)(q0 + qi) * nl * KP, 0, nl * KP * 8, 0x00020000);
+                    int tot = 0;
+                    for (int rd = 0; rd * 64 < nl; ++rd) {
+                        const int li = rd * 64 + lane;
+                        u64 key[KP];
+#pragma unroll
+                        for (int e = 0; e < KP; e += 2) {
+                            const auto v = __builtin_amdgcn_raw_buffer_load_b128(krsrc, (uint32_t)(min(li, nl - 1) * KP + e) * 8u, 0, 16);
+                            key[e] = li < nl ? (((u64)v[1] << 32) | (u64)v[0]) : 0ull;
+                            key[e + 1] = li < nl ? (((u64)v[3] << 32) | (u64)v[2]) : 0ull;
+                        }
+                        const u64 head = key[0];
+                        int above = 0;
+                        for (int l = 0; l < 64; ++l) above += (readlane_u64(head, l) > head) ? 1 : 0;
+                        const u64 hit = __ballot(head != 0ull && above == KP - 1);
+                        const u64 bound = hit ? readlane_u64(head, __ffsll((long long)hit) - 1) : 0ull;
+                        const u64 lt = (1ull << lane) - 1ull;
+#pragma unroll
+                        for (int e = 0; e < KP; ++e) {
+                            const bool keep = key[e] != 0ull && key[e] >= bound;
+                            const u64 m = __ballot(keep);
+                            if (m == 0ull) break;
+                            if (keep) surv[tot + __popcll(m & lt)] = key[e];
+                            tot += __popcll(m);
+                        }
+                    }
+                    for (int base = 0; base < tot; base += 64) {
+                        const int i = base + lane;
+                        const u64 ku = i < tot ? surv[i] : 0ull;
+                        int ru = 0;
+                        for (int j = 0; j < tot; ++j) ru += (surv[j] > ku) ? 1 : 0;
+                        if (ku != 0ull && ru < 128) sorted[ru] = ku;
+                    }
+                    const int slot = q0 + qi;
+                    const int qidx = a.qlist ? a.qlist[slot] : slot;
+                    emit_outputs(a.fin, qidx, sorted, min(min(tot, KP), a.fin.k), adjbuf, lane);
+                }
+                __syncthreads();
+            } else {
             // ---- the last arriver: <= 256 lists per query, lane = list (best first) ------------------------------------------
             // A list's head is its best key. The KP-th largest of a wave's 64 heads bounds the wave's KP-th best from below (KP
             // distinct keys reach it); only keys at or above that bound can rank: the four waves compact theirs into one LDS list
@@ -388,6 +436,7 @@ __global__ __launch_bounds__(256) void stream_topk_kernel(StreamArgs a) {
                     emit_outputs(a.fin, qidx, sorted, min(min(tot, KP), a.fin.k), adjbuf, lane);
                 }
                 __syncthreads();
+            }
             }
             if (tid == 0 && a.fin.host_counters) {   // what the memset in front and finalize<false>'s block 0 did for this path
                 a.fin.counters[0] = 0;

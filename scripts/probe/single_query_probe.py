@@ -74,6 +74,22 @@ def main():
                   f"{bytes_per_call / dev_us / 1e6:5.2f} TB/s = {bytes_per_call / dev_us / 1e6 / 8.0:.3f} of 8 TB/s) | "
                   f"host call median {lat[100]:6.1f} us, p10 {lat[20]:6.1f}, p90 {lat[180]:6.1f}")
     lib.icd_debug_set_stream_one(1)
+    # 3 ... 8 queries per call (a /query request's diagnoses in one search_batch): GPU time by the library's own events
+    for nq in (1, 2, 3, 4, 8, 16):
+        for one in (1, 0):
+            lib.icd_debug_set_stream_one(one)
+            for _ in range(20):
+                index.search_reweighted(dq[:nq], 10)
+            torch.cuda.synchronize()
+            index.set_profiling(True)
+            index.profile_summary()
+            for i in range(100):
+                index.search_reweighted(dq[i & 31:(i & 31) + nq], 10)
+            torch.cuda.synchronize()
+            prof = index.profile_summary()
+            index.set_profiling(False)
+            print(f"nq={nq:2d} k=10 single-launch kernel {'on ' if one else 'off'}: GPU {prof['ms_total'] * 1e3:6.1f} us per call (library events, {prof['count']} calls)")
+    lib.icd_debug_set_stream_one(1)
     index.close()
     # the service: the reference's search(), numpy vector in, hit dicts out
     tmp = tempfile.mkdtemp()

@@ -1125,7 +1125,8 @@ def test_query_sharded_unpack_kernel_matches_the_host_concatenation(world):
 
 @pytest.mark.parametrize("n", [7, 100, 129, 1000, 40474, 300000])
 def test_one_and_two_queries_take_the_single_launch_kernel_and_match_the_oracle(oracle, n):
-    """The reference's call shape - ONE query per MilvusService.search call (services/milvus_service.py:280-285) - and two:
+    """The reference's call shape - ONE query per MilvusService.search call (services/milvus_service.py:280-285) - and up to eight
+    (a /query request batches the searches of its D diagnoses, services/multi_diagnosis_service.py:98-103,153; up to four take this kernel):
     stream_topk_kernel<ONE> folds the list reduction and finalize into the streaming launch (last-arriver ticket). Bit-equal
     to the oracle and to the general four-operation path (icd_debug_set_stream_one(0)), over corpus sizes from one
     work-group to multi-step sweeps, k = 1 ... 16, exact ties (duplicate rows) included; repeated calls (the ticket only
@@ -1134,13 +1135,13 @@ def test_one_and_two_queries_take_the_single_launch_kernel_and_match_the_oracle(
     corpus, levels = unit_rows(n, dim, 41 + n), icd_levels(n, 42 + n)
     if n >= 100:
         corpus[5::7] = corpus[2]          # duplicate rows: exact score ties, broken by row id
-    queries = unit_rows(6, dim, 43 + n)
+    queries = unit_rows(8, dim, 43 + n)
     queries[5] = corpus[2]                # a query that IS the duplicated row
     idx = IcdIndex(corpus, levels, max_nq=64, max_k=16)
     lib = _native.load_library()
     try:
         for k in (1, 5, 10, 16):
-            for lo, hi in ((0, 1), (1, 2), (2, 4), (4, 6), (5, 6)):
+            for lo, hi in ((0, 1), (1, 2), (2, 4), (4, 6), (5, 6), (1, 4), (0, 4), (0, 5), (0, 6), (0, 8)):   # 1, 2, 3-4 and 5-8 queries per call
                 q = queries[lo:hi]
                 os_, oi = oracle.flat_ip_topk(corpus, q, k)
                 want = oracle.reweight(os_, oi, levels)
