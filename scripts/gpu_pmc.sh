@@ -1,6 +1,6 @@
 # rocprofv3 evidence for profiles/: kernel trace + stats of bench.py, then PMC counters in SEPARATE passes
 # (never combined with a trace domain other than --kernel-trace). usage: scripts/gpu_pmc.sh r03
-TAG=${1:-r04}
+TAG=${1:-r05}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
@@ -20,9 +20,10 @@ d=$R/gpurun_out/pmcx_${TAG}
 timeout 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $d -- python3 $R/bench.py --mode exact --steps 4 --warmup 2 --no-cpu-baseline --no-extras --repeats 0 > $d.log 2>&1
 # (3) the row-sharded workload (one 1.25 M-row shard): kernel stats + HBM traffic of a coarse launch
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_rowshard -- python3 $R/bench.py --workload rowshard --steps 1 --rowshard-steps 1 > $R/gpurun_out/rocprof_rowshard_$TAG.log 2>&1
-for set in "FETCH_SIZE" "WRITE_SIZE"; do
-  d=$R/gpurun_out/pmcrs_${TAG}_$set
-  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $d -- python3 $R/bench.py --workload rowshard --steps 1 --rowshard-steps 1 > $d.log 2>&1
+# (FETCH_SIZE three times over: VERDICT r4 item 3 asks that consecutive runs of the paced sweep agree within 15 %)
+for set in "FETCH_SIZE" "WRITE_SIZE" "FETCH_SIZE:2" "FETCH_SIZE:3"; do
+  d=$R/gpurun_out/pmcrs_${TAG}_$(echo $set | tr ':' '_')
+  timeout 600 rocprofv3 --pmc ${set%%:*} --kernel-trace --output-format csv -d $d -- python3 $R/bench.py --workload rowshard --steps 1 --rowshard-steps 1 > $d.log 2>&1
 done
 cd $R
 python3 - $TAG <<'PY'
@@ -51,12 +52,24 @@ json.dump(out, open(f'gpurun_out/{tag}_pmc_counters.json', 'w'), indent=1)
 json.dump(traffic_of(out), open(f'gpurun_out/{tag}_pmc_traffic.json', 'w'), indent=1)
 ex = collect(f'gpurun_out/pmcx_{tag}/**/*counter_collection.csv')
 json.dump({k: v for k, v in ex.items() if 'exact_topk' in k}, open(f'gpurun_out/{tag}_pmc_counters_exact_mode.json', 'w'), indent=1)
-rs = collect(f'gpurun_out/pmcrs_{tag}_*/**/*counter_collection.csv')
-json.dump(traffic_of(rs), open(f'gpurun_out/{tag}_pmc_traffic_rowshard.json', 'w'), indent=1)
+rs = collect(f'gpurun_out/pmcrs_{tag}_[FW]*_SIZE/**/*counter_collection.csv')   # (the first FETCH_SIZE pass and the WRITE_SIZE pass)
+rs_t = traffic_of(rs)
+# the three FETCH_SIZE runs of the row-shard workload, each on its own: per-launch averages of the coarse kernel
+runs = []
+for d in (f'gpurun_out/pmcrs_{tag}_FETCH_SIZE', f'gpurun_out/pmcrs_{tag}_FETCH_SIZE_2', f'gpurun_out/pmcrs_{tag}_FETCH_SIZE_3'):
+    c = collect(d + '/**/*counter_collection.csv')
+    for k, v in c.items():
+        if 'coarse_flat_kernel' in k and 'FETCH_SIZE' in v:
+            runs.append(2 * v['FETCH_SIZE'] * 1024)
+for k in rs_t:
+    if 'coarse_flat_kernel' in k:
+        rs_t[k]['fetch_bytes_of_three_consecutive_runs'] = runs
+json.dump(rs_t, open(f'gpurun_out/{tag}_pmc_traffic_rowshard.json', 'w'), indent=1)
+print('rowshard 2 x FETCH_SIZE per coarse launch, three consecutive runs (GB):', [round(r / 1e9, 2) for r in runs])
 for k, v in out.items():
     if 'coarse' in k or 'finalize_kernel<true' in k:
         print(k[:70], {c: round(x, 1) for c, x in v.items()})
-for k, v in traffic_of(rs).items():
+for k, v in rs_t.items():
     if 'coarse' in k:
         print('rowshard', k[:70], v)
 PY
