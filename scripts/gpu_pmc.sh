@@ -10,6 +10,8 @@ cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $R/gpurun_out/rocprof_bench_$TAG.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_extras -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/rocprof_bench_extras_$TAG.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_exact -- python3 $R/bench.py --mode exact --steps 10 --warmup 3 --no-cpu-baseline --no-extras --repeats 0 > $R/gpurun_out/rocprof_exact_$TAG.log 2>&1
+# (1b) the reference's call shape: ONE query per call, 2 000 calls of the C harness (the single-launch streaming kernel's own duration)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_one -- $R/rag_project_icd10_amd/csrc/icd_selftest --oracle $R/oracle/libicd_oracle.so --skip-cases --bench --auto-only --nq 1 --n 40474 --iters 2000 > $R/gpurun_out/rocprof_one_$TAG.log 2>&1
 # (2) PMC passes of the headline workload alone
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
   d=$R/gpurun_out/pmc_${TAG}_$(echo $set | cut -d' ' -f1)
@@ -59,7 +61,7 @@ runs = []
 for d in (f'gpurun_out/pmcrs_{tag}_FETCH_SIZE', f'gpurun_out/pmcrs_{tag}_FETCH_SIZE_2', f'gpurun_out/pmcrs_{tag}_FETCH_SIZE_3'):
     c = collect(d + '/**/*counter_collection.csv')
     for k, v in c.items():
-        if 'coarse_flat_kernel' in k and 'FETCH_SIZE' in v:
+        if 'coarse_flat_kernel' in k and 'FETCH_SIZE' in v and v['FETCH_SIZE'] > 1e5:   # (the shard-sized launches; the gated second-pass launches fetch nothing)
             runs.append(2 * v['FETCH_SIZE'] * 1024)
 for k in rs_t:
     if 'coarse_flat_kernel' in k:
@@ -74,6 +76,7 @@ for k, v in rs_t.items():
         print('rowshard', k[:70], v)
 PY
 for f in $(find gpurun_out/prof_$TAG -name "*kernel_stats.csv"); do head -10 $f; cp $f gpurun_out/${TAG}_bench_kernel_stats.csv; done
+for f in $(find gpurun_out/prof_${TAG}_one -name "*kernel_stats.csv"); do head -2 $f | cut -c1-160; cp $f gpurun_out/${TAG}_single_query_kernel_stats.csv; done
 for f in $(find gpurun_out/prof_${TAG}_extras -name "*kernel_stats.csv"); do cp $f gpurun_out/${TAG}_bench_with_extras_kernel_stats.csv; done
 for f in $(find gpurun_out/prof_${TAG}_exact -name "*kernel_stats.csv"); do head -3 $f; cp $f gpurun_out/${TAG}_bench_exact_mode_kernel_stats.csv; done
 for f in $(find gpurun_out/prof_${TAG}_rowshard -name "*kernel_stats.csv"); do head -6 $f; cp $f gpurun_out/${TAG}_rowshard_kernel_stats.csv; done

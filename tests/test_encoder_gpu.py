@@ -98,6 +98,28 @@ def test_packed_forward_matches_the_padded_hf_forward(services, monkeypatch):
     assert np.max(np.abs(cls_packed - cls_padded)) <= TOL and np.max(np.abs(cls_packed - packed)) > 1e-3
 
 
+def test_split_bf16_gemms_of_the_packed_forward_stay_within_the_fp32_tolerance(services, monkeypatch):
+    """The packed encoder's Linear layers run as split-bf16 GEMMs on the bf16 MFMA (x_hi W_hi + x_hi W_lo + x_lo W_hi, fp32
+    accumulation and output, one GEMM over the concatenated K; ICD_EMBEDDING_GEMM=bf16x3, the default): the embeddings stay
+    within the tolerance of the fp32 forward (the arithmetic the reference reaches through SentenceTransformer.encode,
+    services/embedding_service.py:97-102) - against the SAME service with fp32 GEMMs and against the CPU fp32 forward - and
+    the cosines of all pairs move by less than 1e-5 (north_star's score tolerance)"""
+    gpu, cpu = services
+    texts = _strings()
+    assert gpu._packed is not None
+    got = gpu.encode_query_batch(texts, batch_size=256)
+    if not gpu._packed.split_gemm:
+        pytest.skip("this torch has no mm(out_dtype=...): the packed forward runs fp32 GEMMs")
+    monkeypatch.setattr(gpu._packed, "split_gemm", False)
+    fp32 = gpu.encode_query_batch(texts, batch_size=256)
+    monkeypatch.undo()
+    ref = cpu.encode_query_batch(texts, batch_size=256)
+    d_gpu, d_cpu = float(np.max(np.abs(got - fp32))), float(np.max(np.abs(got - ref)))
+    d_cos = float(np.max(np.abs(got.astype(np.float64) @ got.astype(np.float64).T - ref.astype(np.float64) @ ref.astype(np.float64).T)))
+    print(f"split-bf16 GEMMs: max |d embedding| vs the fp32 GEMMs on the GPU {d_gpu:.2e}, vs the CPU fp32 forward {d_cpu:.2e}; max |d cosine| {d_cos:.2e}")
+    assert d_gpu <= TOL and d_cpu <= TOL and d_cos <= 1e-5
+
+
 def test_native_packed_attention_kernel_matches_sdpa():
     """icd_packed_attention alone (through the C ABI): softmax(Q K^T / 8) V per sequence and head over packed tokens against
     a float64 softmax attention (and torch's fp32 scaled_dot_product_attention for scale) on every sequence separately - lengths 1 .. 512
