@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define ICD_ABI_VERSION 5   /* 5: icd_debug_unpack_query_slices, icd_debug_set_stream_one, icd_debug_set_pacing, icd_debug_set_exact_narrow (round 5). 4: icd_debug_set_family_order, icd_debug_set_center, icd_stats.centered / mean_share appended, icd_group_prepare / icd_group_connect (round 4). 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
+#define ICD_ABI_VERSION 5   /* 5: icd_debug_unpack_query_slices, icd_debug_set_stream_one, icd_debug_set_pacing, icd_debug_set_exact_narrow, icd_split_bf16x3 (round 5). 4: icd_debug_set_family_order, icd_debug_set_center, icd_stats.centered / mean_share appended, icd_group_prepare / icd_group_connect (round 4). 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
 #define ICD_MAX_K 128
 
 typedef struct icd_index icd_index;
@@ -258,6 +258,14 @@ int icd_cosine_rows(int32_t device, const float *x, const float *y, int64_t y_st
  * Enqueues one launch on `stream`. */
 int icd_packed_attention(int32_t device, const float *qkv, int64_t ld, const int32_t *starts, int32_t nseq, int32_t heads,
                          int32_t head_dim, int32_t max_len, float *out, int64_t out_ld, void *stream);
+
+/* The A operand of a split-bf16 GEMM, in one pass (the Linear layers inside SentenceTransformer.encode, reference
+ * services/embedding_service.py:97-102, run as x_hi W_hi + x_hi W_lo + x_lo W_hi + b on the bf16 MFMA with fp32 accumulation
+ * and output): x fp32 [rows][cols] (row stride ld elements; device, 16-byte aligned), optionally through erf-GELU (act = 1:
+ * BertIntermediate), -> out bf16 [rows][3 cols + 64] = [hi | hi | lo | 1 1 0 ... 0], hi = bf16(x) rounded to nearest
+ * even, lo = bf16(x - hi). The weight operand is [W_hi^T; W_lo^T; W_hi^T; b_hi; b_lo; 0 x 62] (3 cols + 64 rows: K stays a
+ * multiple of the GEMM's 64-deep step). cols must be a multiple of 8 and at least 64. Enqueued on `stream`. */
+int icd_split_bf16x3(int32_t device, const float *x, int64_t rows, int32_t cols, int64_t ld, int32_t act, void *out, void *stream);
 
 /* (last_fallback: every search copies its counters to pinned host memory behind itself, on its stream; this call waits
  *  for the last search of this handle - an event on that stream - and for nothing else on the device) */

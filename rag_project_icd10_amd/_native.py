@@ -32,11 +32,12 @@ EXPORTED_SYMBOLS = (
     "icd_cosine_rows",
     "icd_index_set_second_pass",
     "icd_group_unique_id", "icd_group_create", "icd_group_prepare", "icd_group_connect", "icd_group_search", "icd_group_destroy",
-    "icd_debug_unpack_query_slices", "icd_debug_set_stream_one", "icd_debug_set_pacing", "icd_debug_set_exact_narrow",
+    "icd_debug_unpack_query_slices", "icd_debug_set_stream_one", "icd_debug_set_pacing", "icd_debug_set_exact_narrow", "icd_split_bf16x3",
 )
 GROUP_ROW_SHARD = 0
 GROUP_QUERY_SHARD = 1
 GROUP_ID_BYTES = 128
+SPLIT_TAIL = 64   # csrc/attention_kernel.hpp: elements behind [hi | hi | lo] of icd_split_bf16x3's rows
 
 
 class IcdError(RuntimeError):
@@ -102,6 +103,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.icd_debug_set_stream_one.argtypes = [i32]
     lib.icd_debug_set_pacing.argtypes = [i32, i32]
     lib.icd_debug_set_exact_narrow.argtypes = [i32]
+    lib.icd_split_bf16x3.argtypes = [i32, vp, i64, i32, i64, i32, vp, vp]
     lib.icd_debug_unpack_query_slices.argtypes = [i32, vp, i32, i64, i32, vp, vp, vp, vp, vp]
     lib.icd_packed_attention.argtypes = [i32, vp, i64, vp, i32, i32, i32, i32, vp, i64, vp]
     lib.icd_hier_rescore.argtypes = [i32, vp, vp, i64, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -524,6 +526,19 @@ def packed_attention(qkv, starts, nseq: int, heads: int, max_len: int, out):
     assert qkv.is_cuda and qkv.stride(1) == 1 and out.stride(1) == 1 and starts.is_cuda
     _check(lib, lib.icd_packed_attention(dev.index, qkv.data_ptr(), qkv.stride(0), starts.data_ptr(), int(nseq), int(heads), 64,
                                          int(max_len), out.data_ptr(), out.stride(0), _current_stream_ptr(dev.index)))
+    return out
+
+
+def split_bf16x3(x, gelu: bool = False):
+    """icd_split_bf16x3: x f32 [rows, cols] on the GPU (row-contiguous) -> bf16 [rows, 3 * cols + 64] = [hi | hi | lo | 1 1 0 ...],
+    the A operand of a split-bf16 GEMM (services/embedding_service.py _PackedBert); gelu: through erf-GELU first.
+    Enqueued on the current stream."""
+    import torch
+    lib = load_library()
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] % 8 == 0 and x.shape[1] >= 64
+    out = torch.empty((x.shape[0], 3 * x.shape[1] + SPLIT_TAIL), dtype=torch.bfloat16, device=x.device)
+    _check(lib, lib.icd_split_bf16x3(x.device.index, x.data_ptr(), int(x.shape[0]), int(x.shape[1]), int(x.stride(0)), 1 if gelu else 0,
+                                     out.data_ptr(), _current_stream_ptr(x.device.index)))
     return out
 
 

@@ -175,4 +175,62 @@ __global__ __launch_bounds__(256) void packed_attention_kernel(PackedAttnArgs a)
     }
 }
 
+// ---- split-bf16 operand of the encoder's Linear layers ---------------------------------------------------------------------
+// The packed encoder runs its four Linear layers per block as ONE bf16 GEMM each with fp32 accumulation and output
+// (services/embedding_service.py _PackedBert: y = x_hi W_hi + x_hi W_lo + x_lo W_hi + b, the fp32 arithmetic of
+// SentenceTransformer.encode - reference services/embedding_service.py:97-102 - to 1e-6). This kernel makes the A operand in
+// one pass: row r of x [rows][cols] fp32, optionally through erf-GELU (the BertIntermediate activation), becomes
+//   out[r] = [ hi(cols) | hi(cols) | lo(cols) | 1 1 0 ... 0 ]      bf16, row stride 3 cols + 64 (K stays a multiple of the
+//   vendor GEMM's 64-deep K-step: with a tail of 8 the same GEMMs took 10.2 instead of 8.2 ms per forward)
+// hi = bf16(x) (round to nearest even), lo = bf16(x - hi); the two ones meet the bias rows (b_hi, b_lo) of the weight
+// operand. 16 bytes read, 3 x 16 bytes written per thread and step (bound: HBM): the torch form of the same thing (two
+// casts, a subtraction, a concatenation, a bias add) moved 5 x the bytes in five launches.
+constexpr int SPLIT_TAIL = 64;   // elements behind [hi | hi | lo]: the two ones of the bias rows, zeros up to a whole K-step
+struct SplitArgs {
+    const float *x;
+    unsigned short *out;
+    long long rows;
+    int cols;      // multiple of 8
+    int act;       // 0: none, 1: erf-GELU
+    long long ld;  // elements per input row
+};
+
+__device__ __forceinline__ unsigned short split_bf16_bits(float v) {
+    const __bf16 b = (__bf16)v;   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN (MI355X_MICROARCH.md, correctness boundaries)
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float split_bf16_float(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(SplitArgs a) {
+    const int c8 = a.cols >> 3;                       // 8-element pieces per row
+    const long long total = a.rows * (long long)c8;
+    const long long ostride = 3ll * a.cols + SPLIT_TAIL;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / c8;
+        const int c = (int)(i - r * c8) * 8;
+        const float4 v0 = *reinterpret_cast<const float4 *>(a.x + r * a.ld + c);
+        const float4 v1 = *reinterpret_cast<const float4 *>(a.x + r * a.ld + c + 4);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        unsigned short hi[8], lo[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = v[j];
+            if (a.act == 1) t = 0.5f * t * (1.0f + erff(t * 0.70710678118654752440f));
+            hi[j] = split_bf16_bits(t);
+            lo[j] = split_bf16_bits(t - split_bf16_float(hi[j]));
+        }
+        uint4 ph, pl;
+        ph.x = hi[0] | ((unsigned)hi[1] << 16); ph.y = hi[2] | ((unsigned)hi[3] << 16); ph.z = hi[4] | ((unsigned)hi[5] << 16); ph.w = hi[6] | ((unsigned)hi[7] << 16);
+        pl.x = lo[0] | ((unsigned)lo[1] << 16); pl.y = lo[2] | ((unsigned)lo[3] << 16); pl.z = lo[4] | ((unsigned)lo[5] << 16); pl.w = lo[6] | ((unsigned)lo[7] << 16);
+        unsigned short *o = a.out + r * ostride + c;
+        *reinterpret_cast<uint4 *>(o) = ph;
+        *reinterpret_cast<uint4 *>(o + a.cols) = ph;
+        *reinterpret_cast<uint4 *>(o + 2 * a.cols) = pl;
+        if (c < SPLIT_TAIL) {   // the row's tail, 8 elements per thread: 1 1 0 0 ... (bf16 1.0 = 0x3F80)
+            uint4 one; one.x = c == 0 ? 0x3F803F80u : 0u; one.y = 0u; one.z = 0u; one.w = 0u;
+            *reinterpret_cast<uint4 *>(a.out + r * ostride + 3 * a.cols + c) = one;
+        }
+    }
+}
+
 }  // namespace icd

@@ -1494,6 +1494,22 @@ int icd_packed_attention(int32_t device, const float *qkv, int64_t ld, const int
     return ICD_OK;
 }
 
+int icd_split_bf16x3(int32_t device, const float *x, int64_t rows, int32_t cols, int64_t ld, int32_t act, void *out, void *stream) {
+    if (!x || !out) return fail(ICD_ERR_INVALID, "pointer is NULL");
+    if (rows < 0 || cols < SPLIT_TAIL || cols % 8 != 0 || ld < cols || ld % 4 != 0) return fail(ICD_ERR_INVALID, "rows=%lld cols=%d ld=%lld (cols a multiple of 8, ld >= cols and a multiple of 4)", (long long)rows, cols, (long long)ld);
+    if (act != 0 && act != 1) return fail(ICD_ERR_INVALID, "act=%d (0 none, 1 erf-GELU)", act);
+    if ((reinterpret_cast<uintptr_t>(x) & 15) != 0 || (reinterpret_cast<uintptr_t>(out) & 15) != 0) return fail(ICD_ERR_INVALID, "x and out must be 16-byte aligned");
+    if (rows == 0) return ICD_OK;
+    HIP_TRY(hipSetDevice(device));
+    SplitArgs a{};
+    a.x = x; a.out = static_cast<unsigned short *>(out); a.rows = rows; a.cols = cols; a.act = act; a.ld = ld;
+    const long long total = rows * (long long)(cols / 8);
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    HIP_TRY(hipGetLastError());
+    return ICD_OK;
+}
+
 int icd_index_lookup_levels(icd_index *idx, const int64_t *ids, int64_t count, int32_t *out_levels, void *stream) {
     if (!valid(idx)) return fail(ICD_ERR_STATE, "invalid handle");
     std::lock_guard<std::mutex> guard(idx->mu);

@@ -127,8 +127,9 @@ class _PackedBert:
             })
         # The four Linear layers of a block as SPLIT-bf16 GEMMs on the bf16 MFMA (ICD_EMBEDDING_GEMM=bf16x3, the default for fp32
         # weights on a GPU; =fp32 keeps rocBLAS fp32 GEMMs): x = x_hi + x_lo and W = W_hi + W_lo in bf16 (16 mantissa bits
-        # each way), y = x_hi W_hi + x_hi W_lo + x_lo W_hi accumulated in fp32 inside ONE GEMM over the concatenated K
-        # ([x_hi | x_hi | x_lo] @ [W_hi; W_lo; W_hi]^T, fp32 output) - the dropped x_lo W_lo term is 2^-16 relative. Measured
+        # each way), y = x_hi W_hi + x_hi W_lo + x_lo W_hi + b accumulated in fp32 inside ONE GEMM over the concatenated K
+        # ([x_hi | x_hi | x_lo | 1 1 0..] @ [W_hi; W_lo; W_hi; b_hi; b_lo; 0..], fp32 output; the A operand - GELU included - by one
+        # native pass, icd_split_bf16x3) - the dropped x_lo W_lo term is 2^-16 relative. Measured
         # against the fp32 forward of the same weights: embeddings within 5.3e-7, cosines within 2.8e-7 (the fp32 summation
         # order alone moves them 1.4e-7), at 3 / 16 of the fp32 MFMA's time per FLOP. Needs torch.mm(out_dtype=...).
         self.split_gemm = None   # decided at the first forward on a device (split_weights)
@@ -140,30 +141,50 @@ class _PackedBert:
               and self.bert.embeddings.word_embeddings.weight.dtype == torch.float32)
         if ok:
             try:
-                def split_w(w):   # [N, K] fp32 -> [3K, N] bf16: rows W_hi^T, W_lo^T, W_hi^T stacked along K
-                    hi = w.to(torch.bfloat16)
-                    lo = (w - hi.float()).to(torch.bfloat16)
-                    return torch.cat([hi.t(), lo.t(), hi.t()], 0).contiguous()
+                from .. import _native
+                _native.load_library()
+                self._split_a = _native.split_bf16x3
+
+                def split_w(w, b):   # [N, K] fp32, [N] -> [3K + 64, N] bf16: W_hi^T, W_lo^T, W_hi^T stacked along K, then b_hi, b_lo, 0 x 62
+                    def hl(t):
+                        hi = t.to(torch.bfloat16)
+                        return hi, (t - hi.float()).to(torch.bfloat16)
+                    whi, wlo = hl(w.detach())
+                    bhi, blo = hl(b.detach())
+                    pad = torch.zeros((_native.SPLIT_TAIL - 2, w.shape[0]), dtype=torch.bfloat16, device=w.device)
+                    return torch.cat([whi.t(), wlo.t(), whi.t(), bhi[None, :], blo[None, :], pad], 0).contiguous()
                 for l in self.layers:
-                    l["s_qkv"] = split_w(l["wqkv"])
-                    l["s_attn_out"] = split_w(l["attn_out"].dense.weight.detach())
-                    l["s_inter"] = split_w(l["inter"].weight.detach())
-                    l["s_out"] = split_w(l["out"].dense.weight.detach())
-                probe = torch.mm(torch.zeros((2, 6), dtype=torch.bfloat16, device=device), self.layers[0]["s_qkv"][:6], out_dtype=torch.float32)
+                    l["s_qkv"] = split_w(l["wqkv"], l["bqkv"])
+                    l["s_attn_out"] = split_w(l["attn_out"].dense.weight, l["attn_out"].dense.bias)
+                    l["s_inter"] = split_w(l["inter"].weight, l["inter"].bias)
+                    l["s_out"] = split_w(l["out"].dense.weight, l["out"].dense.bias)
+                probe = torch.mm(self._split_a(torch.zeros((2, 64), dtype=torch.float32, device=device)),
+                                 torch.zeros((3 * 64 + _native.SPLIT_TAIL, 16), dtype=torch.bfloat16, device=device), out_dtype=torch.float32)
                 ok = probe.dtype == torch.float32
-            except Exception as exc:   # (a torch without mm(out_dtype=...): the fp32 GEMMs stay)
+                self._mm_out = False
+                try:   # (the result straight into a slice of the caller's buffer, where this torch takes out= next to out_dtype=)
+                    buf = torch.empty((3, 16), dtype=torch.float32, device=device)
+                    torch.mm(self._split_a(torch.zeros((2, 64), dtype=torch.float32, device=device)),
+                             torch.zeros((3 * 64 + _native.SPLIT_TAIL, 16), dtype=torch.bfloat16, device=device), out_dtype=torch.float32, out=buf[:2])
+                    self._mm_out = True
+                except Exception:
+                    pass
+            except Exception as exc:   # (a torch without mm(out_dtype=...), or no native library: the fp32 GEMMs stay)
                 logger.info("split-bf16 GEMMs unavailable (%s): fp32 GEMMs", exc)
                 ok = False
         self.split_gemm = bool(ok)
         return self.split_gemm
 
-    @staticmethod
-    def _lin3(x, w3, bias):
-        """y = x W^T + b through ONE bf16 GEMM with fp32 accumulation and output: [x_hi | x_hi | x_lo] @ [W_hi; W_lo; W_hi]"""
-        hi = x.to(torch.bfloat16)
-        lo = (x - hi.float()).to(torch.bfloat16)
-        y = torch.mm(torch.cat([hi, hi, lo], 1), w3, out_dtype=torch.float32)
-        return y.add_(bias)
+    def _lin3(self, x, w3, gelu=False, out=None):
+        """y = act(x) W^T + b through ONE bf16 GEMM with fp32 accumulation and output: [x_hi | x_hi | x_lo | 1 1 0...] @ [W_hi; W_lo; W_hi; b_hi; b_lo; 0...]
+        (the A operand by one native pass, csrc/attention_kernel.hpp split_bf16x3_kernel)"""
+        if out is not None and self._mm_out:
+            return torch.mm(self._split_a(x, gelu), w3, out_dtype=torch.float32, out=out)
+        y = torch.mm(self._split_a(x, gelu), w3, out_dtype=torch.float32)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
 
     @classmethod
     def plan_groups(cls, lengths):
@@ -230,7 +251,7 @@ class _PackedBert:
         split = self._split_ready(device)
         for l in self.layers:
             if split:
-                qkv[:T] = self._lin3(x, l["s_qkv"], l["bqkv"])
+                self._lin3(x, l["s_qkv"], out=qkv[:T])
             else:
                 torch.addmm(l["bqkv"], x, l["wqkv"].t(), out=qkv[:T])
             for count, longest, grid, bias, _ in groups:
@@ -241,8 +262,8 @@ class _PackedBert:
             if native is not None:
                 self.native_attention(qkv, native[0], native[1], nh, native[2], ctx)
             if split:
-                x = l["attn_out"].LayerNorm(self._lin3(ctx[:T], l["s_attn_out"], l["attn_out"].dense.bias) + x)
-                x = l["out"].LayerNorm(self._lin3(F.gelu(self._lin3(x, l["s_inter"], l["inter"].bias)), l["s_out"], l["out"].dense.bias) + x)
+                x = l["attn_out"].LayerNorm(self._lin3(ctx[:T], l["s_attn_out"]).add_(x))
+                x = l["out"].LayerNorm(self._lin3(self._lin3(x, l["s_inter"]), l["s_out"], gelu=True).add_(x))
             else:
                 x = l["attn_out"].LayerNorm(l["attn_out"].dense(ctx[:T]) + x)
                 x = l["out"].LayerNorm(l["out"].dense(F.gelu(l["inter"](x))) + x)

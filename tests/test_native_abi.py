@@ -14,7 +14,7 @@ from rag_project_icd10_amd import _native
 def _declared_functions():
     src = open(os.path.join(ROOT, "include", "icd_search.h"), encoding="utf-8").read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(icd_[a-z_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(icd_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol():
