@@ -235,13 +235,19 @@ class Ctx:
             self.dev = torch.device("cuda", self.local_rank)
         self.red_dev = self.dev if self.backend == "nccl" else torch.device("cpu")
         # a CPU side channel for decisions that must not depend on the GPU queue (main(): did any rank's C-ABI trial hang?)
-        self.side = dist.new_group(backend="gloo") if self.world > 1 and self.backend == "nccl" else None
+        self.side = None
+        if self.world > 1 and self.backend == "nccl":
+            try:
+                self.side = dist.new_group(backend="gloo")
+            except Exception as exc:   # (never fatal: the decision then travels over the main group, on the device)
+                print(f"bench.py: rank {self.rank}: no gloo side group ({type(exc).__name__}: {exc}); the trial outcome is agreed over the main group", file=sys.stderr)
 
     def any_rank(self, flag):
         """True on every rank iff `flag` on any rank (all_reduce(MAX) of a CPU tensor over the gloo side group)"""
         if self.world == 1:
             return bool(flag)
-        t = self.torch.tensor([1 if flag else 0], dtype=self.torch.int32)
+        on_cpu = self.side is not None or self.backend != "nccl"
+        t = self.torch.tensor([1 if flag else 0], dtype=self.torch.int32, device="cpu" if on_cpu else self.dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.side)
         return bool(int(t.item()))
 
