@@ -14,6 +14,8 @@ cp gpurun_out/${TAG}_pmc_traffic.json gpurun_out/${TAG}_pmc_traffic_rowshard.jso
 (timeout 900 python bench.py --steps 50 --warmup 5 2>/dev/null | tail -1) > gpurun_out/bench.log
 (timeout 600 python bench.py --workload rowshard --steps 3 2>/dev/null | tail -1) > gpurun_out/bench_rowshard.log
 (timeout 600 python scripts/bench_e2e.py 2>/dev/null | tail -60) > gpurun_out/e2e.json
+(ICD_EMBEDDING_GEMM=fp32 timeout 600 python scripts/bench_e2e.py 2>/dev/null | tail -60) > gpurun_out/e2e_fp32_gemms.json
+(timeout 600 python -m pytest tests/test_encoder_gpu.py -q -m gpu -s -k split 2>&1 | grep -E "split-bf16|passed|failed") > gpurun_out/encoder_split_accuracy.log
 (timeout 600 python scripts/bench_build.py 2>/dev/null) > gpurun_out/build_full.json
 (timeout 900 python scripts/bench_encoder_corpus.py 2>/dev/null) > gpurun_out/e2e_encoder_corpus.json
 # two ranks on this box's ONE device: RCCL refuses duplicate devices; the gloo control flow with the HIP index on one device is what can run

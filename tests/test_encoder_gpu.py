@@ -216,3 +216,31 @@ def test_search_on_an_encoder_made_corpus_is_bit_exact(k, tmp_path, monkeypatch)
     print(f"encoder-made corpus k={k}: second pass {st['last_second_pass']} (x {st['last_second_pass_lists']} lists), "
           f"exact re-search {st['last_fallback']} of {len(strings)}, wide_mode {st['wide_mode']}")
     ms.disconnect()
+
+
+def test_split_bf16x3_kernel_makes_the_documented_operand():
+    """icd_split_bf16x3 alone (through the C ABI): [hi | hi | lo | 1 1 0 ... 0] with hi = bf16(x) rounded to nearest even and
+    lo = bf16(x - hi), bit for bit what torch's casts give; with act = 1 the input goes through erf-GELU first (BertIntermediate,
+    the activation inside SentenceTransformer.encode: reference services/embedding_service.py:97-102) within one bf16 ulp of
+    torch's; hi + lo reproduces x to 2^-16 relative; a strided input view works"""
+    import torch
+    from rag_project_icd10_amd import _native
+    torch.manual_seed(11)
+    for rows, cols in ((1, 64), (37, 768), (1000, 3072)):
+        big = torch.randn((rows, cols + 16), device="cuda") * torch.logspace(-3, 2, cols + 16, device="cuda")
+        x = big[:, :cols]                                      # a view with a wider row stride
+        out = _native.split_bf16x3(x)
+        assert out.shape == (rows, 3 * cols + _native.SPLIT_TAIL) and out.dtype == torch.bfloat16
+        hi = x.to(torch.bfloat16)
+        lo = (x - hi.float()).to(torch.bfloat16)
+        assert torch.equal(out[:, :cols].view(torch.int16), hi.view(torch.int16))
+        assert torch.equal(out[:, cols:2 * cols].view(torch.int16), hi.view(torch.int16))
+        assert torch.equal(out[:, 2 * cols:3 * cols].view(torch.int16), lo.view(torch.int16))
+        tail = out[:, 3 * cols:].float()
+        assert bool((tail[:, :2] == 1).all()) and bool((tail[:, 2:] == 0).all())
+        rel = ((hi.float() + lo.float() - x).abs() / x.abs().clamp(min=1e-30)).max().item()
+        assert rel <= 2.0 ** -16
+        g = _native.split_bf16x3(x, gelu=True)
+        want = torch.nn.functional.gelu(x)
+        got = g[:, :cols].float() + g[:, 2 * cols:3 * cols].float()
+        assert ((got - want).abs() <= 2.0 ** -15 * want.abs() + 1e-30).all()
