@@ -230,6 +230,7 @@ struct icd_index {
     int prof_every = 1;            // events on every prof_every-th search (a recorded event keeps the next kernel from
     long prof_tick = 0;            // overlapping the previous one's tail: sampling keeps that cost out of a timed region)
     bool prof_now = false;
+    bool capturing = false;        // the current search is being captured into a HIP graph (search_common): no event queries, no host-side adaptation
     hipEvent_t evring[EV_RING][NUM_EV + 1] = {};
     bool evring_valid[EV_RING][NUM_EV + 1] = {};
     long prof_count = 0;           // profiled searches since the last summary
@@ -534,7 +535,7 @@ __global__ void gather_rows_kernel(const float *src, float *dst, long long strid
 int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const Outs &o, hipStream_t s) {
     const int row_tiles = (int)((x->n + 127) / 128);
     const bool use_fast = (mode == ICD_MODE_AUTO) && x->fast && k <= FAST_MAX_K && (x->dim == 768 || x->dim == 1024);
-    x->prof_now = x->profiling && (x->prof_tick++ % x->prof_every == 0);
+    x->prof_now = !x->capturing && x->profiling && (x->prof_tick++ % x->prof_every == 0);
     if (x->prof_now) {
         const int slot = (int)(x->prof_count % EV_RING);
         x->ev = x->evring[slot];
@@ -771,7 +772,9 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     // start with the second pass's list count (1.5 instead of 2.2 ms per 10 000 queries there; 7 % slower on Gaussian data,
     // which is why it is not the default). Every WIDE_REPROBE-th large search runs narrow again and decides anew.
     const bool large = nq >= WIDE_MIN_NQ;
-    const bool counters_in = hipEventQuery(x->ev_nflag) == hipSuccess;   // (every search enqueued so far has completed)
+    // (while the stream is being captured into a HIP graph nothing may be queried: the plan is the one the host state gives now,
+    //  and it is frozen into the graph - a performance decision only, the replayed search returns the exact top-k either way)
+    const bool counters_in = !x->capturing && hipEventQuery(x->ev_nflag) == hipSuccess;   // (every search enqueued so far has completed)
     if (counters_in) {
         const int run = x->h_nflag[4];
         if (x->sparse_disarmed && run < x->sparse_need) x->sparse_need = std::min(x->sparse_need * 2, 1 << 16);   // an incident
@@ -1324,6 +1327,11 @@ static int search_common(icd_index *x, const float *queries, int64_t nq, int32_t
     if (!queries) return fail(ICD_ERR_INVALID, "queries is NULL");
     HIP_TRY(hipSetDevice(x->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    {   // device-in / device-out searches are graph-capturable (no allocation, no synchronisation, no query while capturing)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        x->capturing = s != nullptr && hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
+        if (x->capturing && (!q_on_device || !out_on_device)) return fail(ICD_ERR_INVALID, "a search with host buffers synchronises: it cannot be captured into a graph");
+    }
     const float *dq = queries;
     if (!q_on_device) {
         const size_t qbytes = (size_t)nq * x->dim * sizeof(float);
@@ -1359,7 +1367,7 @@ static int search_common(icd_index *x, const float *queries, int64_t nq, int32_t
     rec(x, NUM_EV, s);
     // the search's last kernel has written the fallback counters to pinned host memory: icd_index_stats reads them after
     // waiting for THIS event only (no device-wide synchronisation: other streams - an encoder - keep running)
-    HIP_TRY(hipEventRecord(x->ev_nflag, s));
+    if (!x->capturing) HIP_TRY(hipEventRecord(x->ev_nflag, s));   // (an event recorded inside a capture could not be waited for by icd_index_stats)
     if (pinned_out) {
         HIP_TRY(hipStreamSynchronize(s));   // (the kernels' stores to the mapped block are visible behind it, like the counters')
         const char *h = x->h_pin + PIN_Q_BYTES;

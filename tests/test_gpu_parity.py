@@ -1215,3 +1215,50 @@ def test_exact_mode_above_k32_runs_certified_narrow_lists_and_stays_exact(oracle
         idx.close()
     finally:
         lib.icd_debug_set_exact_narrow(1)
+
+
+def test_device_resident_searches_can_be_captured_into_a_hip_graph(oracle):
+    """Device-in / device-out searches allocate nothing and never synchronise (include/icd_search.h): a batch through the fp16
+    fast path and a one-query call are captured into ONE HIP graph and replayed; the replayed results are the oracle's, eager
+    searches and icd_index_stats still work afterwards, and a host-buffer call inside a capture is refused with a message
+    (it would synchronise). The reference has no counterpart (it calls Milvus per query: services/milvus_service.py:280-285)."""
+    import torch
+    n, dim, k = 20000, 768, 10
+    corpus, levels = unit_rows(n, dim, 71), icd_levels(n, 72)
+    queries = unit_rows(2000, dim, 73)
+    idx = IcdIndex(corpus, levels, max_nq=2000, max_k=10)
+    dq = torch.from_numpy(queries).cuda()
+    os_, oi = oracle.flat_ip_topk(corpus, queries, k)
+    want = oracle.reweight(os_, oi, levels)
+    for _ in range(2):                                   # warm-up outside the capture (kernel attributes, workspaces)
+        idx.search_reweighted(dq, k)
+        idx.search_reweighted(dq[:1], k)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        big = idx.search_reweighted(dq, k)
+        one = idx.search_reweighted(dq[7:8], k)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(big[2].cpu().numpy(), want[2]) and _bits(big[0].cpu().numpy()) == _bits(want[0])
+    assert np.array_equal(one[2].cpu().numpy(), want[2][7:8]) and _bits(one[0].cpu().numpy()) == _bits(want[0][7:8])
+    # new inputs in the captured buffers, replayed: the graph reads the tensors it captured
+    dq.copy_(torch.from_numpy(queries[::-1].copy()).cuda())
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(big[2].cpu().numpy(), want[2][::-1])
+    # eager use of the same index afterwards, stats included
+    st = _check(oracle, idx, corpus, levels, queries[:300], k, MODE_AUTO)
+    assert st["last_mode"] == MODE_AUTO
+    # a host-buffer call synchronises: inside a capture it is refused, and the capture survives without it
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        with pytest.raises(_native.IcdError) as e:
+            idx._lib and _native._check(idx._lib, idx._lib.icd_index_search(idx._h, queries.ctypes.data, 1, k, 0, MODE_AUTO, os_.ctypes.data, oi.ctypes.data, 0,
+                                                                   _native._current_stream_ptr(0)))
+        assert "captured" in str(e.value)
+        idx.search_reweighted(dq[:1], k)
+    g2.replay()
+    torch.cuda.synchronize()
+    idx.close()
