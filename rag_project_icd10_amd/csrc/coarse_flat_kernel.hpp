@@ -827,7 +827,9 @@ __global__ __launch_bounds__(256, 1) void coarse_flat_kernel(CoarseFlatArgs a) {
             if (EXCH == 1 || (tile & (EXCH - 1)) == EXCH - 1) {
                 uint32_t seen;
                 if constexpr (EARLY_THR) {
-                    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(seen_early) : "i"(VM_TILE_END) : "memory");
+                    // (every destination of the asm loads this wait covers is named "+v": cdna_hip_programming.md 5.7 item 1, form (ii))
+                    if constexpr (PACE) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(seen_early), "+v"(pace_seen) : "i"(VM_TILE_END) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(seen_early) : "i"(VM_TILE_END) : "memory");
                     seen = seen_early;
                 } else {
                     seen = __hip_atomic_load(my_shared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

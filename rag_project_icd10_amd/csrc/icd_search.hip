@@ -481,7 +481,9 @@ int launch_stream_one(icd_index *x, const float *dq, int nq, const FinArgs &f, h
     a.fin = f;
     a.fin.counters = x->nflag; a.fin.host_counters = x->h_nflag_dev;
     auto kern = stream_topk_kernel<KP, E, QB, true>;
-    const size_t lds = stream_one_lds_bytes<KP, E, QB>(x->dim, pl.stages, pl.rps);
+    // (at least 84 KB: ONE work-group per CU whatever the corpus size - the fence-free sc1 hand-off of the kernel's tail is the
+    //  form measured for one work-group per CU, MI355X_MICROARCH.md visibility table)
+    const size_t lds = std::max<size_t>(stream_one_lds_bytes<KP, E, QB>(x->dim, pl.stages, pl.rps), (size_t)84 * 1024);
     static int configured[MAX_DEVICES] = {};
     HIP_TRY(ensure_dynamic_lds(kern, x->device, (size_t)LDS_LIMIT, configured));
     hipLaunchKernelGGL(kern, dim3(pl.nwg), dim3(256), lds, s, a);
