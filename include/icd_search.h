@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define ICD_ABI_VERSION 5   /* 5: icd_debug_unpack_query_slices, icd_debug_set_stream_one, icd_debug_set_pacing, icd_debug_set_exact_narrow, icd_split_bf16x3 (round 5). 4: icd_debug_set_family_order, icd_debug_set_center, icd_stats.centered / mean_share appended, icd_group_prepare / icd_group_connect (round 4). 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
+#define ICD_ABI_VERSION 5   /* 5: icd_debug_unpack_query_slices, icd_debug_set_stream_one, icd_debug_set_pacing, icd_debug_set_exact_narrow, icd_debug_set_host_one, icd_split_bf16x3 (round 5). 4: icd_debug_set_family_order, icd_debug_set_center, icd_stats.centered / mean_share appended, icd_group_prepare / icd_group_connect (round 4). 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
 #define ICD_MAX_K 128
 
 typedef struct icd_index icd_index;
@@ -304,6 +304,14 @@ int icd_debug_set_center(int32_t enabled);
  * call shape, services/milvus_service.py:280-285) through the general streaming path - memset, stream_topk, reduce_lists,
  * finalize: four operations - instead of the single-launch kernel that folds all of it. Results are identical either way. */
 int icd_debug_set_stream_one(int32_t enabled);
+
+/* Test / A-B switch, process-wide, read by every search (default 3 = both bits): how a HOST caller's ONE query - the reference's
+ * own call shape, MilvusClient.search(data=[query_vector.tolist()]), services/milvus_service.py:280-285 - reaches and leaves the
+ * single-launch kernel. Bit 1: the vector travels in the kernel's arguments (no host-to-device copy command in front of the
+ * launch). Bit 2: the call returns when the kernel's last work-group has stored the call's sequence number behind the outputs
+ * in the index's mapped host block (polled for a bounded time, then the stream synchronisation as before) instead of waiting for
+ * the stream's completion signal. 0 = the copy + hipStreamSynchronize form. Results are identical either way. */
+int icd_debug_set_host_one(int32_t bits);
 
 /* Test / A-B switch, process-wide, read by every search (default 3, 2: epochs of 8 tiles, classes within 16 tiles): the coarse sweep over an fp16 image that does not stay
  * in the Infinity Cache (a row shard) paces the work-groups that sweep the same corpus tiles: epochs of 2^shift tiles, a

@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = (
     "icd_cosine_rows",
     "icd_index_set_second_pass",
     "icd_group_unique_id", "icd_group_create", "icd_group_prepare", "icd_group_connect", "icd_group_search", "icd_group_destroy",
-    "icd_debug_unpack_query_slices", "icd_debug_set_stream_one", "icd_debug_set_pacing", "icd_debug_set_exact_narrow", "icd_split_bf16x3",
+    "icd_debug_unpack_query_slices", "icd_debug_set_stream_one", "icd_debug_set_host_one", "icd_debug_set_pacing", "icd_debug_set_exact_narrow", "icd_split_bf16x3",
 )
 GROUP_ROW_SHARD = 0
 GROUP_QUERY_SHARD = 1
@@ -101,6 +101,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.icd_debug_set_family_order.argtypes = [i32]
     lib.icd_debug_set_center.argtypes = [i32]
     lib.icd_debug_set_stream_one.argtypes = [i32]
+    lib.icd_debug_set_host_one.argtypes = [i32]
     lib.icd_debug_set_pacing.argtypes = [i32, i32]
     lib.icd_debug_set_exact_narrow.argtypes = [i32]
     lib.icd_split_bf16x3.argtypes = [i32, vp, i64, i32, i64, i32, vp, vp]

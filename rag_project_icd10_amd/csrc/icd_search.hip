@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -46,6 +47,7 @@ bool g_probe = true;     // test switch (icd_debug_set_create_probe): the corpus
 bool g_center = true;         // test switch (icd_debug_set_center): the fp16 corpus image is centred when the rows share a large common component
 int g_pace_shift = 3, g_pace_lead = 2;   // test switch (icd_debug_set_pacing): epochs of 2^shift tiles, classes kept within `lead` epochs; shift < 0: no pacing
 bool g_exact_narrow = true;   // test switch (icd_debug_set_exact_narrow): EXACT mode at k > 32 runs certified lists of 32 over row-strided chunks
+int g_host_one = 3;           // test switch (icd_debug_set_host_one): a host caller's ONE query 1 = travels in the kernel arguments, 2 = completion by a polled word
 bool g_stream_one = true;     // test switch (icd_debug_set_stream_one): one or two queries per call take the single-launch streaming kernel
 bool g_family_order = true;   // test switch (icd_debug_set_family_order): the wide-window finalize visits the queries in family order
 
@@ -196,6 +198,13 @@ struct icd_index {
     // the results straight into its second part (zero-copy stores over PCIe) and the host copies them out after the stream
     // synchronisation: no D2H memcpy call at all (six of them to pageable memory cost ~60 us of a 113-us call)
     char *h_pin = nullptr, *h_pin_dev = nullptr;
+    // ... and for ONE query per call (services/milvus_service.py:280-285) two commands less: the vector travels IN the kernel
+    // arguments of the single-launch kernel (no H2D copy in front of it: host_q is set for the duration of that call), and the
+    // kernel's last work-group stores a sequence number behind its outputs (the block's last 64 bytes) that the host polls
+    // instead of waiting for the stream's completion signal (done_seq counts the calls that asked for it)
+    const float *host_q = nullptr;
+    unsigned long long done_seq = 0;
+    bool done_armed = false;       // the current call's launch carries the word's address
     size_t bytes_ws = 0;
     // knobs / counters
     int chunks_override = 0;
@@ -394,6 +403,7 @@ int launch_coarse_w8(icd_index *x, const CoarseFlatArgs &a, int nwg, hipStream_t
 // p_out = 0: choose the smallest number of output lists (direct tiny-batch path); returns it in *p_used.
 constexpr int LDS_LIMIT = 160 * 1024;   // LDS per CU (MI355X_MICROARCH.md)
 constexpr size_t PIN_Q_BYTES = 64 * 1024;     // queries of a small host call (16 x 1024 floats)
+constexpr size_t PIN_DONE_BYTES = 64;          // the completion word of a ONE-query host call (its own cache line)
 constexpr size_t PIN_OUT_BYTES = 96 * 1024;   // their results: nq * k * 36 bytes over the six output arrays (nq * k <= 2730)
 
 // does a pass of qb queries fit LDS with the minimum ring of two stages per wave?
@@ -468,7 +478,7 @@ inline bool plan_stream_one(int n, int dim, int num_cu, int qb, int cap_entries,
 }
 
 template <int KP, int E, int QB>
-int launch_stream_one(icd_index *x, const float *dq, int nq, const FinArgs &f, hipStream_t s) {
+int launch_stream_one(icd_index *x, const float *dq, int nq, const FinArgs &f, hipStream_t s, const float *host_q = nullptr, bool poll_done = false) {
     StreamOnePlan pl;
     if (!plan_stream_one((int)x->n, x->dim, x->num_cu, QB, 64 * E, &pl)) return fail(ICD_ERR_INVALID, "single-launch stream kernel: no plan for n=%lld dim=%d", (long long)x->n, x->dim);
     if ((size_t)nq * pl.nwg * KP * 2 > x->lists_cap) return fail(ICD_ERR_INVALID, "stream workspace too small");
@@ -480,11 +490,29 @@ int launch_stream_one(icd_index *x, const float *dq, int nq, const FinArgs &f, h
     a.ticket = reinterpret_cast<u64 *>(x->nflag + 6);                   // nflag[6..7]: 8-byte aligned, zeroed at create, only ever counts up
     a.fin = f;
     a.fin.counters = x->nflag; a.fin.host_counters = x->h_nflag_dev;
+    if (poll_done) {
+        a.done = reinterpret_cast<u64 *>(x->h_pin_dev + PIN_Q_BYTES + PIN_OUT_BYTES);
+        a.done_value = ++x->done_seq;
+        x->done_armed = true;
+    }
     auto kern = stream_topk_kernel<KP, E, QB, true>;
     // (at least 84 KB: ONE work-group per CU whatever the corpus size - the fence-free sc1 hand-off of the kernel's tail is the
     //  form measured for one work-group per CU, MI355X_MICROARCH.md visibility table)
     const size_t lds = std::max<size_t>(stream_one_lds_bytes<KP, E, QB>(x->dim, pl.stages, pl.rps), (size_t)84 * 1024);
     static int configured[MAX_DEVICES] = {};
+    if constexpr (QB == 1) {
+        if (host_q) {   // the vector in the kernel arguments: no copy command in front of the launch
+            auto kern_in = stream_one_inline_kernel<KP, E>;
+            static int configured_in[MAX_DEVICES] = {};
+            HIP_TRY(ensure_dynamic_lds(kern_in, x->device, (size_t)LDS_LIMIT, configured_in));
+            StreamInlineQuery iq;
+            memcpy(iq.v, host_q, (size_t)x->dim * sizeof(float));
+            a.queries = nullptr;
+            hipLaunchKernelGGL(kern_in, dim3(pl.nwg), dim3(256), lds, s, a, iq);
+            HIP_TRY(hipGetLastError());
+            return ICD_OK;
+        }
+    }
     HIP_TRY(ensure_dynamic_lds(kern, x->device, (size_t)LDS_LIMIT, configured));
     hipLaunchKernelGGL(kern, dim3(pl.nwg), dim3(256), lds, s, a);
     HIP_TRY(hipGetLastError());
@@ -664,6 +692,16 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         return rc;
     };
 
+    // a host caller's ONE query whose copy search_common left out (host_q): every path but the single-launch kernel wants it
+    // in device memory after all - the copy it would have got, enqueued before anything that reads dq
+    auto stage_host_query = [&]() -> int {
+        if (!x->host_q) return ICD_OK;
+        const size_t qbytes = (size_t)x->dim * sizeof(float);
+        memcpy(x->h_pin, x->host_q, qbytes);
+        HIP_TRY(hipMemcpyAsync(x->qdev, x->h_pin, qbytes, hipMemcpyHostToDevice, s));
+        x->host_q = nullptr;
+        return ICD_OK;
+    };
     // small batches (the reference's one-query-per-call shape): stream the corpus once, exact, no coarse pass
     const bool stream_ok = x->dim % (32 * ST_PF) == 0 && stream_fits(kpx, 1, x->dim);
     // (k > 16 needs the 64-entry lists of the streaming kernel, ~0.9 ms per 16 queries: the coarse pass is faster there)
@@ -682,16 +720,21 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         if (one) {   // up to four queries (the reference's call shape is ONE; a /query request batches its D diagnoses): ONE launch,
                      // no memset, no reduction, no finalize
             rec(x, 3, s);
-            const int rc1 = qb1 == 1 ? launch_stream_one<16, 2, 1>(x, dq, 1, f, s) : qb1 == 2 ? launch_stream_one<16, 2, 2>(x, dq, 2, f, s)
+            const float *hq = qb1 == 1 ? x->host_q : nullptr;   // (a host caller's ONE query: search_common left the copy out)
+            if (!hq) { const int rcq = stage_host_query(); if (rcq) return rcq; }
+            const bool poll = x->host_q != nullptr && (g_host_one & 2) != 0;
+            const int rc1 = qb1 == 1 ? launch_stream_one<16, 2, 1>(x, dq, 1, f, s, hq, poll) : qb1 == 2 ? launch_stream_one<16, 2, 2>(x, dq, 2, f, s)
                           : launch_stream_one<16, 2, 4>(x, dq, (int)nq, f, s);
             rec(x, 4, s);
             rec(x, 5, s);
             return rc1;
         }
+        { const int rcq = stage_host_query(); if (rcq) return rcq; }
         HIP_TRY(hipMemsetAsync(x->nflag, 0, sizeof(int), s));
         rec(x, 3, s);
         return run_exact(nullptr, nullptr, p_sparse, false, true);
     }
+    { const int rcq = stage_host_query(); if (rcq) return rcq; }
     if (!use_fast && kpx > 32 && g_exact_narrow && nq > ST_MAX_ACTIVE && row_tiles >= 64) {
         // ---- k > 32: NARROW certified lists -----------------------------------------------------------------------------------
         // Lists of KP >= k need 64- or 128-entry candidate buffers: one work-group of four waves per CU at k <= 64, of two above
@@ -1262,8 +1305,9 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     memset(x->h_nflag, 0, 8 * sizeof(int));
     CR_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&x->h_nflag_dev), x->h_nflag, 0));
     CR_TRY(hipEventCreateWithFlags(&x->ev_nflag, hipEventDisableTiming));
-    CR_TRY(hipHostMalloc(reinterpret_cast<void **>(&x->h_pin), PIN_Q_BYTES + PIN_OUT_BYTES, hipHostMallocMapped));
+    CR_TRY(hipHostMalloc(reinterpret_cast<void **>(&x->h_pin), PIN_Q_BYTES + PIN_OUT_BYTES + PIN_DONE_BYTES, hipHostMallocMapped));
     CR_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&x->h_pin_dev), x->h_pin, 0));
+    memset(x->h_pin + PIN_Q_BYTES + PIN_OUT_BYTES, 0, PIN_DONE_BYTES);   // (the completion word: sequence numbers start at 1)
     CR_TRY(wsalloc(&x->pace, PACE_WORDS));
     CR_TRY(wsalloc(&x->dbg, (size_t)8192 * 16));
     CR_TRY(hipMemset(x->dbg, 0, (size_t)8192 * 16 * 8));
@@ -1318,6 +1362,18 @@ int icd_index_destroy(icd_index *idx) {
     return ICD_OK;
 }
 
+constexpr long DONE_POLL_US = 500;   // how long a ONE-query host call polls its completion word before it waits for the stream instead
+// results of a small host call: out of the mapped block (the six arrays back to back, 8-byte ones first)
+static void copy_pinned_out(icd_index *x, const Outs &user, size_t no_small) {
+    const char *h = x->h_pin + PIN_Q_BYTES;
+    if (user.adj) memcpy(user.adj, h, no_small * 8);              h += no_small * 8;
+    if (user.ids) memcpy(user.ids, h, no_small * 8);              h += no_small * 8;
+    if (user.adj_ids) memcpy(user.adj_ids, h, no_small * 8);      h += no_small * 8;
+    if (user.scores) memcpy(user.scores, h, no_small * 4);        h += no_small * 4;
+    if (user.adj_raw) memcpy(user.adj_raw, h, no_small * 4);      h += no_small * 4;
+    if (user.adj_lv) memcpy(user.adj_lv, h, no_small * 4);
+}
+
 static int search_common(icd_index *x, const float *queries, int64_t nq, int32_t k, int32_t q_on_device,
                          int32_t mode, Outs user, int32_t out_on_device, void *stream) {
     if (!valid(x)) return fail(ICD_ERR_STATE, "invalid handle");
@@ -1337,7 +1393,9 @@ static int search_common(icd_index *x, const float *queries, int64_t nq, int32_t
     const float *dq = queries;
     if (!q_on_device) {
         const size_t qbytes = (size_t)nq * x->dim * sizeof(float);
-        if (qbytes <= PIN_Q_BYTES) {
+        if (nq == 1 && (g_host_one & 1) && qbytes <= sizeof(StreamInlineQuery) && !x->capturing) {
+            x->host_q = queries;   // ONE query: search_device puts it into the single-launch kernel's arguments (or copies it after all)
+        } else if (qbytes <= PIN_Q_BYTES) {
             memcpy(x->h_pin, queries, qbytes);
             HIP_TRY(hipMemcpyAsync(x->qdev, x->h_pin, qbytes, hipMemcpyHostToDevice, s));
         } else {
@@ -1364,21 +1422,32 @@ static int search_common(icd_index *x, const float *queries, int64_t nq, int32_t
         dev.adj_ids = user.adj_ids ? x->o_adj_ids : nullptr;
         dev.adj_lv = user.adj_lv ? x->o_adj_lv : nullptr;
     }
+    x->done_armed = false;
     int rc = search_device(x, dq, (int)nq, k, mode, dev, s);
+    x->host_q = nullptr;
     if (rc) return rc;
     rec(x, NUM_EV, s);
+    if (x->done_armed && pinned_out) {
+        // ONE query through the single-launch kernel: its last work-group stores the call's sequence number behind the outputs
+        // (system-scope release). Poll it for a bounded time - no event record, no wait for the queue's completion signal -
+        // and fall back to the stream synchronisation (always correct) when the word does not arrive (a busy GPU, a failed launch).
+        const volatile unsigned long long *done = reinterpret_cast<const volatile unsigned long long *>(x->h_pin + PIN_Q_BYTES + PIN_OUT_BYTES);
+        const auto t0 = std::chrono::steady_clock::now();
+        bool seen = false;
+        for (unsigned spin = 0;; ++spin) {
+            if (__atomic_load_n(done, __ATOMIC_ACQUIRE) == x->done_seq) { seen = true; break; }
+            if ((spin & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(DONE_POLL_US)) break;
+        }
+        if (!seen) HIP_TRY(hipStreamSynchronize(s));
+        copy_pinned_out(x, user, no_small);
+        return ICD_OK;
+    }
     // the search's last kernel has written the fallback counters to pinned host memory: icd_index_stats reads them after
     // waiting for THIS event only (no device-wide synchronisation: other streams - an encoder - keep running)
     if (!x->capturing) HIP_TRY(hipEventRecord(x->ev_nflag, s));   // (an event recorded inside a capture could not be waited for by icd_index_stats)
     if (pinned_out) {
         HIP_TRY(hipStreamSynchronize(s));   // (the kernels' stores to the mapped block are visible behind it, like the counters')
-        const char *h = x->h_pin + PIN_Q_BYTES;
-        if (user.adj) memcpy(user.adj, h, no_small * 8);              h += no_small * 8;
-        if (user.ids) memcpy(user.ids, h, no_small * 8);              h += no_small * 8;
-        if (user.adj_ids) memcpy(user.adj_ids, h, no_small * 8);      h += no_small * 8;
-        if (user.scores) memcpy(user.scores, h, no_small * 4);        h += no_small * 4;
-        if (user.adj_raw) memcpy(user.adj_raw, h, no_small * 4);      h += no_small * 4;
-        if (user.adj_lv) memcpy(user.adj_lv, h, no_small * 4);
+        copy_pinned_out(x, user, no_small);
         return ICD_OK;
     }
     if (!out_on_device) {
@@ -1600,6 +1669,11 @@ int icd_debug_set_pacing(int32_t shift, int32_t lead) {
 
 int icd_debug_set_exact_narrow(int32_t enabled) {
     g_exact_narrow = enabled != 0;
+    return ICD_OK;
+}
+
+int icd_debug_set_host_one(int32_t bits) {
+    g_host_one = bits & 3;
     return ICD_OK;
 }
 

@@ -61,7 +61,17 @@ struct StreamArgs {
     u64 *wg_keys;         // [slot][nwg][KP] one merged best-first list per work-group (keys, 0 = empty)
     u64 *ticket;          // monotonic arrival counter (zeroed once, at index create)
     FinArgs fin;          // the outputs, levels, id_base and k of the search (emit_outputs), counters / host_counters
+    // a host caller's ONE query (icd_search.hip, search_common): the last work-group stores done_value to *done - a word of the
+    // index's mapped host block - behind its outputs (system-scope release); nullptr = nobody polls
+    u64 *done;
+    u64 done_value;
 };
+
+// ONE query handed over IN the kernel arguments (a host caller's call: no H2D copy command in front of the launch). The
+// dispatch packet's argument segment is written by the host at launch and read here like any global memory.
+constexpr int ST_INLINE_FLOATS = 768;
+struct alignas(16) StreamInlineQuery { float v[ST_INLINE_FLOATS]; };
+static_assert(sizeof(StreamArgs) + sizeof(StreamInlineQuery) + 16 <= 4096, "kernel arguments: 4 KB at most");
 
 template <int KP, int E, int QB>
 __host__ __device__ constexpr size_t stream_lds_bytes(int dim, int ring_stages) {
@@ -130,8 +140,8 @@ __device__ __forceinline__ void wait_vmcnt_uniform(int n) {
 #undef ICD_VM
 }
 
-template <int KP, int E, int QB, bool ONE = false>
-__global__ __launch_bounds__(256) void stream_topk_kernel(StreamArgs a) {
+template <int KP, int E, int QB, bool ONE>
+__device__ __forceinline__ void stream_topk_body(const StreamArgs &a, const float *qsrc) {
     constexpr int CAP = 64 * E;
     static_assert(!ONE || (QB <= 4 && KP <= 16), "the single-launch form serves up to four queries at k <= 16");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -173,7 +183,7 @@ __global__ __launch_bounds__(256) void stream_topk_kernel(StreamArgs a) {
             const int qi = i / dim, d = i - qi * dim;
             const int slot = q0 + min(qi, nqp - 1);   // unused slots repeat the last query (never emitted)
             const int gq = a.qlist ? a.qlist[slot] : slot;
-            *reinterpret_cast<float4 *>(qs + i) = *reinterpret_cast<const float4 *>(a.queries + (size_t)gq * dim + d);
+            *reinterpret_cast<float4 *>(qs + i) = *reinterpret_cast<const float4 *>(qsrc + (size_t)gq * dim + d);
         }
         __syncthreads();
         float thr[QB];
@@ -443,6 +453,11 @@ __global__ __launch_bounds__(256) void stream_topk_kernel(StreamArgs a) {
                 a.fin.host_counters[0] = 0;
                 for (int i = 1; i < 5; ++i) a.fin.host_counters[i] = a.fin.counters[i];
             }
+            if (a.done) {   // (work-group-uniform) the host polls this word instead of waiting for the stream
+                __threadfence_system();   // every wave: its output stores have reached the host block ...
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(a.done, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before the word does
+            }
             return;
         } else {
         // this wave's best-first list of every query of the pass
@@ -465,6 +480,16 @@ __global__ __launch_bounds__(256) void stream_topk_kernel(StreamArgs a) {
         }
         }
     }
+}
+
+template <int KP, int E, int QB, bool ONE = false>
+__global__ __launch_bounds__(256) void stream_topk_kernel(StreamArgs a) {
+    stream_topk_body<KP, E, QB, ONE>(a, a.queries);
+}
+// the single-launch form of ONE query whose vector arrives in the kernel arguments (StreamInlineQuery)
+template <int KP, int E>
+__global__ __launch_bounds__(256) void stream_one_inline_kernel(StreamArgs a, StreamInlineQuery q) {
+    stream_topk_body<KP, E, 1, true>(a, q.v);
 }
 
 // One wave per (slot, output list g): merge lists g, g + P_out, g + 2 P_out, ... of the slot's nlists

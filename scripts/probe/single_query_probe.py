@@ -61,15 +61,25 @@ def main():
             torch.cuda.synchronize()
             wall_us = (time.perf_counter() - t0) / 400 * 1e6
             dev_us = e0.elapsed_time(e1) / 400 * 1e3
-            # host: numpy in, numpy out, one call at a time
+            # host: numpy in, numpy out, one call at a time; with the single-launch kernel also the four forms of handing the
+            # vector over and of waiting (icd_debug_set_host_one: 0 = copy + stream synchronisation, 1 = vector in the kernel
+            # arguments, 2 = polled completion word, 3 = both, the default), interleaved
+            forms = (0, 1, 2, 3) if one else (3,)
+            lat_by = {b: [] for b in forms}
             for _ in range(20):
                 index.search_reweighted(queries[:1], k)
-            lat = []
             for i in range(200):
-                t0 = time.perf_counter()
-                index.search_reweighted(queries[i & 63:(i & 63) + 1], k)
-                lat.append((time.perf_counter() - t0) * 1e6)
-            lat.sort()
+                for b in forms:
+                    lib.icd_debug_set_host_one(b)
+                    t0 = time.perf_counter()
+                    index.search_reweighted(queries[i & 63:(i & 63) + 1], k)
+                    lat_by[b].append((time.perf_counter() - t0) * 1e6)
+            lib.icd_debug_set_host_one(3)
+            for b in forms:
+                lat_by[b].sort()
+            if one:
+                print(f"k={k:2d} host call by form (median us): " + ", ".join(f"host_one={b}: {lat_by[b][100]:.1f}" for b in forms))
+            lat = lat_by[3]
             print(f"k={k:2d} single-launch kernel {'on ' if one else 'off'}: device {dev_us:6.1f} us per call (host enqueue {wall_us:5.1f} us; "
                   f"{bytes_per_call / dev_us / 1e6:5.2f} TB/s = {bytes_per_call / dev_us / 1e6 / 8.0:.3f} of 8 TB/s) | "
                   f"host call median {lat[100]:6.1f} us, p10 {lat[20]:6.1f}, p90 {lat[180]:6.1f}")

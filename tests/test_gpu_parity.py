@@ -1161,6 +1161,50 @@ def test_one_and_two_queries_take_the_single_launch_kernel_and_match_the_oracle(
         idx.close()
 
 
+@pytest.mark.parametrize("dim", [256, 768, 1024])
+def test_a_host_callers_one_query_in_the_kernel_arguments_and_the_polled_completion(oracle, dim):
+    """ONE query per call from HOST memory (MilvusClient.search(data=[query_vector.tolist()]), services/milvus_service.py:280-285):
+    the vector travels in the single-launch kernel's arguments and the call returns on a polled completion word
+    (icd_debug_set_host_one bits 1 and 2). All four settings are bit-equal to the oracle, call after call (the word is a
+    sequence number), also interleaved with batch calls, calls of two queries and device-resident calls on the same handle;
+    1024-d vectors do not fit the arguments and take the copy; k > 16 leaves the single-launch kernel (the copy is enqueued
+    after all)."""
+    import torch
+    n = 5000
+    corpus, levels = unit_rows(n, dim, 81 + dim), icd_levels(n, 82 + dim)
+    corpus[9::11] = corpus[4]
+    queries = unit_rows(40, dim, 83 + dim)
+    queries[3] = corpus[4]
+    idx = IcdIndex(corpus, levels, max_nq=64, max_k=32)
+    lib = _native.load_library()
+    want = {}
+    for k in (1, 10, 16, 20):
+        os_, oi = oracle.flat_ip_topk(corpus, queries, k)
+        want[k] = (os_, oi, oracle.reweight(os_, oi, levels))
+    dq = torch.from_numpy(queries).cuda()
+    try:
+        for bits in (3, 0, 1, 2, 3):
+            lib.icd_debug_set_host_one(bits)
+            for k in (10, 1, 16, 20):
+                os_, oi, rw = want[k]
+                for j in range(12):
+                    s, i = idx.search(queries[j:j + 1], k)
+                    assert np.array_equal(i, oi[j:j + 1]) and _bits(s) == _bits(os_[j:j + 1]), (dim, bits, k, j)
+                    got = idx.search_reweighted(queries[j:j + 1], k)
+                    assert all(_bits(a) == _bits(b[j:j + 1]) for a, b in zip(got, rw)), (dim, bits, k, j)
+                    if j % 4 == 1:     # a batch, two queries and a device-resident query in between
+                        s2, i2 = idx.search(queries[:40], k)
+                        assert np.array_equal(i2, oi) and _bits(s2) == _bits(os_)
+                        s3, i3 = idx.search(queries[j:j + 2], k)
+                        assert np.array_equal(i3, oi[j:j + 2]) and _bits(s3) == _bits(os_[j:j + 2])
+                        s4, i4 = idx.search(dq[j:j + 1], k)
+                        torch.cuda.synchronize()
+                        assert np.array_equal(i4.cpu().numpy(), oi[j:j + 1]) and _bits(s4.cpu().numpy()) == _bits(os_[j:j + 1])
+    finally:
+        lib.icd_debug_set_host_one(3)
+        idx.close()
+
+
 @pytest.mark.parametrize("k", [33, 50, 64, 100])
 def test_exact_mode_above_k32_runs_certified_narrow_lists_and_stays_exact(oracle, k):
     """ICD_MODE_EXACT at k > 32 (the k range /query can ask for: top_k * 2 with top_k <= 50, models/icd_models.py:138,
