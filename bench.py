@@ -1010,7 +1010,7 @@ def main(argv=None):
     ap.add_argument("--repeats", type=int, default=5, help="replicated workload: repeat the K-step window this many times after the measurement (reported under extra.windows)")
     ap.add_argument("--workload", choices=["replicated", "rowshard"], default="replicated")
     ap.add_argument("--nq", type=int, default=10000)
-    ap.add_argument("--n", type=int, default=37000)
+    ap.add_argument("--n", "--corpus-rows", dest="n", type=int, default=37000)   # (--corpus-rows: `--n` is an ambiguous prefix for torch.distributed.run's own parser)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--mode", choices=["auto", "exact"], default="auto")
     ap.add_argument("--rows-per-gpu", type=int, default=1_250_000)

@@ -115,6 +115,30 @@ def test_bench_gpus_2_starts_two_ranks_itself():
     assert "oracle" in rs["sample_checked_against"] and rs["sample_slices"] == 2 and rs["sample_queries"] == 16
 
 
+def test_bench_under_torch_distributed_run_exactly_as_the_driver_launches_n_gt_1():
+    """The driver's N > 1 command: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` - the ranks come from the launcher (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in the environment), bench.py must not start any itself, and rank 0 prints the ONE line."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update({"ICD_BENCH_BACKEND": "gloo", "ICD_BENCH_DEVICE": "cpu",
+                "ICD_BENCH_TEST_ENGINE": os.path.join(ROOT, "tests", "bench_cpu_engine.py")})
+    port = 29890 + (os.getpid() % 40)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + ["--corpus-rows" if a == "--n" else a for a in SMALL]   # (the launcher's parser rejects `--n` as an ambiguous prefix of its own options)
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["config"]["collective_ranks"] == 2
+    assert line["ids_exact"] and line["adjusted_scores_exact"] and line["value"] > 0
+    assert line["config3"]["n_gpus"] == 2 and line["rowshard"]["config"]["collective_ranks"] == 2
+    assert line["rowshard"]["ids_exact_on_sample"] and line["rowshard"]["config"]["engine"]
+
+
 def test_bench_gpus_1_is_a_single_process_line_with_the_extras():
     p = _run_bench(["--gpus", "1"])
     assert p.returncode == 0, p.stderr[-3000:]
