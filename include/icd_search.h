@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define ICD_ABI_VERSION 5   /* 5: icd_debug_unpack_query_slices, icd_debug_set_stream_one, icd_debug_set_pacing, icd_debug_set_exact_narrow, icd_debug_set_host_one, icd_split_bf16x3 (round 5). 4: icd_debug_set_family_order, icd_debug_set_center, icd_stats.centered / mean_share appended, icd_group_prepare / icd_group_connect (round 4). 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
+#define ICD_ABI_VERSION 5   /* 5: icd_debug_unpack_query_slices, icd_debug_set_stream_one, icd_debug_set_pacing, icd_debug_set_exact_narrow, icd_debug_set_host_one, icd_split_bf16x3, icd_encoder_create / _encode / _destroy (round 5). 4: icd_debug_set_family_order, icd_debug_set_center, icd_stats.centered / mean_share appended, icd_group_prepare / icd_group_connect (round 4). 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
 #define ICD_MAX_K 128
 
 typedef struct icd_index icd_index;
@@ -333,6 +333,40 @@ int icd_debug_set_exact_narrow(int32_t enabled);
  * more) in its first hi_r - lo_r rows. Outputs: device pointers, [nq][k]. No reference counterpart (single process). */
 int icd_debug_unpack_query_slices(int32_t device, const void *gathered, int32_t world, int64_t nq, int32_t k, double *out_adj,
                                   float *out_raw, int64_t *out_ids, int32_t *out_levels, void *stream);
+
+/* ---- the sentence encoder for SMALL inputs ------------------------------------------------
+ * The reference embeds ONE string per call - EmbeddingService.encode_query / encode_single -> SentenceTransformer.encode
+ * (services/embedding_service.py:97-102, 117-120) - and a /query request a handful (services/multi_diagnosis_service.py:97,
+ * 137). At 10-100 tokens the framework's forward is ~220 kernels of ~5 us (1.1 ms replayed from a graph); this is the same
+ * BERT forward (post-LN encoder, absolute positions, erf-GELU, 64-wide heads, fp32) as 7 hand-written launches per layer
+ * (csrc/encoder_small.hpp), replayed as ONE graph per token bucket. The weights stay where the caller keeps them (device
+ * fp32, e.g. the torch module's parameters): the handle borrows the pointers, the caller keeps them alive and unchanged. */
+typedef struct icd_encoder icd_encoder;
+typedef struct {
+    int32_t layers, hidden, heads, inter;   /* hidden = heads * 64; hidden and inter multiples of 192 (<= 3072) and hidden of 256 */
+    int32_t vocab, max_pos;                 /* rows of word_emb / pos_emb */
+    int32_t pos_offset;                     /* position of a sequence's first token: 0 (BERT), padding_idx + 1 (RoBERTa / XLM-R) */
+    float ln_eps;
+    const float *word_emb, *pos_emb, *type_emb0, *emb_ln_g, *emb_ln_b;
+    /* [layers] host arrays of device pointers; Linear weights as torch keeps them, [out][in] row-major */
+    const float *const *w_qkv;  const float *const *b_qkv;    /* [3 hidden][hidden]: query | key | value rows stacked */
+    const float *const *w_ao;   const float *const *b_ao;     /* attention output dense [hidden][hidden] */
+    const float *const *ln1_g;  const float *const *ln1_b;
+    const float *const *w_up;   const float *const *b_up;     /* intermediate dense [inter][hidden] */
+    const float *const *w_down; const float *const *b_down;   /* output dense [hidden][inter] */
+    const float *const *ln2_g;  const float *const *ln2_b;
+} icd_encoder_desc;
+#define ICD_ENCODER_MAX_TOKENS 128   /* packed tokens per call */
+#define ICD_ENCODER_MAX_SEQS 32      /* sequences per call */
+int icd_encoder_create(int32_t device, const icd_encoder_desc *desc, icd_encoder **out);
+/* ids: HOST int32, the sequences' token ids back to back (special tokens included); lengths: HOST int32 [nseq], each >= 1,
+ * their sum <= ICD_ENCODER_MAX_TOKENS. pooling 0 = mean over a sequence's tokens, 1 = its first token; normalize 1 =
+ * torch.nn.functional.normalize(p = 2). out: [nseq][hidden] fp32, host (the call returns when it is filled) or device
+ * (out_on_device = 1: enqueued on `stream`, no synchronisation). hidden_out: NULL, or a DEVICE buffer [sum lengths][hidden]
+ * that receives the last hidden state of every token (token classification heads). Calls on one handle are serialised. */
+int icd_encoder_encode(icd_encoder *e, const int32_t *ids, const int32_t *lengths, int32_t nseq, int32_t pooling, int32_t normalize,
+                       float *out, int32_t out_on_device, float *hidden_out, void *stream);
+int icd_encoder_destroy(icd_encoder *e);
 
 /* Diagnostic builds only (make ABLATE=1, env ICD_FLAT_VAR with bit 1024): per-wave cycle sums of the coarse kernel,
  * [work-group][wave][8] = {LDS-DMA wait, barrier, stage body, fused select, tiles, ...}. */

@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = (
     "icd_cosine_rows",
     "icd_index_set_second_pass",
     "icd_group_unique_id", "icd_group_create", "icd_group_prepare", "icd_group_connect", "icd_group_search", "icd_group_destroy",
-    "icd_debug_unpack_query_slices", "icd_debug_set_stream_one", "icd_debug_set_host_one", "icd_debug_set_pacing", "icd_debug_set_exact_narrow", "icd_split_bf16x3",
+    "icd_debug_unpack_query_slices", "icd_debug_set_stream_one", "icd_debug_set_host_one", "icd_debug_set_pacing", "icd_debug_set_exact_narrow", "icd_split_bf16x3", "icd_encoder_create", "icd_encoder_encode", "icd_encoder_destroy",
 )
 GROUP_ROW_SHARD = 0
 GROUP_QUERY_SHARD = 1
@@ -56,6 +56,20 @@ class _Stats(C.Structure):
                 ("last_mode", C.c_int32), ("last_second_pass", C.c_int64), ("last_second_pass_lists", C.c_int32),
                 ("second_pass_armed", C.c_int32), ("wide_mode", C.c_int32), ("sparse_fallback_armed", C.c_int32),
                 ("centered", C.c_int32), ("mean_share", C.c_float)]
+
+
+_ENC_LAYER_FIELDS = ("w_qkv", "b_qkv", "w_ao", "b_ao", "ln1_g", "ln1_b", "w_up", "b_up", "w_down", "b_down", "ln2_g", "ln2_b")
+
+
+class _EncoderDesc(C.Structure):   # include/icd_search.h icd_encoder_desc
+    _fields_ = ([("layers", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32), ("inter", C.c_int32), ("vocab", C.c_int32),
+                 ("max_pos", C.c_int32), ("pos_offset", C.c_int32), ("ln_eps", C.c_float),
+                 ("word_emb", C.c_void_p), ("pos_emb", C.c_void_p), ("type_emb0", C.c_void_p), ("emb_ln_g", C.c_void_p), ("emb_ln_b", C.c_void_p)]
+                + [(name, C.POINTER(C.c_void_p)) for name in _ENC_LAYER_FIELDS])
+
+
+ENCODER_MAX_TOKENS = 128   # include/icd_search.h ICD_ENCODER_MAX_TOKENS
+ENCODER_MAX_SEQS = 32      # ... ICD_ENCODER_MAX_SEQS
 
 
 class _Profile(C.Structure):
@@ -107,6 +121,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.icd_split_bf16x3.argtypes = [i32, vp, i64, i32, i64, i32, vp, vp]
     lib.icd_debug_unpack_query_slices.argtypes = [i32, vp, i32, i64, i32, vp, vp, vp, vp, vp]
     lib.icd_packed_attention.argtypes = [i32, vp, i64, vp, i32, i32, i32, i32, vp, i64, vp]
+    lib.icd_encoder_create.argtypes = [i32, C.POINTER(_EncoderDesc), C.POINTER(vp)]
+    lib.icd_encoder_encode.argtypes = [vp, vp, vp, i32, i32, i32, vp, i32, vp, vp]
+    lib.icd_encoder_destroy.argtypes = [vp]
     lib.icd_hier_rescore.argtypes = [i32, vp, vp, i64, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.icd_score_stats.argtypes = [i32, vp, vp, i64, i32, i32, vp, vp]
     lib.icd_cosine_rows.argtypes = [i32, vp, vp, i64, i64, i32, vp, vp]
@@ -528,6 +545,109 @@ def packed_attention(qkv, starts, nseq: int, heads: int, max_len: int, out):
     _check(lib, lib.icd_packed_attention(dev.index, qkv.data_ptr(), qkv.stride(0), starts.data_ptr(), int(nseq), int(heads), 64,
                                          int(max_len), out.data_ptr(), out.stride(0), _current_stream_ptr(dev.index)))
     return out
+
+
+class SmallEncoder:
+    """The BERT-style sentence encoder for SMALL inputs (include/icd_search.h icd_encoder_*; csrc/encoder_small.hpp): up to
+    ENCODER_MAX_SEQS sequences / ENCODER_MAX_TOKENS packed tokens per call, ONE graph launch per forward. Replaces the
+    SentenceTransformer.encode call of EmbeddingService.encode_query / encode_single (reference
+    services/embedding_service.py:97-102,117-120) for one string or a request's handful.
+
+    Built from a transformers BertModel-like module on a CUDA device with fp32 parameters; the handle BORROWS the parameter
+    storage (this object keeps the tensors alive; do not modify them while it lives)."""
+
+    @staticmethod
+    def supported(bert) -> bool:
+        cfg = bert.config
+        try:
+            p = bert.embeddings.word_embeddings.weight
+            import torch
+            return (type(bert).__name__ in ("BertModel", "XLMRobertaModel", "RobertaModel") and p.is_cuda and p.dtype == torch.float32
+                    and getattr(cfg, "position_embedding_type", None) in (None, "absolute") and getattr(cfg, "hidden_act", "gelu") == "gelu"
+                    and not getattr(cfg, "is_decoder", False) and int(cfg.hidden_size) == 768 and int(cfg.hidden_size) // int(cfg.num_attention_heads) == 64
+                    and int(cfg.intermediate_size) % 192 == 0 and int(cfg.intermediate_size) <= 3072)
+        except Exception:
+            return False
+
+    def __init__(self, bert):
+        import torch
+        self._lib = load_library()
+        cfg = bert.config
+        emb = bert.embeddings
+        self.hidden = int(cfg.hidden_size)
+        self.device = emb.word_embeddings.weight.device.index or 0
+        keep = []   # every tensor the handle points at
+
+        def ptr(t):
+            t = t.detach()
+            if not t.is_contiguous():
+                t = t.contiguous()
+            assert t.dtype == torch.float32 and t.is_cuda
+            keep.append(t)
+            return t.data_ptr()
+        d = _EncoderDesc()
+        d.layers, d.hidden, d.heads, d.inter = len(bert.encoder.layer), self.hidden, int(cfg.num_attention_heads), int(cfg.intermediate_size)
+        d.vocab, d.max_pos = int(emb.word_embeddings.weight.shape[0]), int(emb.position_embeddings.weight.shape[0])
+        d.pos_offset = int(emb.padding_idx) + 1 if type(bert).__name__ != "BertModel" else 0
+        d.ln_eps = float(cfg.layer_norm_eps)
+        d.word_emb, d.pos_emb = ptr(emb.word_embeddings.weight), ptr(emb.position_embeddings.weight)
+        d.type_emb0 = ptr(emb.token_type_embeddings.weight[0])
+        d.emb_ln_g, d.emb_ln_b = ptr(emb.LayerNorm.weight), ptr(emb.LayerNorm.bias)
+        per = {name: [] for name in _ENC_LAYER_FIELDS}
+        for l in bert.encoder.layer:
+            a = l.attention.self
+            per["w_qkv"].append(ptr(torch.cat([a.query.weight, a.key.weight, a.value.weight], 0)))
+            per["b_qkv"].append(ptr(torch.cat([a.query.bias, a.key.bias, a.value.bias], 0)))
+            per["w_ao"].append(ptr(l.attention.output.dense.weight)); per["b_ao"].append(ptr(l.attention.output.dense.bias))
+            per["ln1_g"].append(ptr(l.attention.output.LayerNorm.weight)); per["ln1_b"].append(ptr(l.attention.output.LayerNorm.bias))
+            per["w_up"].append(ptr(l.intermediate.dense.weight)); per["b_up"].append(ptr(l.intermediate.dense.bias))
+            per["w_down"].append(ptr(l.output.dense.weight)); per["b_down"].append(ptr(l.output.dense.bias))
+            per["ln2_g"].append(ptr(l.output.LayerNorm.weight)); per["ln2_b"].append(ptr(l.output.LayerNorm.bias))
+        arrays = {}
+        for name in _ENC_LAYER_FIELDS:
+            arrays[name] = (C.c_void_p * d.layers)(*per[name])
+            setattr(d, name, C.cast(arrays[name], C.POINTER(C.c_void_p)))
+        self._keep = keep
+        h = C.c_void_p()
+        _check(self._lib, self._lib.icd_encoder_create(self.device, C.byref(d), C.byref(h)))
+        self._h = h
+
+    def fits(self, lengths) -> bool:
+        return 0 < len(lengths) <= ENCODER_MAX_SEQS and sum(lengths) <= ENCODER_MAX_TOKENS and min(lengths) >= 1
+
+    def encode(self, ids, pooling: str = "mean", normalize: bool = True, to_device: bool = False, hidden: bool = False):
+        """ids: token id lists (special tokens included). -> float32 [n, hidden] (numpy, or a CUDA tensor with to_device=True:
+        enqueued on torch's current stream); with hidden=True also the last hidden state of every token, packed [T, hidden]
+        (a CUDA tensor)."""
+        import torch
+        if not getattr(self, "_h", None) or not self._h.value:
+            raise IcdError(-5, "encoder is closed")
+        lengths = np.fromiter((len(x) for x in ids), dtype=np.int32, count=len(ids))
+        flat = np.fromiter((t for x in ids for t in x), dtype=np.int32, count=int(lengths.sum()))
+        n = len(ids)
+        dev = torch.device("cuda", self.device)
+        hid = torch.empty((int(lengths.sum()), self.hidden), dtype=torch.float32, device=dev) if hidden else None
+        if to_device:
+            out = torch.empty((n, self.hidden), dtype=torch.float32, device=dev)
+            optr = out.data_ptr()
+        else:
+            out = np.empty((n, self.hidden), dtype=np.float32)
+            optr = out.ctypes.data
+        _check(self._lib, self._lib.icd_encoder_encode(self._h, flat.ctypes.data, lengths.ctypes.data, n, 1 if pooling == "cls" else 0,
+                                                      1 if normalize else 0, optr, 1 if to_device else 0,
+                                                      hid.data_ptr() if hidden else None, _current_stream_ptr(self.device)))
+        return (out, hid) if hidden else out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.icd_encoder_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def split_bf16x3(x, gelu: bool = False):

@@ -35,6 +35,8 @@ struct PackedAttnArgs {
     long long ld, out_ld; // row strides in floats (3 * hidden, hidden)
     int hidden;           // heads * 64
     float scale;          // 1 / sqrt(64)
+    int qsplit;           // waves per (sequence, head): wave p takes the queries p, p + qsplit, ... (0 / 1: one wave takes them all). The
+                          // small-input encoder (encoder_small.hpp) deals a 16-token string's queries over four waves: latency, not throughput
 };
 
 // acc += q[16 g + n] * k[16 g + n] for n = 0..15, the query element broadcast from lane n of every 16-lane row
@@ -89,7 +91,9 @@ __global__ __launch_bounds__(256) void packed_attention_kernel(PackedAttnArgs a)
     // running softmax state of the queries of a sequence longer than one chunk of 64 keys: max and sum per query, per wave
     __shared__ float run_m[4][ATT_MAX_SEQ], run_l[4][ATT_MAX_SEQ];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int task = blockIdx.x * 4 + wave;
+    const int qs = a.qsplit > 1 ? a.qsplit : 1;
+    const int wtask = blockIdx.x * 4 + wave;
+    const int task = wtask / qs, part = wtask - task * qs;
     if (task >= a.nseq * a.heads) return;   // wave-uniform (no work-group barriers below)
     const int s = task / a.heads, h = task - s * a.heads;
     const int r0 = a.starts[s];
@@ -133,11 +137,12 @@ __global__ __launch_bounds__(256) void packed_attention_kernel(PackedAttnArgs a)
         }
         // (the next query's four values are fetched while this one is worked on: a row's arithmetic is ~150 instructions,
         //  a global load's round trip several times that)
-        float n0 = qp[0], n1 = qp[16], n2 = qp[32], n3 = qp[48];
-        for (int i = 0; i < L; ++i) {
+        const float *qfirst = qp + (size_t)min(part, L - 1) * a.ld;
+        float n0 = qfirst[0], n1 = qfirst[16], n2 = qfirst[32], n3 = qfirst[48];
+        for (int i = part; i < L; i += qs) {
             const float q0 = n0 * a.scale, q1 = n1 * a.scale, q2 = n2 * a.scale, q3 = n3 * a.scale;
             {
-                const float *qn = qp + (size_t)min(i + 1, L - 1) * a.ld;
+                const float *qn = qp + (size_t)min(i + qs, L - 1) * a.ld;
                 n0 = qn[0]; n1 = qn[16]; n2 = qn[32]; n3 = qn[48];
             }
             float acc = 0.f;

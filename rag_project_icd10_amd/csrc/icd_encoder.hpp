@@ -1,0 +1,253 @@
+// icd_encoder.hpp — host side of the small-input sentence encoder (include/icd_search.h, icd_encoder_*; kernels:
+// encoder_small.hpp, attention_kernel.hpp). Included by icd_search.hip (its fail() / HIP_TRY).
+//
+// One forward = ONE graph launch: [descriptor H2D] -> embedding sum -> layers x (LayerNorm + QKV, attention, attention output
+// + residual, LayerNorm + FFN up + GELU, FFN down + residual) -> LayerNorm + pooling -> [result D2H into a pinned block]. The
+// graph depends on the token bucket (16 / 32 / 64 / 128: the grids of the per-token kernels) and the pooling flags only;
+// token ids, positions and sequence bounds travel in the descriptor. Captured once per (bucket, pooling, normalize) on a
+// private stream, replayed on the caller's (a call made while the caller's stream is itself being captured is refused: the
+// token ids are read from host memory at call time).
+#pragma once
+#include "attention_kernel.hpp"
+#include "encoder_small.hpp"
+
+struct icd_encoder {
+    uint64_t magic = 0;
+    int device = 0;
+    icd_encoder_desc d{};
+    std::vector<const float *> w_qkv, b_qkv, w_ao, b_ao, ln1_g, ln1_b, w_up, b_up, w_down, b_down, ln2_g, ln2_b;
+    // workspace: activations of at most ENC_TMAX tokens
+    float *yb[3] = {nullptr, nullptr, nullptr};   // pre-norm sublayer outputs, rotating (encoder_small.hpp)
+    float *x = nullptr, *qkv = nullptr, *ctx = nullptr, *mid = nullptr, *pooled = nullptr, *sA = nullptr, *sB = nullptr;
+    int *d_meta = nullptr;
+    int *h_meta = nullptr;       // pinned: the descriptor the graph's first node copies
+    float *h_out = nullptr;      // pinned: the pooled rows the graph's last node fills
+    hipStream_t cap_stream = nullptr;
+    hipEvent_t ev_done = nullptr;   // behind every launch: the next call may rewrite h_meta only after the copy node has run
+    bool ev_pending = false;
+    static constexpr int NBUCKET = 4;   // 16, 32, 64, 128 tokens
+    hipGraphExec_t exec[NBUCKET][2][2] = {};   // [bucket][pooling][normalize]
+    unsigned long long *stamps = nullptr;   // diagnostic builds (ICD_ABLATE, env ICD_ENC_STAMPS=1): [4 GEMMs of layer 0][16] clock stamps
+    std::mutex mu;
+};
+
+namespace icd {
+constexpr uint64_t ENC_MAGIC = 0x49434445454e4331ull;
+inline bool enc_valid(const icd_encoder *e) { return e && e->magic == ENC_MAGIC; }
+
+// the launches of one forward on stream s (inside a capture): the descriptor H2D in front, the pooled rows' D2H behind
+inline int enc_enqueue(icd_encoder *e, int bucket_tokens, int pooling, int normalize, hipStream_t s) {
+    const icd_encoder_desc &d = e->d;
+    const int H = d.hidden, I = d.inter;
+    HIP_TRY(hipMemcpyAsync(e->d_meta, e->h_meta, ENC_META_WORDS * sizeof(int), hipMemcpyHostToDevice, s));
+    {
+        EncEmbedArgs a{};
+        a.meta = e->d_meta; a.word = d.word_emb; a.pos = d.pos_emb; a.type0 = d.type_emb0; a.H = H; a.y = e->yb[0];
+        hipLaunchKernelGGL(enc_embed_kernel<3>, dim3((bucket_tokens + 3) / 4), dim3(256), 0, s, a);
+    }
+    // y[cur]: the PRE-norm output of the previous sublayer, (pg, pb) the LayerNorm it still has to go through
+    int cur = 0;
+    const float *pg = d.emb_ln_g, *pb = d.emb_ln_b;
+    for (int l = 0; l < d.layers; ++l) {
+        float *y0 = e->yb[cur], *y1 = e->yb[(cur + 1) % 3], *y2 = e->yb[(cur + 2) % 3];
+        {   // Q | K | V = LayerNorm(y0) Wqkv^T + b; leaves LayerNorm's statistics in sA
+            EncLinearArgs a{};
+            a.meta = e->d_meta; a.x = y0; a.ln_g = pg; a.ln_b = pb; a.ln_eps = d.ln_eps; a.stats_out = e->sA;
+            a.w = e->w_qkv[l]; a.bias = e->b_qkv[l]; a.y = e->qkv; a.K = H; a.N = 3 * H; a.stamps = (e->stamps && l == 6) ? e->stamps : nullptr;
+            hipLaunchKernelGGL((enc_linear_kernel<12, 16, 0, true>), dim3(3 * H / 16), dim3(64 * (H / 192)), 0, s, a);
+        }
+        {
+            EncAttnArgs a{};
+            a.meta = e->d_meta; a.qkv = e->qkv; a.out = e->ctx; a.H = H; a.heads = d.heads; a.scale = 0.125f;
+            hipLaunchKernelGGL(enc_attention_kernel, dim3((bucket_tokens * d.heads + 3) / 4), dim3(256), 0, s, a);
+        }
+        {   // y1 = ctx Wo^T + b + LayerNorm(y0)      (BertSelfOutput in front of its LayerNorm)
+            EncLinearArgs a{};
+            a.meta = e->d_meta; a.x = e->ctx; a.w = e->w_ao[l]; a.bias = e->b_ao[l];
+            a.res_src = y0; a.res_stats = e->sA; a.res_g = pg; a.res_b = pb; a.y = y1; a.K = H; a.N = H; a.stamps = (e->stamps && l == 6) ? e->stamps + 16 : nullptr;
+            hipLaunchKernelGGL((enc_linear_kernel<12, 8, 2, false>), dim3(H / 8), dim3(64 * (H / 192)), 0, s, a);
+        }
+        {   // mid = GELU(LayerNorm1(y1) Wup^T + b); statistics of LayerNorm1 in sB
+            EncLinearArgs a{};
+            a.meta = e->d_meta; a.x = y1; a.ln_g = e->ln1_g[l]; a.ln_b = e->ln1_b[l]; a.ln_eps = d.ln_eps; a.stats_out = e->sB;
+            a.w = e->w_up[l]; a.bias = e->b_up[l]; a.y = e->mid; a.K = H; a.N = I; a.stamps = (e->stamps && l == 6) ? e->stamps + 32 : nullptr;
+            hipLaunchKernelGGL((enc_linear_kernel<12, 16, 1, true>), dim3(I / 16), dim3(64 * (H / 192)), 0, s, a);
+        }
+        {   // y2 = mid Wdown^T + b + LayerNorm1(y1)   (BertOutput in front of its LayerNorm)
+            EncLinearArgs a{};
+            a.meta = e->d_meta; a.x = e->mid; a.w = e->w_down[l]; a.bias = e->b_down[l];
+            a.res_src = y1; a.res_stats = e->sB; a.res_g = e->ln1_g[l]; a.res_b = e->ln1_b[l]; a.y = y2; a.K = I; a.N = H; a.stamps = (e->stamps && l == 6) ? e->stamps + 48 : nullptr;
+            hipLaunchKernelGGL((enc_linear_kernel<12, 4, 2, false>), dim3(H / 4), dim3(64 * (I / 192)), 0, s, a);
+        }
+        cur = (cur + 2) % 3;
+        pg = e->ln2_g[l]; pb = e->ln2_b[l];
+    }
+    {   // the last LayerNorm, pooling, normalisation; the last hidden state of every token into x
+        EncPoolArgs a{};
+        a.meta = e->d_meta; a.y = e->yb[cur]; a.g = pg; a.b = pb; a.eps = d.ln_eps; a.H = H; a.pooling = pooling; a.normalize = normalize;
+        a.out = e->pooled; a.hidden = e->x;
+        hipLaunchKernelGGL(enc_pool_kernel<3>, dim3(ENC_BMAX), dim3(256), 0, s, a);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(e->h_out, e->pooled, (size_t)ENC_BMAX * H * sizeof(float), hipMemcpyDeviceToHost, s));
+    return ICD_OK;
+}
+
+inline void enc_free(icd_encoder *e) {
+    for (auto &b : e->exec) for (auto &p : b) for (auto &g : p) if (g) hipGraphExecDestroy(g);
+    for (float *p : {e->yb[0], e->yb[1], e->yb[2], e->x, e->qkv, e->ctx, e->mid, e->pooled, e->sA, e->sB}) if (p) hipFree(p);
+    if (e->d_meta) hipFree(e->d_meta);
+    if (e->stamps) hipFree(e->stamps);
+    if (e->h_meta) hipHostFree(e->h_meta);
+    if (e->h_out) hipHostFree(e->h_out);
+    if (e->ev_done) hipEventDestroy(e->ev_done);
+    if (e->cap_stream) hipStreamDestroy(e->cap_stream);
+    e->magic = 0;
+    delete e;
+}
+}  // namespace icd
+
+extern "C" {
+
+int icd_encoder_create(int32_t device, const icd_encoder_desc *desc, icd_encoder **out) {
+    using namespace icd;
+    if (!out) return fail(ICD_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!desc) return fail(ICD_ERR_INVALID, "desc is NULL");
+    const icd_encoder_desc &d = *desc;
+    if (d.layers < 1 || d.layers > 48) return fail(ICD_ERR_INVALID, "layers=%d", d.layers);
+    if (d.heads < 1 || d.hidden != d.heads * ATT_HEAD_DIM) return fail(ICD_ERR_UNSUPPORTED, "hidden=%d heads=%d (this encoder is written for 64-wide heads)", d.hidden, d.heads);
+    // enc_linear_kernel: K = 192 per wave, at most 16 waves; the LayerNorm kernels: 3 x 256 columns
+    if (d.hidden != 768) return fail(ICD_ERR_UNSUPPORTED, "hidden=%d (the small-input encoder is instantiated for 768)", d.hidden);
+    if (d.inter < 192 || d.inter % 192 != 0 || d.inter > 3072) return fail(ICD_ERR_UNSUPPORTED, "inter=%d (a multiple of 192, at most 3072)", d.inter);
+    if (d.vocab < 1 || d.max_pos < 1 || d.pos_offset < 0 || d.pos_offset >= d.max_pos) return fail(ICD_ERR_INVALID, "vocab=%d max_pos=%d pos_offset=%d", d.vocab, d.max_pos, d.pos_offset);
+    if (!(d.ln_eps > 0.0f)) return fail(ICD_ERR_INVALID, "ln_eps=%g", (double)d.ln_eps);
+    if (!d.word_emb || !d.pos_emb || !d.type_emb0 || !d.emb_ln_g || !d.emb_ln_b) return fail(ICD_ERR_INVALID, "an embedding pointer is NULL");
+    const float *const *arrs[12] = {d.w_qkv, d.b_qkv, d.w_ao, d.b_ao, d.ln1_g, d.ln1_b, d.w_up, d.b_up, d.w_down, d.b_down, d.ln2_g, d.ln2_b};
+    for (auto a : arrs) {
+        if (!a) return fail(ICD_ERR_INVALID, "a per-layer pointer array is NULL");
+        for (int l = 0; l < d.layers; ++l)
+            if (!a[l] || (reinterpret_cast<uintptr_t>(a[l]) & 15) != 0) return fail(ICD_ERR_INVALID, "layer %d: a weight pointer is NULL or not 16-byte aligned", l);
+    }
+    for (const float *p : {d.word_emb, d.pos_emb, d.type_emb0, d.emb_ln_g, d.emb_ln_b})
+        if ((reinterpret_cast<uintptr_t>(p) & 15) != 0) return fail(ICD_ERR_INVALID, "an embedding pointer is not 16-byte aligned");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(ICD_ERR_INVALID, "device=%d of %d", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    icd_encoder *e = new (std::nothrow) icd_encoder();
+    if (!e) return fail(ICD_ERR_NOMEM, "out of host memory");
+    e->magic = ENC_MAGIC; e->device = device; e->d = d;
+    auto keep = [&](std::vector<const float *> &v, const float *const *a) { v.assign(a, a + d.layers); };
+    keep(e->w_qkv, d.w_qkv); keep(e->b_qkv, d.b_qkv); keep(e->w_ao, d.w_ao); keep(e->b_ao, d.b_ao); keep(e->ln1_g, d.ln1_g); keep(e->ln1_b, d.ln1_b);
+    keep(e->w_up, d.w_up); keep(e->b_up, d.b_up); keep(e->w_down, d.w_down); keep(e->b_down, d.b_down); keep(e->ln2_g, d.ln2_g); keep(e->ln2_b, d.ln2_b);
+    e->d.w_qkv = e->d.b_qkv = e->d.w_ao = e->d.b_ao = e->d.ln1_g = e->d.ln1_b = e->d.w_up = e->d.b_up = e->d.w_down = e->d.b_down = e->d.ln2_g = e->d.ln2_b = nullptr;   // (the caller's arrays need not outlive this call)
+#define ENC_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { enc_free(e); return fail(e_ == hipErrorOutOfMemory ? ICD_ERR_NOMEM : ICD_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } } while (0)
+    const size_t H = (size_t)d.hidden, I = (size_t)d.inter, T = ENC_TMAX;
+    struct { float **p; size_t n; } bufs[] = {{&e->yb[0], T * H}, {&e->yb[1], T * H}, {&e->yb[2], T * H}, {&e->x, T * H}, {&e->qkv, T * 3 * H}, {&e->ctx, T * H},
+                                              {&e->mid, T * I}, {&e->pooled, (size_t)ENC_BMAX * H}, {&e->sA, 2 * T}, {&e->sB, 2 * T}};
+    for (auto &b : bufs) {
+        ENC_TRY(hipMalloc(reinterpret_cast<void **>(b.p), b.n * sizeof(float)));
+        ENC_TRY(hipMemset(*b.p, 0, b.n * sizeof(float)));   // (rows past a call's tokens are read by the last 16-token tile: finite, never stored)
+    }
+    ENC_TRY(hipMalloc(reinterpret_cast<void **>(&e->d_meta), ENC_META_WORDS * sizeof(int)));
+    ENC_TRY(hipMemset(e->d_meta, 0, ENC_META_WORDS * sizeof(int)));
+    ENC_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->h_meta), ENC_META_WORDS * sizeof(int), hipHostMallocDefault));
+    ENC_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->h_out), (size_t)ENC_BMAX * H * sizeof(float), hipHostMallocDefault));
+    memset(e->h_meta, 0, ENC_META_WORDS * sizeof(int));
+#ifdef ICD_ABLATE
+    if (getenv("ICD_ENC_STAMPS") && atoi(getenv("ICD_ENC_STAMPS")) == 1) {
+        ENC_TRY(hipMalloc(reinterpret_cast<void **>(&e->stamps), 64 * sizeof(unsigned long long)));
+        ENC_TRY(hipMemset(e->stamps, 0, 64 * sizeof(unsigned long long)));
+    }
+#endif
+    ENC_TRY(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+    ENC_TRY(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
+    ENC_TRY(hipDeviceSynchronize());
+#undef ENC_TRY
+    *out = e;
+    return ICD_OK;
+}
+
+#ifdef ICD_ABLATE
+// diagnostic builds: the 64 clock stamps of layer 6's four GEMMs (encoder_small.hpp ENC_STAMP), after a synchronisation
+int icd_debug_encoder_stamps(icd_encoder *e, unsigned long long *out) {
+    if (!icd::enc_valid(e) || !e->stamps || !out) return fail(ICD_ERR_STATE, "no stamps (ICD_ENC_STAMPS=1 at create, ABLATE build)");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, e->stamps, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return ICD_OK;
+}
+#endif
+
+int icd_encoder_destroy(icd_encoder *e) {
+    if (!icd::enc_valid(e)) return fail(ICD_ERR_STATE, "invalid encoder handle");
+    hipSetDevice(e->device);
+    hipDeviceSynchronize();
+    icd::enc_free(e);
+    return ICD_OK;
+}
+
+int icd_encoder_encode(icd_encoder *e, const int32_t *ids, const int32_t *lengths, int32_t nseq, int32_t pooling, int32_t normalize,
+                       float *out, int32_t out_on_device, float *hidden_out, void *stream) {
+    using namespace icd;
+    if (!enc_valid(e)) return fail(ICD_ERR_STATE, "invalid encoder handle");
+    std::lock_guard<std::mutex> guard(e->mu);
+    if (nseq < 0 || nseq > ENC_BMAX) return fail(ICD_ERR_INVALID, "nseq=%d (at most %d sequences per call)", nseq, ENC_BMAX);
+    if (nseq == 0) return ICD_OK;
+    if (!ids || !lengths || !out) return fail(ICD_ERR_INVALID, "pointer is NULL");
+    if ((pooling != 0 && pooling != 1) || (normalize != 0 && normalize != 1)) return fail(ICD_ERR_INVALID, "pooling=%d normalize=%d", pooling, normalize);
+    const icd_encoder_desc &d = e->d;
+    int T = 0;
+    for (int b = 0; b < nseq; ++b) {
+        if (lengths[b] < 1 || lengths[b] > d.max_pos - d.pos_offset) return fail(ICD_ERR_INVALID, "sequence %d: %d tokens (1 .. %d)", b, lengths[b], d.max_pos - d.pos_offset);
+        T += lengths[b];
+        if (T > ENC_TMAX) return fail(ICD_ERR_INVALID, "more than %d tokens per call", ENC_TMAX);
+    }
+    for (int t = 0; t < T; ++t)
+        if (ids[t] < 0 || ids[t] >= d.vocab) return fail(ICD_ERR_INVALID, "token %d: id %d outside the vocabulary of %d", t, ids[t], d.vocab);
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = s != nullptr && hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
+    if (capturing && !out_on_device) return fail(ICD_ERR_INVALID, "a call with a host output synchronises: it cannot be captured into a graph");
+    if (capturing) return fail(ICD_ERR_UNSUPPORTED, "icd_encoder_encode reads its token ids from host memory at call time: it cannot be captured into a graph");
+    // the previous launch's copy node may not have read h_meta yet (device outputs: the call did not wait)
+    if (e->ev_pending) { HIP_TRY(hipEventSynchronize(e->ev_done)); e->ev_pending = false; }
+    int *m = e->h_meta;
+    m[0] = T; m[1] = nseq;
+    int t = 0;
+    for (int b = 0; b < nseq; ++b) {
+        m[ENC_META_STARTS + b] = t;
+        for (int i = 0; i < lengths[b]; ++i, ++t) { m[ENC_META_IDS + t] = ids[t]; m[ENC_META_POS + t] = d.pos_offset + i; m[ENC_META_SEQ + t] = b; }
+    }
+    for (int b = nseq; b <= ENC_BMAX; ++b) m[ENC_META_STARTS + b] = T;
+    const int bi = T <= 16 ? 0 : (T <= 32 ? 1 : (T <= 64 ? 2 : 3));
+    const int bucket = 16 << bi;
+    hipGraphExec_t &gx = e->exec[bi][pooling][normalize];
+    if (!gx) {
+        hipGraph_t g = nullptr;
+        HIP_TRY(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
+        const int rc = enc_enqueue(e, bucket, pooling, normalize, e->cap_stream);
+        const hipError_t ec = hipStreamEndCapture(e->cap_stream, &g);
+        if (rc) { if (g) hipGraphDestroy(g); return rc; }
+        HIP_TRY(ec);
+        const hipError_t ei = hipGraphInstantiate(&gx, g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (ei != hipSuccess) { gx = nullptr; return fail(ICD_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ei)); }
+    }
+    HIP_TRY(hipGraphLaunch(gx, s));
+    const size_t H = (size_t)d.hidden;
+    if (hidden_out) HIP_TRY(hipMemcpyAsync(hidden_out, e->x, (size_t)T * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (out_on_device) {
+        HIP_TRY(hipMemcpyAsync(out, e->pooled, (size_t)nseq * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipEventRecord(e->ev_done, s));
+        e->ev_pending = true;
+        return ICD_OK;
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    memcpy(out, e->h_out, (size_t)nseq * H * sizeof(float));
+    return ICD_OK;
+}
+
+}  // extern "C"

@@ -12,6 +12,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/icd_search.h"
 #include "coarse_flat_kernel.hpp"
@@ -1786,3 +1787,6 @@ int icd_index_last_profile(icd_index *idx, icd_profile *out) {
 }
 
 }  // extern "C"
+
+// the small-input sentence encoder (icd_encoder_*): its own file, this translation unit (fail(), HIP_TRY, packed_attention_kernel)
+#include "icd_encoder.hpp"

@@ -406,6 +406,17 @@ class EmbeddingService:
         # large batches: the encoder over packed tokens (ICD_EMBEDDING_PACKED=0: the padded HF forward everywhere)
         self._packed = (_PackedBert(self.model.bert) if os.getenv("ICD_EMBEDDING_PACKED", "1") == "1" and _PackedBert.supported(self.model.bert)
                         else None)
+        # ONE string per call (the reference's encode_query / encode_single, :97-120) or a request's handful: the hand-written
+        # small-input forward, one graph launch (csrc/encoder_small.hpp through the C ABI; ICD_EMBEDDING_SMALL=0: the replayed
+        # graph of the framework's forward). fp32 BERT-base shapes on a GPU only; anything else keeps the paths below.
+        self._small = None
+        if os.getenv("ICD_EMBEDDING_SMALL", "1") == "1" and str(self.device).startswith("cuda") and dtype == torch.float32:
+            try:
+                from .. import _native
+                if _native.SmallEncoder.supported(self.model.bert):
+                    self._small = _native.SmallEncoder(self.model.bert)
+            except Exception as exc:   # (a CPU-only install, an unsupported architecture: the framework's forward stays)
+                logger.info("small-input encoder unavailable (%s): the framework's forward", exc)
 
     # ---- text preparation (reference :68-73) ------------------------------------------------------------
     def _prepare_text_for_embedding(self, text: str) -> str:
@@ -427,6 +438,8 @@ class EmbeddingService:
         if n == 0:
             return out if to_device else out.cpu().numpy()
         ids = self._tokenize(texts)
+        if self._small is not None and self._small.fits([len(x) for x in ids]):
+            return self._small.encode(ids, pooling=self.pooling, normalize=True, to_device=to_device)
         order = sorted(range(n), key=lambda i: -len(ids[i]))  # length buckets: least padding per batch
         if self._packed is not None and batch_size > self._GRAPH_BATCHES[-1] and n > self._GRAPH_BATCHES[-1]:
             # chunks of at most PACK_TOKENS tokens (activation memory: ~40 KB per token in fp32), longest strings first

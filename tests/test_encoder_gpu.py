@@ -42,9 +42,80 @@ def test_encode_query_graph_bucket_matches_cpu(services):
         assert a.shape == (768,) and a.dtype == np.float32
         assert np.max(np.abs(a - b)) <= TOL, t
         assert abs(np.linalg.norm(a) - 1.0) <= 1e-5
-    assert gpu._graphs, "the one-string path should have captured a HIP graph"
+    assert gpu._small is not None, "one string per call should take the small-input encoder (csrc/encoder_small.hpp)"
     again = gpu.encode_query(_strings()[3])                                # a replay gives the same bits as the first replay
     assert np.array_equal(again, gpu.encode_query(_strings()[3]))
+
+
+def test_encode_query_through_the_replayed_framework_graph_matches_cpu(services, monkeypatch):
+    """ICD_EMBEDDING_SMALL=0 (and batches of <= 32 strings with more than 128 tokens in all): the framework's forward,
+    replayed from a HIP graph per (batch, width) bucket"""
+    gpu, cpu = services
+    monkeypatch.setattr(gpu, "_small", None)
+    for t in _strings()[:12] + _strings()[-6:]:
+        a, b = gpu.encode_query(t), cpu.encode_query(t)
+        assert np.max(np.abs(a - b)) <= TOL, t
+    assert gpu._graphs, "the one-string path should have captured a HIP graph"
+    texts = _strings()[:20]                                                 # 20 strings, > 128 tokens: the graph buckets with the small encoder ON
+    monkeypatch.undo()
+    assert sum(len(x) for x in gpu._tokenize([f"query: {t}" for t in texts])) > 128
+    a, b = gpu.encode_query_batch(texts, batch_size=32), cpu.encode_query_batch(texts, batch_size=32)
+    assert np.max(np.abs(a - b)) <= TOL
+
+
+def test_small_input_encoder_matches_the_framework_forward(services):
+    """csrc/encoder_small.hpp through icd_encoder_encode: 1 ... 32 sequences, 1 ... 128 packed tokens, every token bucket and
+    its edges - pooled rows (mean and [CLS], normalised or not) and the last hidden state of every token against
+    transformers' padded BertModel forward of the same weights on the GPU (1e-5); host and device outputs identical; the
+    descriptor's limits refused with a clear error."""
+    import torch
+    from rag_project_icd10_amd import _native
+    gpu, _ = services
+    enc = gpu._small
+    assert enc is not None
+    rng = np.random.default_rng(5)
+    vocab = gpu.model.bert.config.vocab_size
+
+    def make(lengths):
+        return [[101] + [int(v) for v in rng.integers(1000, vocab, size=n - 2)] + [102] if n >= 2 else [101] for n in lengths]
+
+    def reference(ids, pooling):
+        width = max(len(x) for x in ids)
+        tok = torch.zeros((len(ids), width), dtype=torch.long)
+        mask = torch.zeros((len(ids), width), dtype=torch.long)
+        for r, x in enumerate(ids):
+            tok[r, :len(x)] = torch.tensor(x)
+            mask[r, :len(x)] = 1
+        tok, mask = tok.cuda(), mask.cuda()
+        with torch.no_grad():
+            hidden = gpu.model.bert(input_ids=tok, attention_mask=mask).last_hidden_state
+        m = mask.unsqueeze(-1).float()
+        pooled = hidden[:, 0] if pooling == "cls" else (hidden * m).sum(1) / m.sum(1)
+        rows = torch.cat([hidden[r, :len(x)] for r, x in enumerate(ids)], 0)
+        return pooled.cpu().numpy(), torch.nn.functional.normalize(pooled, p=2, dim=1).cpu().numpy(), rows.cpu().numpy()
+
+    cases = [[1], [2], [3], [15], [16], [17], [31], [32], [33], [64], [65], [100], [128], [5, 9, 12, 30], [4] * 32, [1] * 32, [64, 64],
+             [17, 1, 40, 2, 23], [16, 16], [7] * 18, [100, 28]]
+    for lengths in cases:
+        ids = make(lengths)
+        for pooling in ("mean", "cls"):
+            want_raw, want_unit, want_rows = reference(ids, pooling)
+            got_unit, rows = enc.encode(ids, pooling=pooling, normalize=True, hidden=True)
+            got_raw = enc.encode(ids, pooling=pooling, normalize=False)
+            assert got_unit.shape == (len(ids), 768) and got_unit.dtype == np.float32
+            assert np.max(np.abs(got_unit - want_unit)) <= TOL, (lengths, pooling)
+            assert np.max(np.abs(got_raw - want_raw)) <= 2e-5, (lengths, pooling)     # (un-normalised rows have norm ~ 10-20)
+            assert np.max(np.abs(rows.cpu().numpy() - want_rows)) <= 5e-5, (lengths, pooling)
+            dev = enc.encode(ids, pooling=pooling, normalize=True, to_device=True)
+            torch.cuda.synchronize()
+            assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), got_unit)
+    with pytest.raises(_native.IcdError, match="128 tokens"):
+        enc.encode(make([100, 29]))
+    with pytest.raises(_native.IcdError, match="sequences per call"):
+        enc.encode(make([2] * 33))
+    with pytest.raises(_native.IcdError, match="vocabulary"):
+        enc.encode([[101, vocab, 102]])
+    assert not enc.fits([100, 29]) and not enc.fits([2] * 33) and enc.fits([128]) and not enc.fits([])
 
 
 def test_encode_batch_32_matches_cpu(services):
