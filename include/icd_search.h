@@ -339,11 +339,13 @@ int icd_debug_unpack_query_slices(int32_t device, const void *gathered, int32_t 
  * (services/embedding_service.py:97-102, 117-120) - and a /query request a handful (services/multi_diagnosis_service.py:97,
  * 137). At 10-100 tokens the framework's forward is ~220 kernels of ~5 us (1.1 ms replayed from a graph); this is the same
  * BERT forward (post-LN encoder, absolute positions, erf-GELU, 64-wide heads, fp32) as 7 hand-written launches per layer
- * (csrc/encoder_small.hpp), replayed as ONE graph per token bucket. The weights stay where the caller keeps them (device
- * fp32, e.g. the torch module's parameters): the handle borrows the pointers, the caller keeps them alive and unchanged. */
+ * (csrc/encoder_small.hpp), replayed as ONE graph per token bucket. All pointers are device fp32 (e.g. the torch module's
+ * parameters). icd_encoder_create COPIES the four Linear weights of every layer (into the order its GEMMs read them: the
+ * caller's may be freed or changed afterwards without effect) and BORROWS the embeddings, biases and LayerNorm parameters:
+ * the caller keeps those alive and unchanged while the handle lives. */
 typedef struct icd_encoder icd_encoder;
 typedef struct {
-    int32_t layers, hidden, heads, inter;   /* hidden = heads * 64; hidden and inter multiples of 192 (<= 3072) and hidden of 256 */
+    int32_t layers, hidden, heads, inter;   /* hidden = heads * 64 = 768; inter a multiple of 768, at most 3072 */
     int32_t vocab, max_pos;                 /* rows of word_emb / pos_emb */
     int32_t pos_offset;                     /* position of a sequence's first token: 0 (BERT), padding_idx + 1 (RoBERTa / XLM-R) */
     float ln_eps;

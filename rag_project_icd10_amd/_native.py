@@ -553,8 +553,9 @@ class SmallEncoder:
     SentenceTransformer.encode call of EmbeddingService.encode_query / encode_single (reference
     services/embedding_service.py:97-102,117-120) for one string or a request's handful.
 
-    Built from a transformers BertModel-like module on a CUDA device with fp32 parameters; the handle BORROWS the parameter
-    storage (this object keeps the tensors alive; do not modify them while it lives)."""
+    Built from a transformers BertModel-like module on a CUDA device with fp32 parameters. The handle COPIES the four Linear
+    weights of every layer at creation (into the order its GEMMs read them) and BORROWS embeddings, biases and LayerNorm
+    parameters (this object keeps those tensors alive): rebuild it after changing the module's parameters."""
 
     @staticmethod
     def supported(bert) -> bool:
@@ -565,7 +566,7 @@ class SmallEncoder:
             return (type(bert).__name__ in ("BertModel", "XLMRobertaModel", "RobertaModel") and p.is_cuda and p.dtype == torch.float32
                     and getattr(cfg, "position_embedding_type", None) in (None, "absolute") and getattr(cfg, "hidden_act", "gelu") == "gelu"
                     and not getattr(cfg, "is_decoder", False) and int(cfg.hidden_size) == 768 and int(cfg.hidden_size) // int(cfg.num_attention_heads) == 64
-                    and int(cfg.intermediate_size) % 192 == 0 and int(cfg.intermediate_size) <= 3072)
+                    and int(cfg.intermediate_size) % 768 == 0 and int(cfg.intermediate_size) <= 3072)
         except Exception:
             return False
 
@@ -594,9 +595,12 @@ class SmallEncoder:
         d.type_emb0 = ptr(emb.token_type_embeddings.weight[0])
         d.emb_ln_g, d.emb_ln_b = ptr(emb.LayerNorm.weight), ptr(emb.LayerNorm.bias)
         per = {name: [] for name in _ENC_LAYER_FIELDS}
+        scratch = []
         for l in bert.encoder.layer:
             a = l.attention.self
-            per["w_qkv"].append(ptr(torch.cat([a.query.weight, a.key.weight, a.value.weight], 0)))
+            wqkv = torch.cat([a.query.weight, a.key.weight, a.value.weight], 0).detach().contiguous()   # (copied by the handle at create: not kept)
+            scratch.append(wqkv)
+            per["w_qkv"].append(wqkv.data_ptr())
             per["b_qkv"].append(ptr(torch.cat([a.query.bias, a.key.bias, a.value.bias], 0)))
             per["w_ao"].append(ptr(l.attention.output.dense.weight)); per["b_ao"].append(ptr(l.attention.output.dense.bias))
             per["ln1_g"].append(ptr(l.attention.output.LayerNorm.weight)); per["ln1_b"].append(ptr(l.attention.output.LayerNorm.bias))
@@ -609,7 +613,8 @@ class SmallEncoder:
             setattr(d, name, C.cast(arrays[name], C.POINTER(C.c_void_p)))
         self._keep = keep
         h = C.c_void_p()
-        _check(self._lib, self._lib.icd_encoder_create(self.device, C.byref(d), C.byref(h)))
+        _check(self._lib, self._lib.icd_encoder_create(self.device, C.byref(d), C.byref(h)))   # (synchronises: the weight copies are done)
+        del scratch
         self._h = h
 
     def fits(self, lengths) -> bool:

@@ -16,9 +16,11 @@
 //                       v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate: exact products; the sum's order differs from the
 //                       vendor GEMM's like any two GEMMs differ); the waves' partial sums meet in LDS, where bias and
 //                       erf-GELU are applied.
-//       LNPRO           A = LayerNorm(X) computed by the work-group itself (its waves hold whole rows between them: two
-//                       reductions through LDS, mean then centred squares): the QKV and FFN-up GEMMs read the PRE-norm sums
-//                       of the previous sublayer. Work-group 0 leaves mean and 1/std per token for ...
+//       LNPRO           A = LayerNorm(X) without touching X: LN(x) W^T + b = rstd (x (W diag g)^T - mean c1) + c2 with c1, c2
+//                       and W diag(g) made once (enc_fold_ln_kernel). The MFMAs run on the PRE-norm rows of the previous
+//                       sublayer the moment they land; mean and 1/std of a row come from the same registers (the work-group's
+//                       waves hold whole rows between them), VALU work beside the MFMAs, and meet the sums behind the ONE
+//                       barrier of the kernel. Work-group 0 leaves the two numbers per token for ...
 //       EPI == 2        ... the residual of the next GEMM (BertSelfOutput / BertOutput: dense(x) + LayerNorm-ed input),
 //                       rebuilt from the pre-norm row and those two numbers. No normalised activation is ever stored.
 //   enc_attention_kernel  softmax(q K^T / 8) V, one wave per (token, head): K rows and V columns of the sequence in
@@ -39,12 +41,61 @@ namespace icd {
 
 constexpr int ENC_TMAX = 128;   // packed tokens per call
 constexpr int ENC_BMAX = 32;    // sequences per call
-// descriptor (int32 words): [0] T, [1] B, then TMAX token ids, TMAX positions, TMAX sequence-of-token, BMAX + 1 sequence
-// starts (starts[b] = T for b >= B)
-constexpr int ENC_META_IDS = 2, ENC_META_POS = 2 + ENC_TMAX, ENC_META_SEQ = 2 + 2 * ENC_TMAX, ENC_META_STARTS = 2 + 3 * ENC_TMAX;
+// descriptor (int32 words): [0] T, [1] B, then per token (TMAX each): id, position, first row of its sequence, length of its
+// sequence (0 past the call's tokens), then BMAX + 1 sequence starts (starts[b] = T for b >= B)
+constexpr int ENC_META_IDS = 2, ENC_META_POS = 2 + ENC_TMAX, ENC_META_TOK_R0 = 2 + 2 * ENC_TMAX, ENC_META_TOK_LEN = 2 + 3 * ENC_TMAX;
+constexpr int ENC_META_STARTS = 2 + 4 * ENC_TMAX;
 constexpr int ENC_META_WORDS = ENC_META_STARTS + ENC_BMAX + 1;
 
 typedef float enc_f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- operand layouts -----------------------------------------------------------------------------------------------------
+// v_mfma_f32_16x16x4_f32 wants element [row r][k] of its A (and column r of its B) operand in lane (r, kq = k & 3 of the
+// step). A wave that loads those straight from a row-major matrix touches 16 rows x 64 B per instruction: 16 half cache
+// lines, ~40 cycles of the CU's address unit each - 24 such loads per wave were 2.2 of a GEMM kernel's 7.7 us (clock stamps,
+// profiles/r05_encoder_small.log). So every matrix a GEMM reads is STORED in the order its loads want it:
+//   activations [T][K] (K = 192 x waves): element (t, k) at ((((t / 16 * K / 192 + w) * 12 + i) * 4 + kq) * 16 + t % 16) * 4 + c
+//       with w = k / 192, i = k % 192 / 16, kq = k % 16 / 4, c = k % 4
+//       - lane (r, kq) of wave w reads step i of token tile t / 16 at  base + (i * 64 + lane) * 16 bytes: ONE KB, contiguous;
+//   weights [N][K] in tiles of NT rows: the same with NT in place of 16 and the row tile n / NT in place of t / 16.
+// Producers (the embedding sum, the GEMM epilogues, the attention) scatter their few values per thread into that order.
+__host__ __device__ __forceinline__ size_t enc_pa(int t, int k, int K) {
+    const int w = k / 192, kk = k - w * 192;
+    return ((((size_t)(t >> 4) * (K / 192) + w) * 12 + (kk >> 4)) * 4 + ((kk >> 2) & 3)) * 64 + (size_t)(t & 15) * 4 + (kk & 3);
+}
+__host__ __device__ __forceinline__ size_t enc_pw(int n, int k, int K, int NT) {
+    const int w = k / 192, kk = k - w * 192;
+    return ((((size_t)(n / NT) * (K / 192) + w) * 12 + (kk >> 4)) * 4 + ((kk >> 2) & 3)) * (size_t)(NT * 4) + (size_t)(n % NT) * 4 + (kk & 3);
+}
+
+// one-time: a torch.nn.Linear weight [N][K] row-major -> the NT-row-tile order above (16 bytes per thread), its columns
+// optionally scaled by a LayerNorm weight (LNPRO below: W' = W diag(g))
+__global__ __launch_bounds__(256) void enc_permute_w_kernel(const float *src, const float *colscale, float *dst, int N, int K, int NT) {
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;   // float4 index in the source
+    if (g >= (size_t)N * K / 4) return;
+    const int n = (int)(g / (K / 4)), k = (int)(g % (K / 4)) * 4;
+    float4 v = *reinterpret_cast<const float4 *>(src + (size_t)n * K + k);
+    if (colscale) {
+        const float4 sc = *reinterpret_cast<const float4 *>(colscale + k);
+        v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+    }
+    *reinterpret_cast<float4 *>(dst + enc_pw(n, k, K, NT)) = v;
+}
+// one-time, for a Linear that reads a LayerNorm's output, LN(x) W^T + bias = rstd (x (W diag g)^T - mean c1) + c2 with
+//   c1[n] = sum_k g[k] W[n][k]        c2[n] = sum_k b[k] W[n][k] + bias[n]          (sums in double); one wave per n
+__global__ __launch_bounds__(256) void enc_fold_ln_kernel(const float *w, const float *g, const float *b, const float *bias, float *c1, float *c2, int N, int K) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = lane; k < K; k += 64) {
+        const double wv = (double)w[(size_t)n * K + k];
+        s1 += (double)g[k] * wv;
+        s2 += (double)b[k] * wv;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+    if (lane == 0) { c1[n] = (float)s1; c2[n] = (float)(s2 + (double)bias[n]); }
+}
 
 __device__ __forceinline__ float enc_wave_sum(float v) {
 #pragma unroll
@@ -56,7 +107,7 @@ struct EncEmbedArgs {
     const int *meta;
     const float *word, *pos, *type0;   // embeddings [vocab][H], [max_pos][H], token type 0 [H]
     int H;
-    float *y;   // [TMAX][H] pre-norm
+    float *y;   // [TMAX][H] pre-norm, operand order
 };
 // y[t] = (word[id] + type0) + pos[p] (BertEmbeddings in front of its LayerNorm): one wave per token
 template <int NV>
@@ -72,26 +123,34 @@ __global__ __launch_bounds__(256) void enc_embed_kernel(EncEmbedArgs a) {
         const float4 pe = *reinterpret_cast<const float4 *>(a.pos + p * a.H + c);
         float4 v;
         v.x = (w.x + ty.x) + pe.x; v.y = (w.y + ty.y) + pe.y; v.z = (w.z + ty.z) + pe.z; v.w = (w.w + ty.w) + pe.w;
-        *reinterpret_cast<float4 *>(a.y + (size_t)t * a.H + c) = v;
+        *reinterpret_cast<float4 *>(a.y + enc_pa(t, c, a.H)) = v;
     }
 }
 
 struct EncLinearArgs {
     const int *meta;
-    const float *x;        // [TMAX][K]: the A operand, or (LNPRO) the pre-norm rows it is the LayerNorm of
-    const float *ln_g, *ln_b;   // LNPRO: that LayerNorm (over K)
-    float ln_eps;
+    const float *x;        // [TMAX][K] operand order: the A operand, or (LNPRO) the pre-norm rows it is the LayerNorm of
+    float ln_eps;          // LNPRO: the LayerNorm's epsilon; its weight and bias are folded into w / c1 / c2 (enc_fold_ln_kernel)
+    const float *c1;       // LNPRO: [N]
     float *stats_out;      // LNPRO: [TMAX][2] mean, 1 / sqrt(var + eps) of every token (written by work-group 0)
-    const float *w;        // [N][K] (torch.nn.Linear.weight)
-    const float *bias;     // [N]
+    const float *w;        // [N][K] in NT-row tiles (enc_pw); LNPRO: its columns scaled by the LayerNorm weight
+    const float *bias;     // [N]; LNPRO: c2
     // EPI == 2: + LayerNorm(res_src)[t][n], rebuilt from the pre-norm row and the statistics a LNPRO kernel left
-    const float *res_src;  // [TMAX][N]
+    const float *res_src;  // [TMAX][N] operand order
     const float *res_stats, *res_g, *res_b;
-    float *y;              // [TMAX][N]
+    float *y;              // [TMAX][N]: operand order (OUT_PA) or row-major
     int K, N;
+    // K split over work-groups (the FFN-down GEMM: K = 3072 in four work-groups of four waves): work-group b takes output tile
+    // b / (nwk / waves) and K slice b % (nwk / waves) and writes its partial sums to slab `slice` of y; bias and residual go
+    // into slab 0. Whoever reads such a matrix adds the slabs up (NSLAB below, res_nslab, EncPoolArgs::nslab): a split
+    // costs its readers three more loads per value and no launch, no atomics, no second pass.
+    int nwk;               // waves over the whole K (K / 192)
+    long long slab;        // floats between the slabs of x / res_src / y
+    int res_nslab;         // slabs of res_src
     unsigned long long *stamps;   // diagnostic builds (ICD_ABLATE): 8 x (s_memtime, s_memrealtime) of wave 0 of work-group 1; nullptr = none
 };
 #ifdef ICD_ABLATE
+__device__ unsigned long long g_enc_first[8];   // diagnostic: clocks at the first instruction of a wave (no kernel argument has been read yet)
 #define ENC_STAMP(i) do { if (a.stamps && blockIdx.x == 1 && tid == 0) { __builtin_amdgcn_sched_barrier(0); \
     a.stamps[2 * (i)] = __builtin_amdgcn_s_memtime(); a.stamps[2 * (i) + 1] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #define ENC_STAMP_DRAIN() do { if (a.stamps) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); } while (0)
@@ -99,53 +158,76 @@ struct EncLinearArgs {
 #define ENC_STAMP(i) do { } while (0)
 #define ENC_STAMP_DRAIN() do { } while (0)
 #endif
-// ITER: 16-column k-steps per wave (K = 16 ITER x waves); NT: output columns per work-group (grid = N / NT);
-// EPI: 0 bias, 1 bias + erf-GELU (BertIntermediate), 2 bias + LayerNorm-ed residual
-template <int ITER, int NT, int EPI, bool LNPRO>
-__global__ __launch_bounds__(LNPRO ? 256 : 1024) void enc_linear_kernel(EncLinearArgs a) {
+// NT: output columns per work-group (grid = N / NT); a wave takes 192 columns of K (12 k-steps of 16), the block has K / 192 waves
+// (at most MAXW: 4 waves keep 512 registers each - the next token tile's operand rows are prefetched into them -, 16 keep 128);
+// EPI: 0 bias, 1 bias + erf-GELU (BertIntermediate), 2 bias + LayerNorm-ed residual; OUT_PA: y in operand order
+// NSLAB: the A operand is the sum of this many slabs
+template <int NT, int EPI, bool LNPRO, bool OUT_PA, int MAXW, int NSLAB>
+__global__ __launch_bounds__(MAXW * 64) void enc_linear_kernel(EncLinearArgs a) {
+    constexpr bool PREFETCH = MAXW <= 4 && NSLAB == 1;
     static_assert(NT == 16 || NT == 8 || NT == 4, "columns per work-group");
+    constexpr int ITER = 12;
     __shared__ float red[16][256];
-    __shared__ float lnred[2][16][16];   // LNPRO: per wave and row, sum and centred sum of squares
+    __shared__ float lnred[2][16][16];   // LNPRO: per wave and row, the slice's mean and centred sum of squares
     const int tid = threadIdx.x, lane = tid & 63;
+#ifdef ICD_ABLATE
+    if (blockIdx.x == 1 && tid == 0) {
+        const int slot = (NT == 16 ? (EPI == 0 ? 0 : 2) : (NT == 8 ? 1 : 3)) * 2;
+        g_enc_first[slot] = __builtin_amdgcn_s_memtime(); g_enc_first[slot + 1] = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = (int)blockDim.x >> 6;
     ENC_STAMP(0);
-    const int n0 = blockIdx.x * NT;
+    const int ksn = a.nwk / nw;                                   // K slices (1: the work-group's waves cover K)
+    const int ntile = (int)blockIdx.x / ksn, ks = (int)blockIdx.x - ntile * ksn;
+    const int kw = ks * nw + wave;                                // this wave's 192 columns of K
+    const int n0 = ntile * NT;
     const int r16 = lane & 15, kq = lane >> 4;
-    const int kbase = wave * (16 * ITER) + 4 * kq;
     // ---- everything this wave will read, issued before anything waits ------------------------------------------------------
     float4 wreg[ITER];   // W rows n0 .. n0 + NT - 1 (lanes r16 >= NT: zero columns of the MFMA's B operand)
     {
-        const float *wp = a.w + (size_t)(n0 + (r16 < NT ? r16 : 0)) * a.K + kbase;
+        const float *wp = a.w + (((size_t)ntile * a.nwk + kw) * ITER * 4 + kq) * (NT * 4) + (size_t)(r16 < NT ? r16 : 0) * 4;
 #pragma unroll
         for (int i = 0; i < ITER; ++i) {
-            const float4 v = *reinterpret_cast<const float4 *>(wp + 16 * i);
+            const float4 v = *reinterpret_cast<const float4 *>(wp + (size_t)i * (4 * NT * 4));
             wreg[i] = r16 < NT ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     float4 areg[ITER];   // rows t0 .. t0 + 15 of the operand (rows past T inside the last tile: finite stale values, never stored)
-    {
-        const float *xp = a.x + (size_t)r16 * a.K + kbase;
+    auto load_tile = [&](float4 (&dst)[ITER], int tile) {
+        const float *xp = a.x + (((size_t)tile * a.nwk + kw) * ITER * 64 + lane) * 4;
 #pragma unroll
-        for (int i = 0; i < ITER; ++i) areg[i] = *reinterpret_cast<const float4 *>(xp + 16 * i);
-    }
-    float4 greg[LNPRO ? ITER : 1], breg[LNPRO ? ITER : 1];
-    if constexpr (LNPRO) {
+        for (int i = 0; i < ITER; ++i) dst[i] = *reinterpret_cast<const float4 *>(xp + (size_t)i * 256);
+        if constexpr (NSLAB > 1) {
 #pragma unroll
-        for (int i = 0; i < ITER; ++i) {
-            greg[i] = *reinterpret_cast<const float4 *>(a.ln_g + kbase + 16 * i);
-            breg[i] = *reinterpret_cast<const float4 *>(a.ln_b + kbase + 16 * i);
+            for (int sl = 1; sl < NSLAB; ++sl) {
+#pragma unroll
+                for (int i = 0; i < ITER; ++i) {
+                    const float4 v = *reinterpret_cast<const float4 *>(xp + (size_t)sl * a.slab + (size_t)i * 256);
+                    dst[i].x += v.x; dst[i].y += v.y; dst[i].z += v.z; dst[i].w += v.w;
+                }
+            }
         }
-    }
+    };
+    auto load_res = [&](int t, float &src, float &mean, float &rstd) {   // residual operands of (token t, this thread's column)
+        const size_t idx = enc_pa(t, n0 + (tid & 15), a.N);
+        float v = a.res_src[idx];
+        for (int sl = 1; sl < a.res_nslab; ++sl) v += a.res_src[idx + (size_t)sl * a.slab];
+        src = v; mean = a.res_stats[2 * t]; rstd = a.res_stats[2 * t + 1];
+    };
+    load_tile(areg, 0);
     // the epilogue's operands of thread tid < 256: output (token 4 (l >> 4) + j, column l & 15), l = tid & 63, j = tid >> 6
     const int ej = tid >> 6, el = tid & 63;
     const int en = el & 15, et = 4 * (el >> 4) + ej;
     const bool ecol = tid < 256 && en < NT;
-    float bias_v = 0.f, rg = 0.f, rb = 0.f, rsrc = 0.f, rmean = 0.f, rrstd = 0.f;
+    float bias_v = 0.f, c1_v = 0.f, rg = 0.f, rb = 0.f, rsrc = 0.f, rmean = 0.f, rrstd = 0.f;
     if (ecol) {
         bias_v = a.bias[n0 + en];
+        if constexpr (LNPRO) c1_v = a.c1[n0 + en];
         if constexpr (EPI == 2) {
             rg = a.res_g[n0 + en]; rb = a.res_b[n0 + en];
-            rsrc = a.res_src[(size_t)et * a.N + n0 + en]; rmean = a.res_stats[2 * et]; rrstd = a.res_stats[2 * et + 1];   // (tile 0)
+            load_res(et, rsrc, rmean, rrstd);   // (tile 0)
         }
     }
     const int T = a.meta[0];
@@ -155,172 +237,194 @@ __global__ __launch_bounds__(LNPRO ? 256 : 1024) void enc_linear_kernel(EncLinea
     ENC_STAMP(2);        // loads landed
 
     for (int t0 = 0; t0 < T; t0 += 16) {
-        if (t0 > 0) {
-            const float *xp = a.x + (size_t)(t0 + r16) * a.K + kbase;
-#pragma unroll
-            for (int i = 0; i < ITER; ++i) areg[i] = *reinterpret_cast<const float4 *>(xp + 16 * i);
-            if constexpr (EPI == 2) {
-                if (ecol) { rsrc = a.res_src[(size_t)(t0 + et) * a.N + n0 + en]; rmean = a.res_stats[2 * (t0 + et)]; rrstd = a.res_stats[2 * (t0 + et) + 1]; }
+        // the NEXT tile's operand rows travel while this one is worked on
+        float4 anext[ITER];   // (PREFETCH only)
+        float rsrc_n = 0.f, rmean_n = 0.f, rrstd_n = 0.f;
+        const bool more = t0 + 16 < T;   // (work-group-uniform)
+        if constexpr (PREFETCH) {
+            if (more) {
+                load_tile(anext, (t0 >> 4) + 1);
+                if constexpr (EPI == 2) {
+                    if (ecol) load_res(t0 + 16 + et, rsrc_n, rmean_n, rrstd_n);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
+        enc_f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};   // (two chains: a dependent MFMA waits out the one before it)
+#pragma unroll
+        for (int i = 0; i < ITER; i += 2) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i].x, wreg[i].x, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i + 1].x, wreg[i + 1].x, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i].y, wreg[i].y, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i + 1].y, wreg[i + 1].y, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i].z, wreg[i].z, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i + 1].z, wreg[i + 1].z, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i].w, wreg[i].w, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i + 1].w, wreg[i + 1].w, c1, 0, 0, 0);
+        }
+        float mw = 0.f, qw = 0.f;
         if constexpr (LNPRO) {
-            // the work-group's waves hold rows t0 .. t0 + 15 whole between them: lane (r16, kq) of wave w has 4 ITER values of row r16
-            float s = 0.f;
+            // LayerNorm without touching the operand: the MFMAs above ran on the RAW rows against W diag(g); what is left is
+            // rstd (acc - mean c1) + c2 per output (epilogue). The statistics: the work-group's waves hold rows t0 .. t0 + 15
+            // whole between them (lane (r16, kq) of wave w: 48 values of row r16); every wave reduces ITS 192 columns of a row
+            // to (mean, centred sum of squares) - two passes over registers, VALU work that runs beside the MFMAs - and the
+            // pairs are combined behind the barrier the partial sums need anyway.
+            float sm = 0.f;
 #pragma unroll
-            for (int i = 0; i < ITER; ++i) s += (areg[i].x + areg[i].y) + (areg[i].z + areg[i].w);
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            if (t0 > 0) __syncthreads();   // (the previous tile's statistics have been read)
-            if (kq == 0) lnred[0][wave][r16] = s;
-            __syncthreads();
-            float mean = 0.f;
-            for (int w = 0; w < nw; ++w) mean += lnred[0][w][r16];
-            mean /= (float)a.K;
-            float q = 0.f;
+            for (int i = 0; i < ITER; ++i) sm += (areg[i].x + areg[i].y) + (areg[i].z + areg[i].w);
+            sm += __shfl_xor(sm, 16);
+            sm += __shfl_xor(sm, 32);
+            mw = sm * (1.0f / (16 * ITER));
 #pragma unroll
             for (int i = 0; i < ITER; ++i) {
-                const float dx = areg[i].x - mean, dy = areg[i].y - mean, dz = areg[i].z - mean, dw = areg[i].w - mean;
-                q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+                const float dx = areg[i].x - mw, dy = areg[i].y - mw, dz = areg[i].z - mw, dw = areg[i].w - mw;
+                qw += (dx * dx + dy * dy) + (dz * dz + dw * dw);
             }
-            q += __shfl_xor(q, 16);
-            q += __shfl_xor(q, 32);
-            if (kq == 0) lnred[1][wave][r16] = q;
-            __syncthreads();
-            float var = 0.f;
-            for (int w = 0; w < nw; ++w) var += lnred[1][w][r16];
-            const float rstd = 1.0f / sqrtf(var / (float)a.K + a.ln_eps);
-#pragma unroll
-            for (int i = 0; i < ITER; ++i) {
-                areg[i].x = (areg[i].x - mean) * rstd * greg[i].x + breg[i].x; areg[i].y = (areg[i].y - mean) * rstd * greg[i].y + breg[i].y;
-                areg[i].z = (areg[i].z - mean) * rstd * greg[i].z + breg[i].z; areg[i].w = (areg[i].w - mean) * rstd * greg[i].w + breg[i].w;
-            }
-            if (blockIdx.x == 0 && wave == 0 && kq == 0 && t0 + r16 < T) {
-                a.stats_out[2 * (t0 + r16)] = mean;
-                a.stats_out[2 * (t0 + r16) + 1] = rstd;
-            }
+            qw += __shfl_xor(qw, 16);
+            qw += __shfl_xor(qw, 32);
         }
-        ENC_STAMP(3);    // LayerNorm prologue done
-        enc_f32x4 c = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < ITER; ++i) {
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i].x, wreg[i].x, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i].y, wreg[i].y, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i].z, wreg[i].z, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i].w, wreg[i].w, c, 0, 0, 0);
-        }
+        ENC_STAMP(3);    // statistics done
         // C[token 4 (lane >> 4) + j][column lane & 15] in register j
         if (t0 > 0) __syncthreads();   // the previous tile's sums have been read
 #pragma unroll
-        for (int j = 0; j < 4; ++j) red[wave][j * 64 + lane] = c[j];
+        for (int j = 0; j < 4; ++j) red[wave][j * 64 + lane] = c0[j] + c1[j];
+        if constexpr (LNPRO) {
+            if (kq == 0) { lnred[0][wave][r16] = mw; lnred[1][wave][r16] = qw; }
+        }
         ENC_STAMP(4);    // MFMAs done (the LDS writes wait for them)
         __syncthreads();
         ENC_STAMP(5);    // barrier passed
         if (ecol) {
             float s = 0.f;
             for (int w = 0; w < nw; ++w) s += red[w][tid];
-            s += bias_v;
+            if constexpr (LNPRO) {
+                // equal counts: mean = the average of the waves' means, M2 = sum of their M2 + 192 sum (mean_w - mean)^2
+                float mean = 0.f;
+                for (int w = 0; w < nw; ++w) mean += lnred[0][w][et];
+                mean /= (float)nw;
+                float m2 = 0.f;
+                for (int w = 0; w < nw; ++w) { const float dm = lnred[0][w][et] - mean; m2 += lnred[1][w][et] + (float)(16 * ITER) * dm * dm; }
+                const float rstd = 1.0f / sqrtf(m2 / (float)a.K + a.ln_eps);
+                s = rstd * (s - mean * c1_v);
+                if (blockIdx.x == 0 && en == 0 && t0 + et < T) {
+                    a.stats_out[2 * (t0 + et)] = mean;
+                    a.stats_out[2 * (t0 + et) + 1] = rstd;
+                }
+            }
+            if (ks == 0) {   // (work-group-uniform) bias and residual once, in slab 0
+                s += bias_v;
+                if constexpr (EPI == 2) s += (rsrc - rmean) * rrstd * rg + rb;
+            }
             if constexpr (EPI == 1) s = 0.5f * s * (1.0f + erff(s * 0.70710678118654752440f));
-            if constexpr (EPI == 2) s += (rsrc - rmean) * rrstd * rg + rb;
-            if (t0 + et < T) a.y[(size_t)(t0 + et) * a.N + n0 + en] = s;
+            if (t0 + et < T) {
+                float *yo = a.y + (size_t)ks * a.slab;
+                if constexpr (OUT_PA) yo[enc_pa(t0 + et, n0 + en, a.N)] = s;
+                else yo[(size_t)(t0 + et) * a.N + n0 + en] = s;
+            }
         }
         ENC_STAMP_DRAIN();
         ENC_STAMP(6);    // epilogue stored
+        if (more) {
+            if constexpr (PREFETCH) {
+#pragma unroll
+                for (int i = 0; i < ITER; ++i) areg[i] = anext[i];
+                rsrc = rsrc_n; rmean = rmean_n; rrstd = rrstd_n;
+            } else {
+                load_tile(areg, (t0 >> 4) + 1);
+                if constexpr (EPI == 2) {
+                    if (ecol) load_res(t0 + 16 + et, rsrc, rmean, rrstd);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     }
 }
 
 struct EncAttnArgs {
     const int *meta;
-    const float *qkv;   // [TMAX][3 H]: Q | K | V of a token side by side
-    float *out;         // [TMAX][H]
+    const float *qkv;   // [TMAX][3 H] row-major: Q | K | V of a token side by side
+    float *out;         // [TMAX][H] operand order
     int H, heads;
     float scale;        // 1 / sqrt(64)
 };
-// softmax(q K^T scale) V for ONE (token, head) per wave: keys in chunks of 64 (one per lane; a string of up to 64 tokens is
-// one chunk), the running maximum / sum / output of the flash recurrence in registers. Inner arithmetic:
-// attention_kernel.hpp (att_dot16: the query sits four registers deep, sixteen lanes wide, broadcast by DPP).
+// softmax(q K^T scale) V for ONE (token, head) per wave, lane = head dimension d: every key and value row of the sequence is
+// one coalesced 256-byte load, the score of a key one wave-wide sum (DPP), the softmax runs on wave-uniform numbers.
+// Keys in chunks of 32 (all loads of a chunk in flight together) with the flash recurrence across chunks.
+// SINGLE: the call is ONE sequence (the reference's call shape): its keys are rows 0, 1, ... whatever the length, so the
+// first chunk's loads are issued without waiting for the descriptor (one dependent memory round trip less: ~2 us of a 6-us
+// kernel); rows past the length hold finite stale values and are masked.
+template <bool SINGLE>
 __global__ __launch_bounds__(256) void enc_attention_kernel(EncAttnArgs a) {
+    constexpr int CH = 32;
     const int lane = threadIdx.x & 63;
     const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int t = task / a.heads, h = task - t * a.heads;
-    if (t >= a.meta[0]) return;   // wave-uniform, no barriers below
-    const int s = a.meta[ENC_META_SEQ + t];
-    const int r0 = a.meta[ENC_META_STARTS + s];
-    const int L = a.meta[ENC_META_STARTS + s + 1] - r0;
+    if (t >= ENC_TMAX) return;
     const size_t ld = 3 * (size_t)a.H;
-    const float *base = a.qkv + (size_t)r0 * ld + (size_t)h * ATT_HEAD_DIM;
-    const float *qp = a.qkv + (size_t)t * ld + (size_t)h * ATT_HEAD_DIM + (lane & 15);
-    const float q0 = qp[0] * a.scale, q1 = qp[16] * a.scale, q2 = qp[32] * a.scale, q3 = qp[48] * a.scale;
-    float m_run = -INFINITY, l_run = 0.f, o_run = 0.f;
-    for (int k0 = 0; k0 < L; k0 += ATT_MAX_LEN) {
-        const int Lc = min(ATT_MAX_LEN, L - k0);
-        const float *kbase = base + (size_t)k0 * ld;
-        float kreg[ATT_HEAD_DIM];               // row `lane` of the chunk's K
-        {
-            const float4 *kp = reinterpret_cast<const float4 *>(kbase + (size_t)min(lane, Lc - 1) * ld + a.H);
-            const bool live = lane < Lc;
+    int r0 = 0, L;
+    float kreg[CH], vreg[CH];
+    if constexpr (SINGLE) {
+        const float *kb0 = a.qkv + a.H + (size_t)h * ATT_HEAD_DIM + lane;
 #pragma unroll
-            for (int c = 0; c < ATT_HEAD_DIM / 4; ++c) {
-                const float4 v = kp[c];
-                kreg[4 * c + 0] = live ? v.x : 0.f; kreg[4 * c + 1] = live ? v.y : 0.f;
-                kreg[4 * c + 2] = live ? v.z : 0.f; kreg[4 * c + 3] = live ? v.w : 0.f;
-            }
-        }
-        float vreg[ATT_MAX_LEN];                // column `lane` of the chunk's V, one register per key
-        {
-            const float *vp = kbase + 2 * (size_t)a.H + lane;
-#pragma unroll
-            for (int jb = 0; jb < ATT_MAX_LEN; jb += 8) {
-                if (jb < Lc) {                  // wave-uniform
-#pragma unroll
-                    for (int j = jb; j < jb + 8; ++j) vreg[j] = (j < Lc) ? vp[(size_t)j * ld] : 0.f;
-                } else {
-#pragma unroll
-                    for (int j = jb; j < jb + 8; ++j) vreg[j] = 0.f;
-                }
-            }
-        }
-        float acc = 0.f;
-        att_dot16(acc, q0, kreg);
-        att_dot16(acc, q1, kreg + 16);
-        att_dot16(acc, q2, kreg + 32);
-        att_dot16(acc, q3, kreg + 48);
-        const float sc = lane < Lc ? acc : -INFINITY;
-        const float m_new = fmaxf(m_run, att_wave_max(sc));
-        const float carry = expf(m_run - m_new);      // (first chunk: exp(-inf) = 0)
-        const float e = lane < Lc ? expf(sc - m_new) : 0.f;
-        l_run = l_run * carry + att_wave_sum(e);
-        float o = o_run * carry;
-#pragma unroll
-        for (int jb = 0; jb < ATT_MAX_LEN; jb += 8) {
-            if (jb < Lc) {
-#pragma unroll
-                for (int j = jb; j < jb + 8; ++j) o = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e), j)), vreg[j], o);
-            }
-        }
-        o_run = o;
-        m_run = m_new;
+        for (int j = 0; j < CH; ++j) { kreg[j] = kb0[(size_t)j * ld]; vreg[j] = kb0[(size_t)j * ld + a.H]; }
+        L = a.meta[0];
+        if (t >= L) return;
+    } else {
+        r0 = a.meta[ENC_META_TOK_R0 + t];
+        L = a.meta[ENC_META_TOK_LEN + t];   // (0 past the call's tokens)
+        if (L <= 0) return;   // wave-uniform, no barriers below
     }
-    a.out[(size_t)t * a.H + (size_t)h * ATT_HEAD_DIM + lane] = o_run / l_run;
+    const float q = a.qkv[(size_t)t * ld + (size_t)h * ATT_HEAD_DIM + lane] * a.scale;
+    const float *kb = a.qkv + (size_t)r0 * ld + a.H + (size_t)h * ATT_HEAD_DIM + lane;
+    const float *vb = kb + a.H;
+    float m_run = -INFINITY, l_run = 0.f, o_run = 0.f;
+    for (int k0 = 0; k0 < L; k0 += CH) {
+        const int Lc = min(CH, L - k0);
+        if (!SINGLE || k0 > 0) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const size_t row = (size_t)(k0 + min(j, Lc - 1)) * ld;
+                kreg[j] = kb[row];
+                vreg[j] = vb[row];
+            }
+        }
+        float sc[CH];
+        float m = m_run;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            sc[j] = j < Lc ? att_wave_sum(q * kreg[j]) : -INFINITY;   // (wave-uniform)
+            m = fmaxf(m, sc[j]);
+        }
+        const float carry = expf(m_run - m);      // (first chunk: exp(-inf) = 0)
+        float l = l_run * carry, o = o_run * carry;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const float e = j < Lc ? expf(sc[j] - m) : 0.f;
+            l += e;
+            o = fmaf(e, vreg[j], o);
+        }
+        m_run = m; l_run = l; o_run = o;
+    }
+    a.out[enc_pa(t, h * ATT_HEAD_DIM + lane, a.H)] = o_run / l_run;
 }
 
 struct EncPoolArgs {
     const int *meta;
-    const float *y;        // [TMAX][H] pre-norm output of the last layer
+    const float *y;        // [TMAX][H] pre-norm output of the last layer, operand order
     const float *g, *b;    // its LayerNorm
     float eps;
     int H;                 // 768
     int pooling;           // 0: mean over the sequence's tokens, 1: its first token ([CLS])
     int normalize;         // 1: L2-normalise (torch.nn.functional.normalize, eps 1e-12)
     float *out;            // [BMAX][H]
-    float *hidden;         // [TMAX][H]: the last hidden state of every token (token-classification heads)
+    float *hidden;         // [TMAX][H] row-major: the last hidden state of every token (token-classification heads)
+    long long slab;        // y is the sum of NSLAB slabs this many floats apart (EncLinearArgs)
 };
 // one work-group per sequence: wave w normalises tokens w, w + 4, ... (two passes over registers), keeps their sum, and the
 // four sums meet in LDS. Column 4 (lane + 64 j) + c sits in element c of chunk j of lane `lane`.
-template <int NV>
+template <int NV, int NSLAB>
 __global__ __launch_bounds__(256) void enc_pool_kernel(EncPoolArgs a) {
     __shared__ float4 part[4][NV][64];
-    __shared__ float nrm[4];
     const int b = blockIdx.x;
     if (b >= a.meta[1]) return;
     const int r0 = a.meta[ENC_META_STARTS + b], r1 = a.meta[ENC_META_STARTS + b + 1];
@@ -335,7 +439,15 @@ __global__ __launch_bounds__(256) void enc_pool_kernel(EncPoolArgs a) {
     for (int r = r0 + wave; r < r1; r += 4) {
         float4 v[NV];
 #pragma unroll
-        for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const float4 *>(a.y + (size_t)r * a.H + 4 * (lane + 64 * j));
+        for (int j = 0; j < NV; ++j) {   // (every load of the row in flight before the first add)
+            const size_t idx = enc_pa(r, 4 * (lane + 64 * j), a.H);
+            float4 u[NSLAB];
+#pragma unroll
+            for (int sl = 0; sl < NSLAB; ++sl) u[sl] = *reinterpret_cast<const float4 *>(a.y + idx + (size_t)sl * a.slab);
+            v[j] = u[0];
+#pragma unroll
+            for (int sl = 1; sl < NSLAB; ++sl) { v[j].x += u[sl].x; v[j].y += u[sl].y; v[j].z += u[sl].z; v[j].w += u[sl].w; }
+        }
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < NV; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);

@@ -15,9 +15,12 @@ struct icd_encoder {
     uint64_t magic = 0;
     int device = 0;
     icd_encoder_desc d{};
-    std::vector<const float *> w_qkv, b_qkv, w_ao, b_ao, ln1_g, ln1_b, w_up, b_up, w_down, b_down, ln2_g, ln2_b;
+    std::vector<const float *> b_qkv, b_ao, ln1_g, ln1_b, b_up, b_down, ln2_g, ln2_b;   // borrowed from the caller
+    std::vector<float *> w_qkv, w_ao, w_up, w_down;   // OWNED copies of the four Linear weights in the order their GEMM reads them (encoder_small.hpp enc_pw);
+                                                      // w_qkv / w_up with the LayerNorm in front of them folded in, c1 / c2 per output column (enc_fold_ln_kernel)
+    std::vector<float *> c1_qkv, c2_qkv, c1_up, c2_up;
     // workspace: activations of at most ENC_TMAX tokens
-    float *yb[3] = {nullptr, nullptr, nullptr};   // pre-norm sublayer outputs, rotating (encoder_small.hpp)
+    float *yb[3] = {nullptr, nullptr, nullptr};   // pre-norm sublayer outputs, rotating, ENC_SLABS slabs each (encoder_small.hpp: the FFN-down GEMM splits K over work-groups)
     float *x = nullptr, *qkv = nullptr, *ctx = nullptr, *mid = nullptr, *pooled = nullptr, *sA = nullptr, *sB = nullptr;
     int *d_meta = nullptr;
     int *h_meta = nullptr;       // pinned: the descriptor the graph's first node copies
@@ -26,7 +29,7 @@ struct icd_encoder {
     hipEvent_t ev_done = nullptr;   // behind every launch: the next call may rewrite h_meta only after the copy node has run
     bool ev_pending = false;
     static constexpr int NBUCKET = 4;   // 16, 32, 64, 128 tokens
-    hipGraphExec_t exec[NBUCKET][2][2] = {};   // [bucket][pooling][normalize]
+    hipGraphExec_t exec[NBUCKET][2][2][2] = {};   // [bucket][pooling][normalize][one sequence]
     unsigned long long *stamps = nullptr;   // diagnostic builds (ICD_ABLATE, env ICD_ENC_STAMPS=1): [4 GEMMs of layer 0][16] clock stamps
     std::mutex mu;
 };
@@ -36,9 +39,11 @@ constexpr uint64_t ENC_MAGIC = 0x49434445454e4331ull;
 inline bool enc_valid(const icd_encoder *e) { return e && e->magic == ENC_MAGIC; }
 
 // the launches of one forward on stream s (inside a capture): the descriptor H2D in front, the pooled rows' D2H behind
-inline int enc_enqueue(icd_encoder *e, int bucket_tokens, int pooling, int normalize, hipStream_t s) {
+constexpr int ENC_SLABS = 4;   // K slices of the FFN-down GEMM = slabs of its output
+inline int enc_enqueue(icd_encoder *e, int bucket_tokens, int pooling, int normalize, bool single, hipStream_t s) {
     const icd_encoder_desc &d = e->d;
     const int H = d.hidden, I = d.inter;
+    const long long slab = (long long)ENC_TMAX * H;
     HIP_TRY(hipMemcpyAsync(e->d_meta, e->h_meta, ENC_META_WORDS * sizeof(int), hipMemcpyHostToDevice, s));
     {
         EncEmbedArgs a{};
@@ -52,32 +57,39 @@ inline int enc_enqueue(icd_encoder *e, int bucket_tokens, int pooling, int norma
         float *y0 = e->yb[cur], *y1 = e->yb[(cur + 1) % 3], *y2 = e->yb[(cur + 2) % 3];
         {   // Q | K | V = LayerNorm(y0) Wqkv^T + b; leaves LayerNorm's statistics in sA
             EncLinearArgs a{};
-            a.meta = e->d_meta; a.x = y0; a.ln_g = pg; a.ln_b = pb; a.ln_eps = d.ln_eps; a.stats_out = e->sA;
-            a.w = e->w_qkv[l]; a.bias = e->b_qkv[l]; a.y = e->qkv; a.K = H; a.N = 3 * H; a.stamps = (e->stamps && l == 6) ? e->stamps : nullptr;
-            hipLaunchKernelGGL((enc_linear_kernel<12, 16, 0, true>), dim3(3 * H / 16), dim3(64 * (H / 192)), 0, s, a);
+            a.meta = e->d_meta; a.x = y0; a.ln_eps = d.ln_eps; a.stats_out = e->sA;
+            a.w = e->w_qkv[l]; a.c1 = e->c1_qkv[l]; a.bias = e->c2_qkv[l]; a.y = e->qkv; a.K = H; a.N = 3 * H; a.stamps = (e->stamps && l == d.layers - 1) ? e->stamps : nullptr;
+            a.nwk = H / 192; a.slab = slab; a.res_nslab = 1;
+            if (l == 0) hipLaunchKernelGGL((enc_linear_kernel<16, 0, true, false, 4, 1>), dim3(3 * H / 16), dim3(64 * (H / 192)), 0, s, a);   // (the embedding sum: one slab)
+            else hipLaunchKernelGGL((enc_linear_kernel<16, 0, true, false, 4, ENC_SLABS>), dim3(3 * H / 16), dim3(64 * (H / 192)), 0, s, a);
         }
         {
             EncAttnArgs a{};
             a.meta = e->d_meta; a.qkv = e->qkv; a.out = e->ctx; a.H = H; a.heads = d.heads; a.scale = 0.125f;
-            hipLaunchKernelGGL(enc_attention_kernel, dim3((bucket_tokens * d.heads + 3) / 4), dim3(256), 0, s, a);
+            if (single) hipLaunchKernelGGL(enc_attention_kernel<true>, dim3((bucket_tokens * d.heads + 3) / 4), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL(enc_attention_kernel<false>, dim3((bucket_tokens * d.heads + 3) / 4), dim3(256), 0, s, a);
         }
         {   // y1 = ctx Wo^T + b + LayerNorm(y0)      (BertSelfOutput in front of its LayerNorm)
             EncLinearArgs a{};
             a.meta = e->d_meta; a.x = e->ctx; a.w = e->w_ao[l]; a.bias = e->b_ao[l];
-            a.res_src = y0; a.res_stats = e->sA; a.res_g = pg; a.res_b = pb; a.y = y1; a.K = H; a.N = H; a.stamps = (e->stamps && l == 6) ? e->stamps + 16 : nullptr;
-            hipLaunchKernelGGL((enc_linear_kernel<12, 8, 2, false>), dim3(H / 8), dim3(64 * (H / 192)), 0, s, a);
+            a.res_src = y0; a.res_stats = e->sA; a.res_g = pg; a.res_b = pb; a.y = y1; a.K = H; a.N = H; a.stamps = (e->stamps && l == d.layers - 1) ? e->stamps + 16 : nullptr;
+            a.nwk = H / 192; a.slab = slab; a.res_nslab = l == 0 ? 1 : ENC_SLABS;
+            hipLaunchKernelGGL((enc_linear_kernel<8, 2, false, true, 4, 1>), dim3(H / 8), dim3(64 * (H / 192)), 0, s, a);
         }
         {   // mid = GELU(LayerNorm1(y1) Wup^T + b); statistics of LayerNorm1 in sB
             EncLinearArgs a{};
-            a.meta = e->d_meta; a.x = y1; a.ln_g = e->ln1_g[l]; a.ln_b = e->ln1_b[l]; a.ln_eps = d.ln_eps; a.stats_out = e->sB;
-            a.w = e->w_up[l]; a.bias = e->b_up[l]; a.y = e->mid; a.K = H; a.N = I; a.stamps = (e->stamps && l == 6) ? e->stamps + 32 : nullptr;
-            hipLaunchKernelGGL((enc_linear_kernel<12, 16, 1, true>), dim3(I / 16), dim3(64 * (H / 192)), 0, s, a);
+            a.meta = e->d_meta; a.x = y1; a.ln_eps = d.ln_eps; a.stats_out = e->sB;
+            a.w = e->w_up[l]; a.c1 = e->c1_up[l]; a.bias = e->c2_up[l]; a.y = e->mid; a.K = H; a.N = I; a.stamps = (e->stamps && l == d.layers - 1) ? e->stamps + 32 : nullptr;
+            a.nwk = H / 192; a.slab = slab; a.res_nslab = 1;
+            hipLaunchKernelGGL((enc_linear_kernel<16, 1, true, true, 4, 1>), dim3(I / 16), dim3(64 * (H / 192)), 0, s, a);
         }
         {   // y2 = mid Wdown^T + b + LayerNorm1(y1)   (BertOutput in front of its LayerNorm)
             EncLinearArgs a{};
             a.meta = e->d_meta; a.x = e->mid; a.w = e->w_down[l]; a.bias = e->b_down[l];
-            a.res_src = y1; a.res_stats = e->sB; a.res_g = e->ln1_g[l]; a.res_b = e->ln1_b[l]; a.y = y2; a.K = I; a.N = H; a.stamps = (e->stamps && l == 6) ? e->stamps + 48 : nullptr;
-            hipLaunchKernelGGL((enc_linear_kernel<12, 4, 2, false>), dim3(H / 4), dim3(64 * (I / 192)), 0, s, a);
+            a.res_src = y1; a.res_stats = e->sB; a.res_g = e->ln1_g[l]; a.res_b = e->ln1_b[l]; a.y = y2; a.K = I; a.N = H; a.stamps = (e->stamps && l == d.layers - 1) ? e->stamps + 48 : nullptr;
+            // K = inter split over ENC_SLABS work-groups of (inter / 192 / ENC_SLABS) waves per 16 output columns: partial sums into the slabs of y2
+            a.nwk = I / 192; a.slab = slab; a.res_nslab = 1;
+            hipLaunchKernelGGL((enc_linear_kernel<16, 2, false, true, 4, 1>), dim3(H / 16 * ENC_SLABS), dim3(64 * (I / 192 / ENC_SLABS)), 0, s, a);
         }
         cur = (cur + 2) % 3;
         pg = e->ln2_g[l]; pb = e->ln2_b[l];
@@ -85,8 +97,8 @@ inline int enc_enqueue(icd_encoder *e, int bucket_tokens, int pooling, int norma
     {   // the last LayerNorm, pooling, normalisation; the last hidden state of every token into x
         EncPoolArgs a{};
         a.meta = e->d_meta; a.y = e->yb[cur]; a.g = pg; a.b = pb; a.eps = d.ln_eps; a.H = H; a.pooling = pooling; a.normalize = normalize;
-        a.out = e->pooled; a.hidden = e->x;
-        hipLaunchKernelGGL(enc_pool_kernel<3>, dim3(ENC_BMAX), dim3(256), 0, s, a);
+        a.out = e->pooled; a.hidden = e->x; a.slab = slab;
+        hipLaunchKernelGGL((enc_pool_kernel<3, ENC_SLABS>), dim3(ENC_BMAX), dim3(256), 0, s, a);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e->h_out, e->pooled, (size_t)ENC_BMAX * H * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -94,8 +106,9 @@ inline int enc_enqueue(icd_encoder *e, int bucket_tokens, int pooling, int norma
 }
 
 inline void enc_free(icd_encoder *e) {
-    for (auto &b : e->exec) for (auto &p : b) for (auto &g : p) if (g) hipGraphExecDestroy(g);
+    for (auto &b : e->exec) for (auto &p : b) for (auto &n : p) for (auto &g : n) if (g) hipGraphExecDestroy(g);
     for (float *p : {e->yb[0], e->yb[1], e->yb[2], e->x, e->qkv, e->ctx, e->mid, e->pooled, e->sA, e->sB}) if (p) hipFree(p);
+    for (auto *v : {&e->w_qkv, &e->w_ao, &e->w_up, &e->w_down, &e->c1_qkv, &e->c2_qkv, &e->c1_up, &e->c2_up}) for (float *p : *v) if (p) hipFree(p);
     if (e->d_meta) hipFree(e->d_meta);
     if (e->stamps) hipFree(e->stamps);
     if (e->h_meta) hipHostFree(e->h_meta);
@@ -119,7 +132,7 @@ int icd_encoder_create(int32_t device, const icd_encoder_desc *desc, icd_encoder
     if (d.heads < 1 || d.hidden != d.heads * ATT_HEAD_DIM) return fail(ICD_ERR_UNSUPPORTED, "hidden=%d heads=%d (this encoder is written for 64-wide heads)", d.hidden, d.heads);
     // enc_linear_kernel: K = 192 per wave, at most 16 waves; the LayerNorm kernels: 3 x 256 columns
     if (d.hidden != 768) return fail(ICD_ERR_UNSUPPORTED, "hidden=%d (the small-input encoder is instantiated for 768)", d.hidden);
-    if (d.inter < 192 || d.inter % 192 != 0 || d.inter > 3072) return fail(ICD_ERR_UNSUPPORTED, "inter=%d (a multiple of 192, at most 3072)", d.inter);
+    if (d.inter < 768 || d.inter % 768 != 0 || d.inter > 3072) return fail(ICD_ERR_UNSUPPORTED, "inter=%d (a multiple of 768, at most 3072: four K slices of at most four waves)", d.inter);
     if (d.vocab < 1 || d.max_pos < 1 || d.pos_offset < 0 || d.pos_offset >= d.max_pos) return fail(ICD_ERR_INVALID, "vocab=%d max_pos=%d pos_offset=%d", d.vocab, d.max_pos, d.pos_offset);
     if (!(d.ln_eps > 0.0f)) return fail(ICD_ERR_INVALID, "ln_eps=%g", (double)d.ln_eps);
     if (!d.word_emb || !d.pos_emb || !d.type_emb0 || !d.emb_ln_g || !d.emb_ln_b) return fail(ICD_ERR_INVALID, "an embedding pointer is NULL");
@@ -139,16 +152,46 @@ int icd_encoder_create(int32_t device, const icd_encoder_desc *desc, icd_encoder
     if (!e) return fail(ICD_ERR_NOMEM, "out of host memory");
     e->magic = ENC_MAGIC; e->device = device; e->d = d;
     auto keep = [&](std::vector<const float *> &v, const float *const *a) { v.assign(a, a + d.layers); };
-    keep(e->w_qkv, d.w_qkv); keep(e->b_qkv, d.b_qkv); keep(e->w_ao, d.w_ao); keep(e->b_ao, d.b_ao); keep(e->ln1_g, d.ln1_g); keep(e->ln1_b, d.ln1_b);
-    keep(e->w_up, d.w_up); keep(e->b_up, d.b_up); keep(e->w_down, d.w_down); keep(e->b_down, d.b_down); keep(e->ln2_g, d.ln2_g); keep(e->ln2_b, d.ln2_b);
+    keep(e->b_qkv, d.b_qkv); keep(e->b_ao, d.b_ao); keep(e->ln1_g, d.ln1_g); keep(e->ln1_b, d.ln1_b);
+    keep(e->b_up, d.b_up); keep(e->b_down, d.b_down); keep(e->ln2_g, d.ln2_g); keep(e->ln2_b, d.ln2_b);
+    for (auto *v : {&e->w_qkv, &e->w_ao, &e->w_up, &e->w_down, &e->c1_qkv, &e->c2_qkv, &e->c1_up, &e->c2_up}) v->assign(d.layers, nullptr);
     e->d.w_qkv = e->d.b_qkv = e->d.w_ao = e->d.b_ao = e->d.ln1_g = e->d.ln1_b = e->d.w_up = e->d.b_up = e->d.w_down = e->d.b_down = e->d.ln2_g = e->d.ln2_b = nullptr;   // (the caller's arrays need not outlive this call)
 #define ENC_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { enc_free(e); return fail(e_ == hipErrorOutOfMemory ? ICD_ERR_NOMEM : ICD_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } } while (0)
     const size_t H = (size_t)d.hidden, I = (size_t)d.inter, T = ENC_TMAX;
-    struct { float **p; size_t n; } bufs[] = {{&e->yb[0], T * H}, {&e->yb[1], T * H}, {&e->yb[2], T * H}, {&e->x, T * H}, {&e->qkv, T * 3 * H}, {&e->ctx, T * H},
+    struct { float **p; size_t n; } bufs[] = {{&e->yb[0], ENC_SLABS * T * H}, {&e->yb[1], ENC_SLABS * T * H}, {&e->yb[2], ENC_SLABS * T * H}, {&e->x, T * H}, {&e->qkv, T * 3 * H}, {&e->ctx, T * H},
                                               {&e->mid, T * I}, {&e->pooled, (size_t)ENC_BMAX * H}, {&e->sA, 2 * T}, {&e->sB, 2 * T}};
     for (auto &b : bufs) {
         ENC_TRY(hipMalloc(reinterpret_cast<void **>(b.p), b.n * sizeof(float)));
         ENC_TRY(hipMemset(*b.p, 0, b.n * sizeof(float)));   // (rows past a call's tokens are read by the last 16-token tile: finite, never stored)
+    }
+    // the four Linear weights of every layer, copied ONCE into the order their GEMM's loads want (enc_pw: tiles of 16 / 8 / 16 / 16
+    // rows); the two that read a LayerNorm's output (QKV: the previous sublayer's, FFN up: LayerNorm1) with it folded in
+    {
+        auto permute = [&](const float *src, const float *colscale, float **dst, int N, int K, int NT) -> hipError_t {
+            hipError_t er = hipMalloc(reinterpret_cast<void **>(dst), (size_t)N * K * sizeof(float));
+            if (er != hipSuccess) return er;
+            const size_t groups = (size_t)N * K / 4;
+            hipLaunchKernelGGL(enc_permute_w_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, nullptr, src, colscale, *dst, N, K, NT);
+            return hipGetLastError();
+        };
+        auto fold = [&](const float *w, const float *g, const float *b, const float *bias, float **c1, float **c2, int N, int K) -> hipError_t {
+            hipError_t er = hipMalloc(reinterpret_cast<void **>(c1), (size_t)N * sizeof(float));
+            if (er != hipSuccess) return er;
+            er = hipMalloc(reinterpret_cast<void **>(c2), (size_t)N * sizeof(float));
+            if (er != hipSuccess) return er;
+            hipLaunchKernelGGL(enc_fold_ln_kernel, dim3((N + 3) / 4), dim3(256), 0, nullptr, w, g, b, bias, *c1, *c2, N, K);
+            return hipGetLastError();
+        };
+        const float *pg = d.emb_ln_g, *pb = d.emb_ln_b;   // the LayerNorm in front of layer l's QKV
+        for (int l = 0; l < d.layers; ++l) {
+            ENC_TRY(permute(desc->w_qkv[l], pg, &e->w_qkv[l], 3 * d.hidden, d.hidden, 16));
+            ENC_TRY(fold(desc->w_qkv[l], pg, pb, desc->b_qkv[l], &e->c1_qkv[l], &e->c2_qkv[l], 3 * d.hidden, d.hidden));
+            ENC_TRY(permute(desc->w_ao[l], nullptr, &e->w_ao[l], d.hidden, d.hidden, 8));
+            ENC_TRY(permute(desc->w_up[l], desc->ln1_g[l], &e->w_up[l], d.inter, d.hidden, 16));
+            ENC_TRY(fold(desc->w_up[l], desc->ln1_g[l], desc->ln1_b[l], desc->b_up[l], &e->c1_up[l], &e->c2_up[l], d.inter, d.hidden));
+            ENC_TRY(permute(desc->w_down[l], nullptr, &e->w_down[l], d.hidden, d.inter, 16));
+            pg = desc->ln2_g[l]; pb = desc->ln2_b[l];
+        }
     }
     ENC_TRY(hipMalloc(reinterpret_cast<void **>(&e->d_meta), ENC_META_WORDS * sizeof(int)));
     ENC_TRY(hipMemset(e->d_meta, 0, ENC_META_WORDS * sizeof(int)));
@@ -176,6 +219,9 @@ int icd_debug_encoder_stamps(icd_encoder *e, unsigned long long *out) {
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, e->stamps, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long first[8];
+    HIP_TRY(hipMemcpyFromSymbol(first, HIP_SYMBOL(icd::g_enc_first), sizeof first));
+    for (int g = 0; g < 4; ++g) { out[g * 16 + 14] = first[2 * g]; out[g * 16 + 15] = first[2 * g + 1]; }   // (slot 7 of every GEMM: its first instruction)
     return ICD_OK;
 }
 #endif
@@ -219,16 +265,19 @@ int icd_encoder_encode(icd_encoder *e, const int32_t *ids, const int32_t *length
     int t = 0;
     for (int b = 0; b < nseq; ++b) {
         m[ENC_META_STARTS + b] = t;
-        for (int i = 0; i < lengths[b]; ++i, ++t) { m[ENC_META_IDS + t] = ids[t]; m[ENC_META_POS + t] = d.pos_offset + i; m[ENC_META_SEQ + t] = b; }
+        const int first = t;
+        for (int i = 0; i < lengths[b]; ++i, ++t) { m[ENC_META_IDS + t] = ids[t]; m[ENC_META_POS + t] = d.pos_offset + i; m[ENC_META_TOK_R0 + t] = first; m[ENC_META_TOK_LEN + t] = lengths[b]; }
     }
     for (int b = nseq; b <= ENC_BMAX; ++b) m[ENC_META_STARTS + b] = T;
+    for (int u = T; u < ENC_TMAX; ++u) { m[ENC_META_TOK_R0 + u] = 0; m[ENC_META_TOK_LEN + u] = 0; }
     const int bi = T <= 16 ? 0 : (T <= 32 ? 1 : (T <= 64 ? 2 : 3));
     const int bucket = 16 << bi;
-    hipGraphExec_t &gx = e->exec[bi][pooling][normalize];
+    const bool single = nseq == 1;
+    hipGraphExec_t &gx = e->exec[bi][pooling][normalize][single ? 1 : 0];
     if (!gx) {
         hipGraph_t g = nullptr;
         HIP_TRY(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
-        const int rc = enc_enqueue(e, bucket, pooling, normalize, e->cap_stream);
+        const int rc = enc_enqueue(e, bucket, pooling, normalize, single, e->cap_stream);
         const hipError_t ec = hipStreamEndCapture(e->cap_stream, &g);
         if (rc) { if (g) hipGraphDestroy(g); return rc; }
         HIP_TRY(ec);

@@ -122,6 +122,19 @@ class _TokenClassifier:
                 self._packed = _PackedBert(bert)
         except Exception as exc:   # pragma: no cover - an optimisation, never fatal
             logger.warning("packed NER forward unavailable (%s): padded batches", exc)
+        # one request's one to a few strings (<= 32 strings, <= 128 tokens in all): the hand-written small-input forward, ONE graph
+        # launch for the encoder (csrc/encoder_small.hpp through icd_encoder_encode), the classifier head over its packed last
+        # hidden state. fp32 BERT-base shapes on a GPU; ICD_NER_SMALL=0 keeps the replayed graph of the framework's forward.
+        self._small = None
+        try:
+            bert = getattr(self.model, "bert", None) or getattr(self.model, "roberta", None)
+            if (os.getenv("ICD_NER_SMALL", "1") == "1" and str(device).startswith("cuda") and bert is not None
+                    and hasattr(self.model, "classifier")):
+                from .. import _native
+                if _native.SmallEncoder.supported(bert):
+                    self._small = _native.SmallEncoder(bert)
+        except Exception as exc:   # pragma: no cover - an optimisation, never fatal
+            logger.info("small-input NER forward unavailable (%s): the framework's forward", exc)
 
     # -- tokenisation: ids, character offsets, token strings, special-token mask ---------------------------------
     def _encode(self, text: str):
@@ -228,6 +241,17 @@ class _TokenClassifier:
         order = sorted(range(len(encoded)), key=lambda i: len(encoded[i][0]))   # length-sorted: little padding per batch
         pad = getattr(self.tokenizer, "pad_token_id", None)
         pad = 0 if pad is None else pad
+        if self._small is not None and encoded and self._small.fits([len(e[0]) for e in encoded]):
+            with torch.no_grad():
+                _, hidden = self._small.encode([e[0] for e in encoded], to_device=True, hidden=True)
+                score, label = torch.softmax(self.model.classifier(hidden).float(), dim=-1).max(dim=-1)
+                score, label = score.cpu().numpy(), label.cpu().numpy()
+            a = 0
+            for i, e in enumerate(encoded):
+                b = a + len(e[0])
+                out[i] = (label[a:b].tolist(), score[a:b])
+                a = b
+            return out
         if self._packed is not None and len(order) > 32 and self.max_batch > 32:
             with torch.no_grad():
                 rev = order[::-1]                                  # longest first

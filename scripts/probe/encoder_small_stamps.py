@@ -36,6 +36,7 @@ def main():
     print(f"{ntok} tokens; per segment: shader-clock cycles, microseconds by the 100 MHz counter, and the clock they imply")
     for g in range(4):
         print(names[g])
+        print(f"   first instruction -> first kernel argument read  {st[g, 0, 0] - st[g, 7, 0]:8d} cycles {(st[g, 0, 1] - st[g, 7, 1]) / 100.0:7.2f} us")
         for i in range(6):
             dc, dr = st[g, i + 1, 0] - st[g, i, 0], st[g, i + 1, 1] - st[g, i, 1]
             print(f"   {labels[i]:32s} {dc:8d} cycles {dr / 100.0:7.2f} us" + (f"  ({dc / dr * 100:.0f} MHz)" if dr > 20 else ""))

@@ -52,3 +52,33 @@ def test_bert_base_classifier_batched_equals_single_on_gpu(monkeypatch):
     out = svc.extract_medical_entities_batch(strings)
     assert len(out) == len(strings) and out[-2] == {} and all(isinstance(o, dict) for o in out)
     assert svc.get_model_info()["device"] == "GPU" and svc.get_entity_summary(strings[0])["extraction_method"] == "model"
+
+
+def test_bert_base_classifier_small_input_forward_equals_the_framework_forward(monkeypatch):
+    """a request's one to a few strings: the hand-written small-input encoder (csrc/encoder_small.hpp, last hidden state of
+    every token) + the classifier head give the labels and probabilities of the framework's forward (ICD_NER_SMALL=0 path:
+    the replayed graph of the padded transformers forward)"""
+    import torch
+    from rag_project_icd10_amd.services.medical_ner_service import MedicalNERService
+    monkeypatch.setenv("MEDICAL_NER_MODEL", "/nonexistent/ner-model")
+    monkeypatch.setenv("ICD_NER_ALLOW_SYNTHETIC", "1")
+    svc = MedicalNERService()
+    clf = svc.ner_pipeline
+    assert clf._small is not None
+    strings = [l.strip() for l in open(os.path.join(GOLD, "diagnosis_strings.txt"), encoding="utf-8") if l.strip()][:40]
+    small = clf._small
+    for group in ([strings[0]], strings[1:4], strings[4:10], [strings[11]], ["肺"], strings[12:14]):
+        enc = [clf._encode(s) for s in group]
+        assert small.fits([len(e[0]) for e in enc])
+        got = clf._forward(enc)
+        clf._small = None
+        want = clf._forward(enc)
+        clf._small = small
+        for (gl, gs), (wl, ws), e in zip(got, want, enc):
+            assert len(gl) == len(wl) == len(e[0])
+            assert float(np.abs(gs - ws).max()) <= 5e-5
+            assert np.mean(np.array(gl) == np.array(wl)) >= 0.9    # (random-init logits: near-ties may flip)
+    long_enc = [clf._encode("高血压" * 60)]
+    assert not small.fits([len(long_enc[0][0])])                  # more than 128 tokens: the framework's forward
+    assert len(clf._forward(long_enc)[0][0]) == len(long_enc[0][0])
+    assert svc.extract_medical_entities_batch(strings[:3]) == [svc.extract_medical_entities(s) for s in strings[:3]]
