@@ -345,6 +345,53 @@ def side_workload(*a, **kw):
         return {"workload": a[3] if len(a) > 3 else "?", "error": f"{type(exc).__name__}: {exc}", "traceback": traceback.format_exc()[-1500:]}
 
 
+def embed_one_string_extra(ctx):
+    """The embed step at the reference's own call shape: EmbeddingService.encode_query(ONE string) -> SentenceTransformer.encode
+    (services/embedding_service.py:97-102,117-120), 100 golden diagnosis strings one call at a time, through the hand-written
+    small-input forward (csrc/encoder_small.hpp, icd_encoder_encode: one graph launch) and through the framework's forward
+    replayed from a HIP graph (rounds 1-4). Synthetic BERT-base weights (the real model's shapes; no checkpoint offline).
+    Checked in the same run: the two paths' embeddings against each other (tolerance 1e-5; both against the CPU fp32 forward of
+    the same weights: tests/test_encoder_gpu.py - no CPU forward here, the cpu_baseline leg times one right after)."""
+    torch = ctx.torch
+    saved = {v: os.environ.get(v) for v in ("EMBEDDING_MODEL_NAME", "ICD_EMBEDDING_ALLOW_SYNTHETIC")}
+    os.environ.update({"EMBEDDING_MODEL_NAME": "shibing624/text2vec-base-chinese", "ICD_EMBEDDING_ALLOW_SYNTHETIC": "1"})
+    try:
+        from rag_project_icd10_amd.services.embedding_service import EmbeddingService
+        es = EmbeddingService(allow_synthetic=True, device=f"cuda:{ctx.local_rank}" if ctx.local_rank else "cuda")
+        strings = [l.strip() for l in open(os.path.join(ROOT, "tests", "golden", "diagnosis_strings.txt"), encoding="utf-8") if l.strip()][:100]
+        small = getattr(es, "_small", None)
+        out = {"workload": "EmbeddingService.encode_query, ONE string per call, 100 golden diagnosis strings, synthetic BERT-base weights",
+               "small_input_encoder": small is not None, "synthetic_weights": bool(es.synthetic)}
+        vecs = {}
+        for mode in (("small", "graph") if small is not None else ("graph",)):
+            es._small = small if mode == "small" else None
+            for t in strings[:20]:
+                es.encode_query(t)
+            lat = []
+            for i in range(200):
+                t0 = time.perf_counter()
+                v = es.encode_query(strings[i % len(strings)])
+                lat.append((time.perf_counter() - t0) * 1e6)
+                if i < len(strings):
+                    vecs.setdefault(mode, []).append(v)
+            lat.sort()
+            out[f"{mode}_us_per_call"] = {"median": lat[100], "p10": lat[20], "p90": lat[180], "calls": len(lat)}
+        es._small = small
+        if small is not None:
+            out["max_abs_d_small_vs_graph"] = float(np.max(np.abs(np.stack(vecs["small"]) - np.stack(vecs["graph"]))))
+            out["speedup"] = out["graph_us_per_call"]["median"] / out["small_us_per_call"]["median"]
+        if small is not None:
+            out["within_1e-5"] = bool(out["max_abs_d_small_vs_graph"] <= 1e-5)
+        out["tokens_per_string"] = {"median": int(np.median([len(x) for x in es._tokenize([f"query: {t}" for t in strings])]))}
+        return out
+    finally:
+        for v, val in saved.items():
+            if val is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = val
+
+
 def single_query_extra(ctx, args, index_factory):
     """The reference's own call shape (services/milvus_service.py:280-285: ONE query per MilvusService.search call) at the real
     CSV's size, k = 5 (the /query default top_k) and 10 (search's default): what the GPU needs per call (hipEvents of the
@@ -624,6 +671,15 @@ def run_replicated(ctx, args, index_factory=hip_index_factory):
                                              corpus, levels, queries, k, MODE_EXACT, max(3, steps_x // 4))
     if line is not None and ctx.world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(corpus, levels, queries, k)
+    # LAST, behind the CPU baseline: with the GPU encoder built BEFORE it in this process the baseline's CPU forward ran 60 x slower
+    # on the GPU box (0.09 against 5.2 strings/s, twice; a 16-CPU share under three thread pools) - not reproduced outside bench.py
+    # (scripts/probe/cpu_encoder_after_gpu.py), so the order is what guards the baseline.
+    if (line is not None and ctx.world == 1 and not ctx.cpu_only and mode == MODE_AUTO and not args.no_extras and not args.no_family
+            and not getattr(args, "no_embed_extra", False)):
+        try:
+            line.setdefault("extra", {})["embed_one_string"] = embed_one_string_extra(ctx)
+        except Exception as exc:   # pragma: no cover - reported, never fatal
+            line.setdefault("extra", {})["embed_one_string"] = {"error": f"{type(exc).__name__}: {exc}"}
     return line
 
 
@@ -1028,6 +1084,7 @@ def main(argv=None):
     ap.add_argument("--no-config3", action="store_true", help="N > 1: skip the configs[3] leg of the default run")
     ap.add_argument("--no-native-trial", action="store_true", help="N > 1: skip the time-limited trial of the C-ABI RCCL group behind the row-sharded leg")
     ap.add_argument("--native-trial-limit", type=float, default=90.0)
+    ap.add_argument("--no-embed-extra", action="store_true", help="leave extra.embed_one_string out (the encode_query latency of the embed step)")
     ap.add_argument("--rank-timeout", type=float, default=1500.0, help="--gpus N > 1 started by this process: wall-clock limit of the ranks in seconds")
     args = ap.parse_args(argv)
     if args.gpus < 1:

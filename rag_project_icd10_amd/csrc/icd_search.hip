@@ -204,6 +204,7 @@ struct icd_index {
     // kernel's last work-group stores a sequence number behind its outputs (the block's last 64 bytes) that the host polls
     // instead of waiting for the stream's completion signal (done_seq counts the calls that asked for it)
     const float *host_q = nullptr;
+    bool host_one_call = false;    // the current call is ONE query from host memory with host outputs in the mapped block: it may poll
     unsigned long long done_seq = 0;
     bool done_armed = false;       // the current call's launch carries the word's address
     size_t bytes_ws = 0;
@@ -723,7 +724,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             rec(x, 3, s);
             const float *hq = qb1 == 1 ? x->host_q : nullptr;   // (a host caller's ONE query: search_common left the copy out)
             if (!hq) { const int rcq = stage_host_query(); if (rcq) return rcq; }
-            const bool poll = x->host_q != nullptr && (g_host_one & 2) != 0;
+            const bool poll = x->host_one_call && (g_host_one & 2) != 0;
             const int rc1 = qb1 == 1 ? launch_stream_one<16, 2, 1>(x, dq, 1, f, s, hq, poll) : qb1 == 2 ? launch_stream_one<16, 2, 2>(x, dq, 2, f, s)
                           : launch_stream_one<16, 2, 4>(x, dq, (int)nq, f, s);
             rec(x, 4, s);
@@ -1424,8 +1425,10 @@ static int search_common(icd_index *x, const float *queries, int64_t nq, int32_t
         dev.adj_lv = user.adj_lv ? x->o_adj_lv : nullptr;
     }
     x->done_armed = false;
+    x->host_one_call = !q_on_device && nq == 1 && pinned_out && !x->capturing;
     int rc = search_device(x, dq, (int)nq, k, mode, dev, s);
     x->host_q = nullptr;
+    x->host_one_call = false;
     if (rc) return rc;
     rec(x, NUM_EV, s);
     if (x->done_armed && pinned_out) {

@@ -24,6 +24,7 @@ cp gpurun_out/${TAG}_pmc_traffic.json gpurun_out/${TAG}_pmc_traffic_rowshard.jso
 (timeout 600 python3 scripts/probe/single_query_probe.py 2>&1 | grep -v amdgpu.ids) > gpurun_out/single_query_probe.log
 (timeout 900 python3 scripts/probe/exact_by_k.py 2>&1 | grep -v amdgpu.ids) > gpurun_out/exact_by_k.log
 (timeout 600 python3 scripts/probe/rowshard_pacing_probe.py 2>&1 | grep -v amdgpu.ids) > gpurun_out/rowshard_pacing.log
+bash scripts/gpu_encoder_small.sh $TAG > gpurun_out/encoder_small_$TAG.out 2>&1   # -> gpurun_out/${TAG}_encoder_small.log, ${TAG}_query_latency.log
 : > gpurun_out/fuzz_final.log
 for seed in 541 542; do (timeout 600 python scripts/gpu_fuzz.py --cases 60 --seed $seed 2>&1 | grep -E "FAIL|gpu_fuzz") >> gpurun_out/fuzz_final.log; done
 (timeout 600 python scripts/gpu_fuzz.py --cases 40 --seed 543 --focus exact_k 2>&1 | grep -E "FAIL|gpu_fuzz") >> gpurun_out/fuzz_final.log
