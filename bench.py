@@ -673,7 +673,7 @@ def run_replicated(ctx, args, index_factory=hip_index_factory):
         line["cpu_baseline"] = cpu_baseline(corpus, levels, queries, k)
     # LAST, behind the CPU baseline: with the GPU encoder built BEFORE it in this process the baseline's CPU forward ran 60 x slower
     # on the GPU box (0.09 against 5.2 strings/s, twice; a 16-CPU share under three thread pools) - not reproduced outside bench.py
-    # (scripts/probe/cpu_encoder_after_gpu.py), so the order is what guards the baseline.
+    # (GPU service first, then a new CPU service: 100-150 ms per string either way), so the order is what guards the baseline.
     if (line is not None and ctx.world == 1 and not ctx.cpu_only and mode == MODE_AUTO and not args.no_extras and not args.no_family
             and not getattr(args, "no_embed_extra", False)):
         try:
