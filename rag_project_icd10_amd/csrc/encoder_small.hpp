@@ -172,7 +172,7 @@ __global__ __launch_bounds__(MAXW * 64) void enc_linear_kernel(EncLinearArgs a) 
     const int tid = threadIdx.x, lane = tid & 63;
 #ifdef ICD_ABLATE
     if (blockIdx.x == 1 && tid == 0) {
-        const int slot = (NT == 16 ? (EPI == 0 ? 0 : 2) : (NT == 8 ? 1 : 3)) * 2;
+        const int slot = (LNPRO ? (EPI == 0 ? 0 : 2) : (NT == 8 ? 1 : 3)) * 2;   // QKV, attention output, FFN up, FFN down
         g_enc_first[slot] = __builtin_amdgcn_s_memtime(); g_enc_first[slot + 1] = __builtin_amdgcn_s_memrealtime();
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(MAXW * 64) void enc_linear_kernel(EncLinearArgs a) 
             qw += __shfl_xor(qw, 16);
             qw += __shfl_xor(qw, 32);
         }
-        ENC_STAMP(3);    // statistics done
+        ENC_STAMP(3);    // MFMAs issued, statistics done
         // C[token 4 (lane >> 4) + j][column lane & 15] in register j
         if (t0 > 0) __syncthreads();   // the previous tile's sums have been read
 #pragma unroll
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(MAXW * 64) void enc_linear_kernel(EncLinearArgs a) 
         if constexpr (LNPRO) {
             if (kq == 0) { lnred[0][wave][r16] = mw; lnred[1][wave][r16] = qw; }
         }
-        ENC_STAMP(4);    // MFMAs done (the LDS writes wait for them)
+        ENC_STAMP(4);    // partial sums in LDS (the writes wait for the MFMAs)
         __syncthreads();
         ENC_STAMP(5);    // barrier passed
         if (ecol) {
@@ -420,11 +420,13 @@ struct EncPoolArgs {
     float *hidden;         // [TMAX][H] row-major: the last hidden state of every token (token-classification heads)
     long long slab;        // y is the sum of NSLAB slabs this many floats apart (EncLinearArgs)
 };
-// one work-group per sequence: wave w normalises tokens w, w + 4, ... (two passes over registers), keeps their sum, and the
-// four sums meet in LDS. Column 4 (lane + 64 j) + c sits in element c of chunk j of lane `lane`.
+// one work-group of 16 waves per sequence: wave w normalises tokens w, w + 16, ... (two passes over registers; a row is a
+// dependent memory round trip, so the rows are dealt over as many waves as a work-group has), keeps their sum, and the
+// sums meet in LDS. Column 4 (lane + 64 j) + c sits in element c of chunk j of lane `lane`.
+constexpr int ENC_POOL_WAVES = 16;
 template <int NV, int NSLAB>
-__global__ __launch_bounds__(256) void enc_pool_kernel(EncPoolArgs a) {
-    __shared__ float4 part[4][NV][64];
+__global__ __launch_bounds__(ENC_POOL_WAVES * 64) void enc_pool_kernel(EncPoolArgs a) {
+    __shared__ float4 part[ENC_POOL_WAVES][NV][64];
     const int b = blockIdx.x;
     if (b >= a.meta[1]) return;
     const int r0 = a.meta[ENC_META_STARTS + b], r1 = a.meta[ENC_META_STARTS + b + 1];
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(256) void enc_pool_kernel(EncPoolArgs a) {
         bb[j] = *reinterpret_cast<const float4 *>(a.b + 4 * (lane + 64 * j));
         acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int r = r0 + wave; r < r1; r += 4) {
+    for (int r = r0 + wave; r < r1; r += ENC_POOL_WAVES) {
         float4 v[NV];
 #pragma unroll
         for (int j = 0; j < NV; ++j) {   // (every load of the row in flight before the first add)
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(256) void enc_pool_kernel(EncPoolArgs a) {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         float4 t = part[0][j][lane];
-        for (int w = 1; w < 4; ++w) { const float4 u = part[w][j][lane]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        for (int w = 1; w < ENC_POOL_WAVES; ++w) { const float4 u = part[w][j][lane]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
         t.x /= cnt; t.y /= cnt; t.z /= cnt; t.w /= cnt;
         acc[j] = t;
         ss += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);

@@ -98,7 +98,7 @@ inline int enc_enqueue(icd_encoder *e, int bucket_tokens, int pooling, int norma
         EncPoolArgs a{};
         a.meta = e->d_meta; a.y = e->yb[cur]; a.g = pg; a.b = pb; a.eps = d.ln_eps; a.H = H; a.pooling = pooling; a.normalize = normalize;
         a.out = e->pooled; a.hidden = e->x; a.slab = slab;
-        hipLaunchKernelGGL((enc_pool_kernel<3, ENC_SLABS>), dim3(ENC_BMAX), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((enc_pool_kernel<3, ENC_SLABS>), dim3(ENC_BMAX), dim3(ENC_POOL_WAVES * 64), 0, s, a);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e->h_out, e->pooled, (size_t)ENC_BMAX * H * sizeof(float), hipMemcpyDeviceToHost, s));

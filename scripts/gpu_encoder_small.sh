@@ -17,7 +17,12 @@ for nt in 15 98; do
   echo "# (3) rocprofv3 --kernel-trace --stats of scripts/probe/encoder_small_profile.py $nt (200 forwards of one $nt-token string): name, calls, total ns, average ns"
   cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/encp && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/encp -o enc -- python3 $R/scripts/probe/encoder_small_profile.py $nt > /tmp/encp.log 2>&1
   f=$(find /tmp/encp -name "*kernel_stats.csv" 2>/dev/null | head -1)
-  if [ -n "$f" ]; then grep -E "enc_|copyBuffer" "$f" | cut -d, -f1-4 | cut -c1-160; else echo "(no kernel stats: $(tail -1 /tmp/encp.log))"; fi
+  if [ -n "$f" ]; then python3 -c "
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if 'enc_' in r['Name'] or 'copyBuffer' in r['Name']:
+        print(f\"{r['Name'][:110]:110s} calls {int(r['Calls']):5d}  average {float(r['AverageNs']) / 1e3:8.2f} us  min {float(r['MinNs']) / 1e3:7.2f}\")
+" "$f"; else echo "(no kernel stats: $(tail -1 /tmp/encp.log))"; fi
   cd $R
 done
 } > $O 2>&1

@@ -31,8 +31,9 @@ def main():
     lib.icd_debug_encoder_stamps.argtypes = [C.c_void_p, C.c_void_p]
     assert lib.icd_debug_encoder_stamps(es._small._h, buf) == 0
     st = np.array(buf, dtype=np.uint64).reshape(4, 8, 2).astype(np.int64)
-    names = ["QKV (LayerNorm prologue, 144 WG x 256)", "attention output (96 WG x 256)", "FFN up (LayerNorm prologue, GELU; 192 WG x 256)", "FFN down (192 WG x 1024)"]
-    labels = ["start -> loads issued", "-> loads landed", "-> LayerNorm prologue done", "-> MFMAs done", "-> barrier passed", "-> epilogue stored"]
+    names = ["QKV (LayerNorm folded in; 144 WG x 256, 48 operand loads per lane: four slabs)", "attention output (96 WG x 256)",
+             "FFN up (LayerNorm folded in, GELU; 192 WG x 256)", "FFN down (K split four ways: 192 WG x 256)"]
+    labels = ["first kernel argument -> loads issued", "-> loads landed", "-> MFMAs issued, statistics done", "-> partial sums in LDS", "-> barrier passed", "-> epilogue stored"]
     print(f"{ntok} tokens; per segment: shader-clock cycles, microseconds by the 100 MHz counter, and the clock they imply")
     for g in range(4):
         print(names[g])
