@@ -358,7 +358,7 @@ typedef struct {
     const float *const *w_down; const float *const *b_down;   /* output dense [hidden][inter] */
     const float *const *ln2_g;  const float *const *ln2_b;
 } icd_encoder_desc;
-#define ICD_ENCODER_MAX_TOKENS 128   /* packed tokens per call */
+#define ICD_ENCODER_MAX_TOKENS 256   /* packed tokens per call */
 #define ICD_ENCODER_MAX_SEQS 32      /* sequences per call */
 int icd_encoder_create(int32_t device, const icd_encoder_desc *desc, icd_encoder **out);
 /* ids: HOST int32, the sequences' token ids back to back (special tokens included); lengths: HOST int32 [nseq], each >= 1,

@@ -68,7 +68,7 @@ class _EncoderDesc(C.Structure):   # include/icd_search.h icd_encoder_desc
                 + [(name, C.POINTER(C.c_void_p)) for name in _ENC_LAYER_FIELDS])
 
 
-ENCODER_MAX_TOKENS = 128   # include/icd_search.h ICD_ENCODER_MAX_TOKENS
+ENCODER_MAX_TOKENS = 256   # include/icd_search.h ICD_ENCODER_MAX_TOKENS
 ENCODER_MAX_SEQS = 32      # ... ICD_ENCODER_MAX_SEQS
 
 

@@ -29,7 +29,7 @@
 //                       [CLS]) pooling and L2 normalisation, one work-group per sequence.
 //
 // Token ids, positions and sequence bounds come from a small descriptor in device memory (layout below) that the host
-// fills per call: the launches themselves depend only on the token BUCKET (16 / 32 / 64 / 128), so a forward is one replay
+// fills per call: the launches themselves depend only on the token BUCKET (16 / 32 / 64 / 128 / 256), so a forward is one replay
 // of a captured graph (icd_encoder.hpp). Arithmetic restated from transformers' BertModel - the published architecture
 // the reference reaches through sentence-transformers; the checkpoint's numerics are unpinned (no weights offline,
 // DESIGN.md section 7): the tests compare with the framework's fp32 forward of the same weights (1e-5).
@@ -39,7 +39,7 @@
 
 namespace icd {
 
-constexpr int ENC_TMAX = 128;   // packed tokens per call
+constexpr int ENC_TMAX = 256;   // packed tokens per call
 constexpr int ENC_BMAX = 32;    // sequences per call
 // descriptor (int32 words): [0] T, [1] B, then per token (TMAX each): id, position, first row of its sequence, length of its
 // sequence (0 past the call's tokens), then BMAX + 1 sequence starts (starts[b] = T for b >= B)
@@ -158,13 +158,13 @@ __device__ unsigned long long g_enc_first[8];   // diagnostic: clocks at the fir
 #define ENC_STAMP(i) do { } while (0)
 #define ENC_STAMP_DRAIN() do { } while (0)
 #endif
-// NT: output columns per work-group (grid = N / NT); a wave takes 192 columns of K (12 k-steps of 16), the block has K / 192 waves
-// (at most MAXW: 4 waves keep 512 registers each - the next token tile's operand rows are prefetched into them -, 16 keep 128);
+// NT: output columns per work-group (grid.x = N / NT x K slices, grid.y = token tiles of 16: the tiles of a longer input run
+// side by side on other CUs, each re-reading its slice of W from the caches); a wave takes 192 columns of K (12 k-steps of 16),
+// the block has at most MAXW waves;
 // EPI: 0 bias, 1 bias + erf-GELU (BertIntermediate), 2 bias + LayerNorm-ed residual; OUT_PA: y in operand order
 // NSLAB: the A operand is the sum of this many slabs
 template <int NT, int EPI, bool LNPRO, bool OUT_PA, int MAXW, int NSLAB>
 __global__ __launch_bounds__(MAXW * 64) void enc_linear_kernel(EncLinearArgs a) {
-    constexpr bool PREFETCH = MAXW <= 4 && NSLAB == 1;
     static_assert(NT == 16 || NT == 8 || NT == 4, "columns per work-group");
     constexpr int ITER = 12;
     __shared__ float red[16][256];
@@ -216,7 +216,8 @@ __global__ __launch_bounds__(MAXW * 64) void enc_linear_kernel(EncLinearArgs a) 
         for (int sl = 1; sl < a.res_nslab; ++sl) v += a.res_src[idx + (size_t)sl * a.slab];
         src = v; mean = a.res_stats[2 * t]; rstd = a.res_stats[2 * t + 1];
     };
-    load_tile(areg, 0);
+    const int t0 = (int)blockIdx.y * 16;   // this work-group's 16 tokens (grid.y = token tiles of the bucket)
+    load_tile(areg, (int)blockIdx.y);
     // the epilogue's operands of thread tid < 256: output (token 4 (l >> 4) + j, column l & 15), l = tid & 63, j = tid >> 6
     const int ej = tid >> 6, el = tid & 63;
     const int en = el & 15, et = 4 * (el >> 4) + ej;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(MAXW * 64) void enc_linear_kernel(EncLinearArgs a) 
         if constexpr (LNPRO) c1_v = a.c1[n0 + en];
         if constexpr (EPI == 2) {
             rg = a.res_g[n0 + en]; rb = a.res_b[n0 + en];
-            load_res(et, rsrc, rmean, rrstd);   // (tile 0)
+            load_res(t0 + et, rsrc, rmean, rrstd);
         }
     }
     const int T = a.meta[0];
@@ -236,20 +237,8 @@ __global__ __launch_bounds__(MAXW * 64) void enc_linear_kernel(EncLinearArgs a) 
     ENC_STAMP_DRAIN();
     ENC_STAMP(2);        // loads landed
 
-    for (int t0 = 0; t0 < T; t0 += 16) {
-        // the NEXT tile's operand rows travel while this one is worked on
-        float4 anext[ITER];   // (PREFETCH only)
-        float rsrc_n = 0.f, rmean_n = 0.f, rrstd_n = 0.f;
-        const bool more = t0 + 16 < T;   // (work-group-uniform)
-        if constexpr (PREFETCH) {
-            if (more) {
-                load_tile(anext, (t0 >> 4) + 1);
-                if constexpr (EPI == 2) {
-                    if (ecol) load_res(t0 + 16 + et, rsrc_n, rmean_n, rrstd_n);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+    if (t0 >= T) return;   // (work-group-uniform, before any barrier: a token tile past the call's tokens; its loads were harmless)
+    {
         enc_f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};   // (two chains: a dependent MFMA waits out the one before it)
 #pragma unroll
         for (int i = 0; i < ITER; i += 2) {
@@ -285,7 +274,6 @@ __global__ __launch_bounds__(MAXW * 64) void enc_linear_kernel(EncLinearArgs a) 
         }
         ENC_STAMP(3);    // MFMAs issued, statistics done
         // C[token 4 (lane >> 4) + j][column lane & 15] in register j
-        if (t0 > 0) __syncthreads();   // the previous tile's sums have been read
 #pragma unroll
         for (int j = 0; j < 4; ++j) red[wave][j * 64 + lane] = c0[j] + c1[j];
         if constexpr (LNPRO) {
@@ -324,19 +312,6 @@ __global__ __launch_bounds__(MAXW * 64) void enc_linear_kernel(EncLinearArgs a) 
         }
         ENC_STAMP_DRAIN();
         ENC_STAMP(6);    // epilogue stored
-        if (more) {
-            if constexpr (PREFETCH) {
-#pragma unroll
-                for (int i = 0; i < ITER; ++i) areg[i] = anext[i];
-                rsrc = rsrc_n; rmean = rmean_n; rrstd = rrstd_n;
-            } else {
-                load_tile(areg, (t0 >> 4) + 1);
-                if constexpr (EPI == 2) {
-                    if (ecol) load_res(t0 + 16 + et, rsrc, rmean, rrstd);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
     }
 }
 

@@ -3,7 +3,7 @@
 //
 // One forward = ONE graph launch: [descriptor H2D] -> embedding sum -> layers x (LayerNorm + QKV, attention, attention output
 // + residual, LayerNorm + FFN up + GELU, FFN down + residual) -> LayerNorm + pooling -> [result D2H into a pinned block]. The
-// graph depends on the token bucket (16 / 32 / 64 / 128: the grids of the per-token kernels) and the pooling flags only;
+// graph depends on the token bucket (16 / 32 / 64 / 128 / 256: the grids of the per-token kernels) and the pooling flags only;
 // token ids, positions and sequence bounds travel in the descriptor. Captured once per (bucket, pooling, normalize) on a
 // private stream, replayed on the caller's (a call made while the caller's stream is itself being captured is refused: the
 // token ids are read from host memory at call time).
@@ -28,7 +28,7 @@ struct icd_encoder {
     hipStream_t cap_stream = nullptr;
     hipEvent_t ev_done = nullptr;   // behind every launch: the next call may rewrite h_meta only after the copy node has run
     bool ev_pending = false;
-    static constexpr int NBUCKET = 4;   // 16, 32, 64, 128 tokens
+    static constexpr int NBUCKET = 5;   // 16, 32, 64, 128, 256 tokens
     hipGraphExec_t exec[NBUCKET][2][2][2] = {};   // [bucket][pooling][normalize][one sequence]
     unsigned long long *stamps = nullptr;   // diagnostic builds (ICD_ABLATE, env ICD_ENC_STAMPS=1): [4 GEMMs of layer 0][16] clock stamps
     std::mutex mu;
@@ -44,6 +44,7 @@ inline int enc_enqueue(icd_encoder *e, int bucket_tokens, int pooling, int norma
     const icd_encoder_desc &d = e->d;
     const int H = d.hidden, I = d.inter;
     const long long slab = (long long)ENC_TMAX * H;
+    const int tiles = bucket_tokens / 16;   // grid.y of the GEMMs: the 16-token tiles of the bucket side by side
     HIP_TRY(hipMemcpyAsync(e->d_meta, e->h_meta, ENC_META_WORDS * sizeof(int), hipMemcpyHostToDevice, s));
     {
         EncEmbedArgs a{};
@@ -60,8 +61,8 @@ inline int enc_enqueue(icd_encoder *e, int bucket_tokens, int pooling, int norma
             a.meta = e->d_meta; a.x = y0; a.ln_eps = d.ln_eps; a.stats_out = e->sA;
             a.w = e->w_qkv[l]; a.c1 = e->c1_qkv[l]; a.bias = e->c2_qkv[l]; a.y = e->qkv; a.K = H; a.N = 3 * H; a.stamps = (e->stamps && l == d.layers - 1) ? e->stamps : nullptr;
             a.nwk = H / 192; a.slab = slab; a.res_nslab = 1;
-            if (l == 0) hipLaunchKernelGGL((enc_linear_kernel<16, 0, true, false, 4, 1>), dim3(3 * H / 16), dim3(64 * (H / 192)), 0, s, a);   // (the embedding sum: one slab)
-            else hipLaunchKernelGGL((enc_linear_kernel<16, 0, true, false, 4, ENC_SLABS>), dim3(3 * H / 16), dim3(64 * (H / 192)), 0, s, a);
+            if (l == 0) hipLaunchKernelGGL((enc_linear_kernel<16, 0, true, false, 4, 1>), dim3(3 * H / 16, tiles), dim3(64 * (H / 192)), 0, s, a);   // (the embedding sum: one slab)
+            else hipLaunchKernelGGL((enc_linear_kernel<16, 0, true, false, 4, ENC_SLABS>), dim3(3 * H / 16, tiles), dim3(64 * (H / 192)), 0, s, a);
         }
         {
             EncAttnArgs a{};
@@ -74,14 +75,14 @@ inline int enc_enqueue(icd_encoder *e, int bucket_tokens, int pooling, int norma
             a.meta = e->d_meta; a.x = e->ctx; a.w = e->w_ao[l]; a.bias = e->b_ao[l];
             a.res_src = y0; a.res_stats = e->sA; a.res_g = pg; a.res_b = pb; a.y = y1; a.K = H; a.N = H; a.stamps = (e->stamps && l == d.layers - 1) ? e->stamps + 16 : nullptr;
             a.nwk = H / 192; a.slab = slab; a.res_nslab = l == 0 ? 1 : ENC_SLABS;
-            hipLaunchKernelGGL((enc_linear_kernel<8, 2, false, true, 4, 1>), dim3(H / 8), dim3(64 * (H / 192)), 0, s, a);
+            hipLaunchKernelGGL((enc_linear_kernel<8, 2, false, true, 4, 1>), dim3(H / 8, tiles), dim3(64 * (H / 192)), 0, s, a);
         }
         {   // mid = GELU(LayerNorm1(y1) Wup^T + b); statistics of LayerNorm1 in sB
             EncLinearArgs a{};
             a.meta = e->d_meta; a.x = y1; a.ln_eps = d.ln_eps; a.stats_out = e->sB;
             a.w = e->w_up[l]; a.c1 = e->c1_up[l]; a.bias = e->c2_up[l]; a.y = e->mid; a.K = H; a.N = I; a.stamps = (e->stamps && l == d.layers - 1) ? e->stamps + 32 : nullptr;
             a.nwk = H / 192; a.slab = slab; a.res_nslab = 1;
-            hipLaunchKernelGGL((enc_linear_kernel<16, 1, true, true, 4, 1>), dim3(I / 16), dim3(64 * (H / 192)), 0, s, a);
+            hipLaunchKernelGGL((enc_linear_kernel<16, 1, true, true, 4, 1>), dim3(I / 16, tiles), dim3(64 * (H / 192)), 0, s, a);
         }
         {   // y2 = mid Wdown^T + b + LayerNorm1(y1)   (BertOutput in front of its LayerNorm)
             EncLinearArgs a{};
@@ -89,7 +90,7 @@ inline int enc_enqueue(icd_encoder *e, int bucket_tokens, int pooling, int norma
             a.res_src = y1; a.res_stats = e->sB; a.res_g = e->ln1_g[l]; a.res_b = e->ln1_b[l]; a.y = y2; a.K = I; a.N = H; a.stamps = (e->stamps && l == d.layers - 1) ? e->stamps + 48 : nullptr;
             // K = inter split over ENC_SLABS work-groups of (inter / 192 / ENC_SLABS) waves per 16 output columns: partial sums into the slabs of y2
             a.nwk = I / 192; a.slab = slab; a.res_nslab = 1;
-            hipLaunchKernelGGL((enc_linear_kernel<16, 2, false, true, 4, 1>), dim3(H / 16 * ENC_SLABS), dim3(64 * (I / 192 / ENC_SLABS)), 0, s, a);
+            hipLaunchKernelGGL((enc_linear_kernel<16, 2, false, true, 4, 1>), dim3(H / 16 * ENC_SLABS, tiles), dim3(64 * (I / 192 / ENC_SLABS)), 0, s, a);
         }
         cur = (cur + 2) % 3;
         pg = e->ln2_g[l]; pb = e->ln2_b[l];
@@ -270,7 +271,7 @@ int icd_encoder_encode(icd_encoder *e, const int32_t *ids, const int32_t *length
     }
     for (int b = nseq; b <= ENC_BMAX; ++b) m[ENC_META_STARTS + b] = T;
     for (int u = T; u < ENC_TMAX; ++u) { m[ENC_META_TOK_R0 + u] = 0; m[ENC_META_TOK_LEN + u] = 0; }
-    const int bi = T <= 16 ? 0 : (T <= 32 ? 1 : (T <= 64 ? 2 : 3));
+    const int bi = T <= 16 ? 0 : (T <= 32 ? 1 : (T <= 64 ? 2 : (T <= 128 ? 3 : 4)));
     const int bucket = 16 << bi;
     const bool single = nseq == 1;
     hipGraphExec_t &gx = e->exec[bi][pooling][normalize][single ? 1 : 0];

@@ -122,7 +122,7 @@ class _TokenClassifier:
                 self._packed = _PackedBert(bert)
         except Exception as exc:   # pragma: no cover - an optimisation, never fatal
             logger.warning("packed NER forward unavailable (%s): padded batches", exc)
-        # one request's one to a few strings (<= 32 strings, <= 128 tokens in all): the hand-written small-input forward, ONE graph
+        # one request's one to a few strings (<= 32 strings, <= 256 tokens in all): the hand-written small-input forward, ONE graph
         # launch for the encoder (csrc/encoder_small.hpp through icd_encoder_encode), the classifier head over its packed last
         # hidden state. fp32 BERT-base shapes on a GPU; ICD_NER_SMALL=0 keeps the replayed graph of the framework's forward.
         self._small = None

@@ -24,7 +24,7 @@ def main():
     assert small is not None
     strings = [l.strip() for l in open(os.path.join(ROOT, "tests", "golden", "diagnosis_strings.txt"), encoding="utf-8") if l.strip()]
     cases = [("1 string, short (%d tokens)", [strings[0]]), ("1 string, long (%d tokens)", ["高血压" * 30]),
-             ("3 strings (%d tokens)", strings[1:4]), ("8 strings (%d tokens)", strings[4:12])]
+             ("3 strings (%d tokens)", strings[1:4]), ("8 strings (%d tokens)", strings[4:12]), ("14 strings (%d tokens)", strings[12:26])]
     for label, texts in cases:
         ntok = sum(len(x) for x in es._tokenize([f"query: {t}" for t in texts]))
         res = {}

@@ -48,7 +48,7 @@ def test_encode_query_graph_bucket_matches_cpu(services):
 
 
 def test_encode_query_through_the_replayed_framework_graph_matches_cpu(services, monkeypatch):
-    """ICD_EMBEDDING_SMALL=0 (and batches of <= 32 strings with more than 128 tokens in all): the framework's forward,
+    """ICD_EMBEDDING_SMALL=0 (and batches of <= 32 strings with more than 256 tokens in all): the framework's forward,
     replayed from a HIP graph per (batch, width) bucket"""
     gpu, cpu = services
     monkeypatch.setattr(gpu, "_small", None)
@@ -56,15 +56,15 @@ def test_encode_query_through_the_replayed_framework_graph_matches_cpu(services,
         a, b = gpu.encode_query(t), cpu.encode_query(t)
         assert np.max(np.abs(a - b)) <= TOL, t
     assert gpu._graphs, "the one-string path should have captured a HIP graph"
-    texts = _strings()[:20]                                                 # 20 strings, > 128 tokens: the graph buckets with the small encoder ON
+    texts = _strings()[:24]                                                 # 24 strings, > 256 tokens: the graph buckets with the small encoder ON
     monkeypatch.undo()
-    assert sum(len(x) for x in gpu._tokenize([f"query: {t}" for t in texts])) > 128
+    assert sum(len(x) for x in gpu._tokenize([f"query: {t}" for t in texts])) > 256
     a, b = gpu.encode_query_batch(texts, batch_size=32), cpu.encode_query_batch(texts, batch_size=32)
     assert np.max(np.abs(a - b)) <= TOL
 
 
 def test_small_input_encoder_matches_the_framework_forward(services):
-    """csrc/encoder_small.hpp through icd_encoder_encode: 1 ... 32 sequences, 1 ... 128 packed tokens, every token bucket and
+    """csrc/encoder_small.hpp through icd_encoder_encode: 1 ... 32 sequences, 1 ... 256 packed tokens, every token bucket and
     its edges - pooled rows (mean and [CLS], normalised or not) and the last hidden state of every token against
     transformers' padded BertModel forward of the same weights on the GPU (1e-5); host and device outputs identical; the
     descriptor's limits refused with a clear error."""
@@ -95,7 +95,7 @@ def test_small_input_encoder_matches_the_framework_forward(services):
         return pooled.cpu().numpy(), torch.nn.functional.normalize(pooled, p=2, dim=1).cpu().numpy(), rows.cpu().numpy()
 
     cases = [[1], [2], [3], [15], [16], [17], [31], [32], [33], [64], [65], [100], [128], [5, 9, 12, 30], [4] * 32, [1] * 32, [64, 64],
-             [17, 1, 40, 2, 23], [16, 16], [7] * 18, [100, 28]]
+             [17, 1, 40, 2, 23], [16, 16], [7] * 18, [100, 28], [129], [200], [130, 100], [8] * 32, [256], [90, 3, 128, 35]]
     for lengths in cases:
         ids = make(lengths)
         for pooling in ("mean", "cls"):
@@ -109,13 +109,13 @@ def test_small_input_encoder_matches_the_framework_forward(services):
             dev = enc.encode(ids, pooling=pooling, normalize=True, to_device=True)
             torch.cuda.synchronize()
             assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), got_unit)
-    with pytest.raises(_native.IcdError, match="128 tokens"):
-        enc.encode(make([100, 29]))
+    with pytest.raises(_native.IcdError, match="256 tokens"):
+        enc.encode(make([200, 57]))
     with pytest.raises(_native.IcdError, match="sequences per call"):
         enc.encode(make([2] * 33))
     with pytest.raises(_native.IcdError, match="vocabulary"):
         enc.encode([[101, vocab, 102]])
-    assert not enc.fits([100, 29]) and not enc.fits([2] * 33) and enc.fits([128]) and not enc.fits([])
+    assert not enc.fits([200, 57]) and not enc.fits([2] * 33) and enc.fits([256]) and not enc.fits([])
 
 
 def test_encode_batch_32_matches_cpu(services):

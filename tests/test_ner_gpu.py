@@ -78,7 +78,7 @@ def test_bert_base_classifier_small_input_forward_equals_the_framework_forward(m
             assert len(gl) == len(wl) == len(e[0])
             assert float(np.abs(gs - ws).max()) <= 5e-5
             assert np.mean(np.array(gl) == np.array(wl)) >= 0.9    # (random-init logits: near-ties may flip)
-    long_enc = [clf._encode("高血压" * 60)]
-    assert not small.fits([len(long_enc[0][0])])                  # more than 128 tokens: the framework's forward
+    long_enc = [clf._encode("高血压" * 100)]
+    assert not small.fits([len(long_enc[0][0])])                  # more than 256 tokens: the framework's forward
     assert len(clf._forward(long_enc)[0][0]) == len(long_enc[0][0])
     assert svc.extract_medical_entities_batch(strings[:3]) == [svc.extract_medical_entities(s) for s in strings[:3]]
