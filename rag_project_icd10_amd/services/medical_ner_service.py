@@ -245,7 +245,8 @@ class _TokenClassifier:
             with torch.no_grad():
                 _, hidden = self._small.encode([e[0] for e in encoded], to_device=True, hidden=True)
                 score, label = torch.softmax(self.model.classifier(hidden).float(), dim=-1).max(dim=-1)
-                score, label = score.cpu().numpy(), label.cpu().numpy()
+                both = torch.stack([score.double(), label.double()]).cpu().numpy()   # (one copy, one synchronisation; exact for both)
+                score, label = both[0].astype(np.float32), both[1].astype(np.int64)
             a = 0
             for i, e in enumerate(encoded):
                 b = a + len(e[0])
