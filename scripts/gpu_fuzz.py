@@ -49,14 +49,62 @@ def rows(rng, n, dim, kind):
     return np.ascontiguousarray(x, dtype=np.float32)
 
 
+def fuzz_encoder(args):
+    """--focus encoder: the small-input sentence encoder (csrc/encoder_small.hpp through icd_encoder_encode) against
+    transformers' padded fp32 forward of the same seeded BERT-base weights on the GPU: random numbers of sequences (1 ... 32) and
+    lengths (1 ... 256 packed tokens: every token bucket, sequences that straddle the 16-token tiles), mean and [CLS] pooling,
+    normalised or not, pooled rows and the last hidden state of every token; tolerance 1e-5 on unit rows."""
+    import torch
+    os.environ.setdefault("EMBEDDING_MODEL_NAME", "shibing624/text2vec-base-chinese")
+    from rag_project_icd10_amd.services.embedding_service import EmbeddingService
+    es = EmbeddingService(allow_synthetic=True, device="cuda")
+    enc = es._small
+    assert enc is not None, "the small-input encoder is not available"
+    rng = np.random.default_rng(args.seed)
+    vocab = es.model.bert.config.vocab_size
+    bad, t0 = 0, time.time()
+    for case in range(args.cases):
+        nseq = int(rng.choice([1, 1, 1, 2, 3, 5, 8, 13, 32]))
+        budget = int(rng.choice([16, 17, 32, 33, 64, 100, 128, 129, 200, 256]))
+        budget = max(budget, nseq)
+        cuts = np.sort(rng.choice(np.arange(1, budget), size=nseq - 1, replace=False)) if nseq > 1 else np.array([], dtype=np.int64)
+        lengths = np.diff(np.concatenate([[0], cuts, [budget]])).astype(int).tolist()
+        ids = [[101] + [int(v) for v in rng.integers(1000, vocab, size=n - 2)] + [102] if n >= 2 else [101] for n in lengths]
+        pooling = str(rng.choice(["mean", "cls"]))
+        width = max(lengths)
+        tok = torch.zeros((nseq, width), dtype=torch.long)
+        mask = torch.zeros((nseq, width), dtype=torch.long)
+        for r, x in enumerate(ids):
+            tok[r, :len(x)] = torch.tensor(x)
+            mask[r, :len(x)] = 1
+        tok, mask = tok.cuda(), mask.cuda()
+        with torch.no_grad():
+            hidden = es.model.bert(input_ids=tok, attention_mask=mask).last_hidden_state
+        m = mask.unsqueeze(-1).float()
+        pooled = hidden[:, 0] if pooling == "cls" else (hidden * m).sum(1) / m.sum(1)
+        want = torch.nn.functional.normalize(pooled, p=2, dim=1).cpu().numpy()
+        want_rows = torch.cat([hidden[r, :len(x)] for r, x in enumerate(ids)], 0).cpu().numpy()
+        got, rows_ = enc.encode(ids, pooling=pooling, normalize=True, hidden=True)
+        d1, d2 = float(np.max(np.abs(got - want))), float(np.max(np.abs(rows_.cpu().numpy() - want_rows)))
+        again = enc.encode(ids, pooling=pooling, normalize=True)
+        ok = d1 <= 1e-5 and d2 <= 5e-5 and np.array_equal(again, got)
+        if not ok:
+            bad += 1
+            print(f"FAIL case {case}: lengths {lengths} pooling {pooling}: max |d pooled| {d1:.2e}, max |d hidden| {d2:.2e}, replay equal {np.array_equal(again, got)}", flush=True)
+    print(f"gpu_fuzz --focus encoder: {args.cases - bad} ok, {bad} failed in {time.time() - t0:.1f} s (seed {args.seed})", flush=True)
+    return 1 if bad else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=7)
-    ap.add_argument("--focus", choices=["", "exact_k", "one_query"], default="",
+    ap.add_argument("--focus", choices=["", "exact_k", "one_query", "encoder"], default="",
                     help="exact_k: mostly ICD_MODE_EXACT at k = 33 ... 100 on batches the narrow certified lists take (round 5); "
                          "one_query: mostly one or two queries per call at k <= 16 (the single-launch streaming kernel)")
     args = ap.parse_args()
+    if args.focus == "encoder":
+        sys.exit(fuzz_encoder(args))
     import oracle as orc
     from rag_project_icd10_amd import _native
     from rag_project_icd10_amd._native import MODE_AUTO, MODE_EXACT, IcdIndex
