@@ -353,21 +353,16 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(EncAttnArgs a) {
     const float *kb = a.qkv + (size_t)r0 * ld + a.H + (size_t)h * ATT_HEAD_DIM + lane;
     const float *vb = kb + a.H;
     float m_run = -INFINITY, l_run = 0.f, o_run = 0.f;
-    auto load_chunk = [&](float (&kd)[CH], float (&vd)[CH], int k0) {
-        const int last = min(CH, L - k0) - 1;
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const size_t row = (size_t)(k0 + min(j, last)) * ld;
-            kd[j] = kb[row];
-            vd[j] = vb[row];
-        }
-    };
-    if constexpr (!SINGLE) load_chunk(kreg, vreg, 0);
     for (int k0 = 0; k0 < L; k0 += CH) {
         const int Lc = min(CH, L - k0);
-        float knext[CH], vnext[CH];   // the next chunk's rows travel while this one is worked on
-        const bool more = k0 + CH < L;   // (wave-uniform)
-        if (more) load_chunk(knext, vnext, k0 + CH);
+        if (!SINGLE || k0 > 0) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const size_t row = (size_t)(k0 + min(j, Lc - 1)) * ld;
+                kreg[j] = kb[row];
+                vreg[j] = vb[row];
+            }
+        }
         float sc[CH];
         float m = m_run;
 #pragma unroll
@@ -384,10 +379,6 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(EncAttnArgs a) {
             o = fmaf(e, vreg[j], o);
         }
         m_run = m; l_run = l; o_run = o;
-        if (more) {
-#pragma unroll
-            for (int j = 0; j < CH; ++j) { kreg[j] = knext[j]; vreg[j] = vnext[j]; }
-        }
     }
     a.out[enc_pa(t, h * ATT_HEAD_DIM + lane, a.H)] = o_run / l_run;
 }
