@@ -345,7 +345,7 @@ int icd_debug_unpack_query_slices(int32_t device, const void *gathered, int32_t 
  * the caller keeps those alive and unchanged while the handle lives. */
 typedef struct icd_encoder icd_encoder;
 typedef struct {
-    int32_t layers, hidden, heads, inter;   /* hidden = heads * 64 = 768; inter a multiple of 768, at most 3072 */
+    int32_t layers, hidden, heads, inter;   /* hidden = heads * 64 = 768 or 1024; inter a multiple of hidden, at most 4 hidden */
     int32_t vocab, max_pos;                 /* rows of word_emb / pos_emb */
     int32_t pos_offset;                     /* position of a sequence's first token: 0 (BERT), padding_idx + 1 (RoBERTa / XLM-R) */
     float ln_eps;

@@ -565,8 +565,8 @@ class SmallEncoder:
             import torch
             return (type(bert).__name__ in ("BertModel", "XLMRobertaModel", "RobertaModel") and p.is_cuda and p.dtype == torch.float32
                     and getattr(cfg, "position_embedding_type", None) in (None, "absolute") and getattr(cfg, "hidden_act", "gelu") == "gelu"
-                    and not getattr(cfg, "is_decoder", False) and int(cfg.hidden_size) == 768 and int(cfg.hidden_size) // int(cfg.num_attention_heads) == 64
-                    and int(cfg.intermediate_size) % 768 == 0 and int(cfg.intermediate_size) <= 3072)
+                    and not getattr(cfg, "is_decoder", False) and int(cfg.hidden_size) in (768, 1024) and int(cfg.hidden_size) // int(cfg.num_attention_heads) == 64
+                    and int(cfg.intermediate_size) % int(cfg.hidden_size) == 0 and int(cfg.hidden_size) <= int(cfg.intermediate_size) <= 4 * int(cfg.hidden_size))
         except Exception:
             return False
 

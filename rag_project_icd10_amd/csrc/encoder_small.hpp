@@ -55,22 +55,23 @@ typedef float enc_f32x4 __attribute__((ext_vector_type(4)));
 // lines, ~40 cycles of the CU's address unit each - 24 such loads per wave were 2.2 of a GEMM kernel's 7.7 us (clock stamps,
 // profiles/r05_encoder_small.log). So every matrix a GEMM reads is STORED in the order its loads want it:
 //   activations [T][K] (K = 192 x waves): element (t, k) at ((((t / 16 * K / 192 + w) * 12 + i) * 4 + kq) * 16 + t % 16) * 4 + c
-//       with w = k / 192, i = k % 192 / 16, kq = k % 16 / 4, c = k % 4
+//       with w = k / 192, i = k % 192 / 16, kq = k % 16 / 4, c = k % 4      (192 = the columns a wave takes; 256 at hidden 1 024)
 //       - lane (r, kq) of wave w reads step i of token tile t / 16 at  base + (i * 64 + lane) * 16 bytes: ONE KB, contiguous;
 //   weights [N][K] in tiles of NT rows: the same with NT in place of 16 and the row tile n / NT in place of t / 16.
 // Producers (the embedding sum, the GEMM epilogues, the attention) scatter their few values per thread into that order.
-__host__ __device__ __forceinline__ size_t enc_pa(int t, int k, int K) {
-    const int w = k / 192, kk = k - w * 192;
-    return ((((size_t)(t >> 4) * (K / 192) + w) * 12 + (kk >> 4)) * 4 + ((kk >> 2) & 3)) * 64 + (size_t)(t & 15) * 4 + (kk & 3);
+// KW = the columns of K a wave takes: 192 for hidden 768 / inter 3 072 (12 k-steps of 16), 256 for hidden 1 024 / inter 4 096 (16)
+__host__ __device__ __forceinline__ size_t enc_pa(int t, int k, int K, int KW) {
+    const int w = k / KW, kk = k - w * KW;
+    return ((((size_t)(t >> 4) * (K / KW) + w) * (KW >> 4) + (kk >> 4)) * 4 + ((kk >> 2) & 3)) * 64 + (size_t)(t & 15) * 4 + (kk & 3);
 }
-__host__ __device__ __forceinline__ size_t enc_pw(int n, int k, int K, int NT) {
-    const int w = k / 192, kk = k - w * 192;
-    return ((((size_t)(n / NT) * (K / 192) + w) * 12 + (kk >> 4)) * 4 + ((kk >> 2) & 3)) * (size_t)(NT * 4) + (size_t)(n % NT) * 4 + (kk & 3);
+__host__ __device__ __forceinline__ size_t enc_pw(int n, int k, int K, int NT, int KW) {
+    const int w = k / KW, kk = k - w * KW;
+    return ((((size_t)(n / NT) * (K / KW) + w) * (KW >> 4) + (kk >> 4)) * 4 + ((kk >> 2) & 3)) * (size_t)(NT * 4) + (size_t)(n % NT) * 4 + (kk & 3);
 }
 
 // one-time: a torch.nn.Linear weight [N][K] row-major -> the NT-row-tile order above (16 bytes per thread), its columns
 // optionally scaled by a LayerNorm weight (LNPRO below: W' = W diag(g))
-__global__ __launch_bounds__(256) void enc_permute_w_kernel(const float *src, const float *colscale, float *dst, int N, int K, int NT) {
+__global__ __launch_bounds__(256) void enc_permute_w_kernel(const float *src, const float *colscale, float *dst, int N, int K, int NT, int KW) {
     const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;   // float4 index in the source
     if (g >= (size_t)N * K / 4) return;
     const int n = (int)(g / (K / 4)), k = (int)(g % (K / 4)) * 4;
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void enc_permute_w_kernel(const float *src, co
         const float4 sc = *reinterpret_cast<const float4 *>(colscale + k);
         v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
     }
-    *reinterpret_cast<float4 *>(dst + enc_pw(n, k, K, NT)) = v;
+    *reinterpret_cast<float4 *>(dst + enc_pw(n, k, K, NT, KW)) = v;
 }
 // one-time, for a Linear that reads a LayerNorm's output, LN(x) W^T + bias = rstd (x (W diag g)^T - mean c1) + c2 with
 //   c1[n] = sum_k g[k] W[n][k]        c2[n] = sum_k b[k] W[n][k] + bias[n]          (sums in double); one wave per n
@@ -106,7 +107,7 @@ __device__ __forceinline__ float enc_wave_sum(float v) {
 struct EncEmbedArgs {
     const int *meta;
     const float *word, *pos, *type0;   // embeddings [vocab][H], [max_pos][H], token type 0 [H]
-    int H;
+    int H, KW;
     float *y;   // [TMAX][H] pre-norm, operand order
 };
 // y[t] = (word[id] + type0) + pos[p] (BertEmbeddings in front of its LayerNorm): one wave per token
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void enc_embed_kernel(EncEmbedArgs a) {
         const float4 pe = *reinterpret_cast<const float4 *>(a.pos + p * a.H + c);
         float4 v;
         v.x = (w.x + ty.x) + pe.x; v.y = (w.y + ty.y) + pe.y; v.z = (w.z + ty.z) + pe.z; v.w = (w.w + ty.w) + pe.w;
-        *reinterpret_cast<float4 *>(a.y + enc_pa(t, c, a.H)) = v;
+        *reinterpret_cast<float4 *>(a.y + enc_pa(t, c, a.H, a.KW)) = v;
     }
 }
 
@@ -159,14 +160,14 @@ __device__ unsigned long long g_enc_first[8];   // diagnostic: clocks at the fir
 #define ENC_STAMP_DRAIN() do { } while (0)
 #endif
 // NT: output columns per work-group (grid.x = N / NT x K slices, grid.y = token tiles of 16: the tiles of a longer input run
-// side by side on other CUs, each re-reading its slice of W from the caches); a wave takes 192 columns of K (12 k-steps of 16),
-// the block has at most MAXW waves;
+// side by side on other CUs, each re-reading its slice of W from the caches); a wave takes 16 ITER columns of K (ITER = 12: hidden
+// 768, 16: hidden 1 024), the block has at most MAXW waves;
 // EPI: 0 bias, 1 bias + erf-GELU (BertIntermediate), 2 bias + LayerNorm-ed residual; OUT_PA: y in operand order
 // NSLAB: the A operand is the sum of this many slabs
-template <int NT, int EPI, bool LNPRO, bool OUT_PA, int MAXW, int NSLAB>
+template <int ITER, int NT, int EPI, bool LNPRO, bool OUT_PA, int MAXW, int NSLAB>
 __global__ __launch_bounds__(MAXW * 64) void enc_linear_kernel(EncLinearArgs a) {
     static_assert(NT == 16 || NT == 8 || NT == 4, "columns per work-group");
-    constexpr int ITER = 12;
+    constexpr int KW = 16 * ITER;   // this wave's columns of K
     __shared__ float red[16][256];
     __shared__ float lnred[2][16][16];   // LNPRO: per wave and row, the slice's mean and centred sum of squares
     const int tid = threadIdx.x, lane = tid & 63;
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(MAXW * 64) void enc_linear_kernel(EncLinearArgs a) 
         }
     };
     auto load_res = [&](int t, float &src, float &mean, float &rstd) {   // residual operands of (token t, this thread's column)
-        const size_t idx = enc_pa(t, n0 + (tid & 15), a.N);
+        const size_t idx = enc_pa(t, n0 + (tid & 15), a.N, KW);
         float v = a.res_src[idx];
         for (int sl = 1; sl < a.res_nslab; ++sl) v += a.res_src[idx + (size_t)sl * a.slab];
         src = v; mean = a.res_stats[2 * t]; rstd = a.res_stats[2 * t + 1];
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(MAXW * 64) void enc_linear_kernel(EncLinearArgs a) 
             if constexpr (EPI == 1) s = 0.5f * s * (1.0f + erff(s * 0.70710678118654752440f));
             if (t0 + et < T) {
                 float *yo = a.y + (size_t)ks * a.slab;
-                if constexpr (OUT_PA) yo[enc_pa(t0 + et, n0 + en, a.N)] = s;
+                if constexpr (OUT_PA) yo[enc_pa(t0 + et, n0 + en, a.N, KW)] = s;
                 else yo[(size_t)(t0 + et) * a.N + n0 + en] = s;
             }
         }
@@ -319,7 +320,7 @@ struct EncAttnArgs {
     const int *meta;
     const float *qkv;   // [TMAX][3 H] row-major: Q | K | V of a token side by side
     float *out;         // [TMAX][H] operand order
-    int H, heads;
+    int H, heads, KW;
     float scale;        // 1 / sqrt(64)
 };
 // softmax(q K^T scale) V for ONE (token, head) per wave, lane = head dimension d: every key and value row of the sequence is
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(EncAttnArgs a) {
         }
         m_run = m; l_run = l; o_run = o;
     }
-    a.out[enc_pa(t, h * ATT_HEAD_DIM + lane, a.H)] = o_run / l_run;
+    a.out[enc_pa(t, h * ATT_HEAD_DIM + lane, a.H, a.KW)] = o_run / l_run;
 }
 
 struct EncPoolArgs {
@@ -388,7 +389,7 @@ struct EncPoolArgs {
     const float *y;        // [TMAX][H] pre-norm output of the last layer, operand order
     const float *g, *b;    // its LayerNorm
     float eps;
-    int H;                 // 768
+    int H, KW;             // H = 256 NV
     int pooling;           // 0: mean over the sequence's tokens, 1: its first token ([CLS])
     int normalize;         // 1: L2-normalise (torch.nn.functional.normalize, eps 1e-12)
     float *out;            // [BMAX][H]
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(ENC_POOL_WAVES * 64) void enc_pool_kernel(EncPoolAr
         float4 v[NV];
 #pragma unroll
         for (int j = 0; j < NV; ++j) {   // (every load of the row in flight before the first add)
-            const size_t idx = enc_pa(r, 4 * (lane + 64 * j), a.H);
+            const size_t idx = enc_pa(r, 4 * (lane + 64 * j), a.H, a.KW);
             float4 u[NSLAB];
 #pragma unroll
             for (int sl = 0; sl < NSLAB; ++sl) u[sl] = *reinterpret_cast<const float4 *>(a.y + idx + (size_t)sl * a.slab);

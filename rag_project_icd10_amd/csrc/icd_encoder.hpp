@@ -40,7 +40,10 @@ inline bool enc_valid(const icd_encoder *e) { return e && e->magic == ENC_MAGIC;
 
 // the launches of one forward on stream s (inside a capture): the descriptor H2D in front, the pooled rows' D2H behind
 constexpr int ENC_SLABS = 4;   // K slices of the FFN-down GEMM = slabs of its output
-inline int enc_enqueue(icd_encoder *e, int bucket_tokens, int pooling, int normalize, bool single, hipStream_t s) {
+// ITER: 16-column k-steps per wave (12: hidden 768 / inter 3 072, 16: hidden 1 024 / inter 4 096); NV = hidden / 256
+template <int ITER, int NV>
+inline int enc_enqueue_t(icd_encoder *e, int bucket_tokens, int pooling, int normalize, bool single, hipStream_t s) {
+    constexpr int KW = 16 * ITER;
     const icd_encoder_desc &d = e->d;
     const int H = d.hidden, I = d.inter;
     const long long slab = (long long)ENC_TMAX * H;
@@ -48,8 +51,8 @@ inline int enc_enqueue(icd_encoder *e, int bucket_tokens, int pooling, int norma
     HIP_TRY(hipMemcpyAsync(e->d_meta, e->h_meta, ENC_META_WORDS * sizeof(int), hipMemcpyHostToDevice, s));
     {
         EncEmbedArgs a{};
-        a.meta = e->d_meta; a.word = d.word_emb; a.pos = d.pos_emb; a.type0 = d.type_emb0; a.H = H; a.y = e->yb[0];
-        hipLaunchKernelGGL(enc_embed_kernel<3>, dim3((bucket_tokens + 3) / 4), dim3(256), 0, s, a);
+        a.meta = e->d_meta; a.word = d.word_emb; a.pos = d.pos_emb; a.type0 = d.type_emb0; a.H = H; a.KW = KW; a.y = e->yb[0];
+        hipLaunchKernelGGL(enc_embed_kernel<NV>, dim3((bucket_tokens + 3) / 4), dim3(256), 0, s, a);
     }
     // y[cur]: the PRE-norm output of the previous sublayer, (pg, pb) the LayerNorm it still has to go through
     int cur = 0;
@@ -60,13 +63,13 @@ inline int enc_enqueue(icd_encoder *e, int bucket_tokens, int pooling, int norma
             EncLinearArgs a{};
             a.meta = e->d_meta; a.x = y0; a.ln_eps = d.ln_eps; a.stats_out = e->sA;
             a.w = e->w_qkv[l]; a.c1 = e->c1_qkv[l]; a.bias = e->c2_qkv[l]; a.y = e->qkv; a.K = H; a.N = 3 * H; a.stamps = (e->stamps && l == d.layers - 1) ? e->stamps : nullptr;
-            a.nwk = H / 192; a.slab = slab; a.res_nslab = 1;
-            if (l == 0) hipLaunchKernelGGL((enc_linear_kernel<16, 0, true, false, 4, 1>), dim3(3 * H / 16, tiles), dim3(64 * (H / 192)), 0, s, a);   // (the embedding sum: one slab)
-            else hipLaunchKernelGGL((enc_linear_kernel<16, 0, true, false, 4, ENC_SLABS>), dim3(3 * H / 16, tiles), dim3(64 * (H / 192)), 0, s, a);
+            a.nwk = H / KW; a.slab = slab; a.res_nslab = 1;
+            if (l == 0) hipLaunchKernelGGL((enc_linear_kernel<ITER, 16, 0, true, false, 4, 1>), dim3(3 * H / 16, tiles), dim3(64 * (H / KW)), 0, s, a);   // (the embedding sum: one slab)
+            else hipLaunchKernelGGL((enc_linear_kernel<ITER, 16, 0, true, false, 4, ENC_SLABS>), dim3(3 * H / 16, tiles), dim3(64 * (H / KW)), 0, s, a);
         }
         {
             EncAttnArgs a{};
-            a.meta = e->d_meta; a.qkv = e->qkv; a.out = e->ctx; a.H = H; a.heads = d.heads; a.scale = 0.125f;
+            a.meta = e->d_meta; a.qkv = e->qkv; a.out = e->ctx; a.H = H; a.heads = d.heads; a.KW = KW; a.scale = 0.125f;
             if (single) hipLaunchKernelGGL(enc_attention_kernel<true>, dim3((bucket_tokens * d.heads + 3) / 4), dim3(256), 0, s, a);
             else hipLaunchKernelGGL(enc_attention_kernel<false>, dim3((bucket_tokens * d.heads + 3) / 4), dim3(256), 0, s, a);
         }
@@ -74,36 +77,41 @@ inline int enc_enqueue(icd_encoder *e, int bucket_tokens, int pooling, int norma
             EncLinearArgs a{};
             a.meta = e->d_meta; a.x = e->ctx; a.w = e->w_ao[l]; a.bias = e->b_ao[l];
             a.res_src = y0; a.res_stats = e->sA; a.res_g = pg; a.res_b = pb; a.y = y1; a.K = H; a.N = H; a.stamps = (e->stamps && l == d.layers - 1) ? e->stamps + 16 : nullptr;
-            a.nwk = H / 192; a.slab = slab; a.res_nslab = l == 0 ? 1 : ENC_SLABS;
-            hipLaunchKernelGGL((enc_linear_kernel<8, 2, false, true, 4, 1>), dim3(H / 8, tiles), dim3(64 * (H / 192)), 0, s, a);
+            a.nwk = H / KW; a.slab = slab; a.res_nslab = l == 0 ? 1 : ENC_SLABS;
+            hipLaunchKernelGGL((enc_linear_kernel<ITER, 8, 2, false, true, 4, 1>), dim3(H / 8, tiles), dim3(64 * (H / KW)), 0, s, a);
         }
         {   // mid = GELU(LayerNorm1(y1) Wup^T + b); statistics of LayerNorm1 in sB
             EncLinearArgs a{};
             a.meta = e->d_meta; a.x = y1; a.ln_eps = d.ln_eps; a.stats_out = e->sB;
             a.w = e->w_up[l]; a.c1 = e->c1_up[l]; a.bias = e->c2_up[l]; a.y = e->mid; a.K = H; a.N = I; a.stamps = (e->stamps && l == d.layers - 1) ? e->stamps + 32 : nullptr;
-            a.nwk = H / 192; a.slab = slab; a.res_nslab = 1;
-            hipLaunchKernelGGL((enc_linear_kernel<16, 1, true, true, 4, 1>), dim3(I / 16, tiles), dim3(64 * (H / 192)), 0, s, a);
+            a.nwk = H / KW; a.slab = slab; a.res_nslab = 1;
+            hipLaunchKernelGGL((enc_linear_kernel<ITER, 16, 1, true, true, 4, 1>), dim3(I / 16, tiles), dim3(64 * (H / KW)), 0, s, a);
         }
         {   // y2 = mid Wdown^T + b + LayerNorm1(y1)   (BertOutput in front of its LayerNorm)
             EncLinearArgs a{};
             a.meta = e->d_meta; a.x = e->mid; a.w = e->w_down[l]; a.bias = e->b_down[l];
             a.res_src = y1; a.res_stats = e->sB; a.res_g = e->ln1_g[l]; a.res_b = e->ln1_b[l]; a.y = y2; a.K = I; a.N = H; a.stamps = (e->stamps && l == d.layers - 1) ? e->stamps + 48 : nullptr;
             // K = inter split over ENC_SLABS work-groups of (inter / 192 / ENC_SLABS) waves per 16 output columns: partial sums into the slabs of y2
-            a.nwk = I / 192; a.slab = slab; a.res_nslab = 1;
-            hipLaunchKernelGGL((enc_linear_kernel<16, 2, false, true, 4, 1>), dim3(H / 16 * ENC_SLABS, tiles), dim3(64 * (I / 192 / ENC_SLABS)), 0, s, a);
+            a.nwk = I / KW; a.slab = slab; a.res_nslab = 1;
+            hipLaunchKernelGGL((enc_linear_kernel<ITER, 16, 2, false, true, 4, 1>), dim3(H / 16 * ENC_SLABS, tiles), dim3(64 * (I / KW / ENC_SLABS)), 0, s, a);
         }
         cur = (cur + 2) % 3;
         pg = e->ln2_g[l]; pb = e->ln2_b[l];
     }
     {   // the last LayerNorm, pooling, normalisation; the last hidden state of every token into x
         EncPoolArgs a{};
-        a.meta = e->d_meta; a.y = e->yb[cur]; a.g = pg; a.b = pb; a.eps = d.ln_eps; a.H = H; a.pooling = pooling; a.normalize = normalize;
+        a.meta = e->d_meta; a.y = e->yb[cur]; a.g = pg; a.b = pb; a.eps = d.ln_eps; a.H = H; a.KW = KW; a.pooling = pooling; a.normalize = normalize;
         a.out = e->pooled; a.hidden = e->x; a.slab = slab;
-        hipLaunchKernelGGL((enc_pool_kernel<3, ENC_SLABS>), dim3(ENC_BMAX), dim3(ENC_POOL_WAVES * 64), 0, s, a);
+        hipLaunchKernelGGL((enc_pool_kernel<NV, ENC_SLABS>), dim3(ENC_BMAX), dim3(ENC_POOL_WAVES * 64), 0, s, a);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e->h_out, e->pooled, (size_t)ENC_BMAX * H * sizeof(float), hipMemcpyDeviceToHost, s));
     return ICD_OK;
+}
+
+inline int enc_enqueue(icd_encoder *e, int bucket_tokens, int pooling, int normalize, bool single, hipStream_t s) {
+    return e->d.hidden == 1024 ? enc_enqueue_t<16, 4>(e, bucket_tokens, pooling, normalize, single, s)
+                               : enc_enqueue_t<12, 3>(e, bucket_tokens, pooling, normalize, single, s);
 }
 
 inline void enc_free(icd_encoder *e) {
@@ -131,9 +139,10 @@ int icd_encoder_create(int32_t device, const icd_encoder_desc *desc, icd_encoder
     const icd_encoder_desc &d = *desc;
     if (d.layers < 1 || d.layers > 48) return fail(ICD_ERR_INVALID, "layers=%d", d.layers);
     if (d.heads < 1 || d.hidden != d.heads * ATT_HEAD_DIM) return fail(ICD_ERR_UNSUPPORTED, "hidden=%d heads=%d (this encoder is written for 64-wide heads)", d.hidden, d.heads);
-    // enc_linear_kernel: K = 192 per wave, at most 16 waves; the LayerNorm kernels: 3 x 256 columns
-    if (d.hidden != 768) return fail(ICD_ERR_UNSUPPORTED, "hidden=%d (the small-input encoder is instantiated for 768)", d.hidden);
-    if (d.inter < 768 || d.inter % 768 != 0 || d.inter > 3072) return fail(ICD_ERR_UNSUPPORTED, "inter=%d (a multiple of 768, at most 3072: four K slices of at most four waves)", d.inter);
+    // enc_linear_kernel: four waves cover the hidden size (192 or 256 columns of K each); embed / pool: 3 or 4 x 256 columns
+    if (d.hidden != 768 && d.hidden != 1024) return fail(ICD_ERR_UNSUPPORTED, "hidden=%d (the small-input encoder is instantiated for 768 and 1024)", d.hidden);
+    const int kw = d.hidden == 1024 ? 256 : 192;   // columns of K per wave (four waves cover the hidden size)
+    if (d.inter < 4 * kw || d.inter % (4 * kw) != 0 || d.inter > 16 * kw) return fail(ICD_ERR_UNSUPPORTED, "inter=%d (a multiple of %d, at most %d: four K slices of at most four waves)", d.inter, 4 * kw, 16 * kw);
     if (d.vocab < 1 || d.max_pos < 1 || d.pos_offset < 0 || d.pos_offset >= d.max_pos) return fail(ICD_ERR_INVALID, "vocab=%d max_pos=%d pos_offset=%d", d.vocab, d.max_pos, d.pos_offset);
     if (!(d.ln_eps > 0.0f)) return fail(ICD_ERR_INVALID, "ln_eps=%g", (double)d.ln_eps);
     if (!d.word_emb || !d.pos_emb || !d.type_emb0 || !d.emb_ln_g || !d.emb_ln_b) return fail(ICD_ERR_INVALID, "an embedding pointer is NULL");
@@ -172,7 +181,7 @@ int icd_encoder_create(int32_t device, const icd_encoder_desc *desc, icd_encoder
             hipError_t er = hipMalloc(reinterpret_cast<void **>(dst), (size_t)N * K * sizeof(float));
             if (er != hipSuccess) return er;
             const size_t groups = (size_t)N * K / 4;
-            hipLaunchKernelGGL(enc_permute_w_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, nullptr, src, colscale, *dst, N, K, NT);
+            hipLaunchKernelGGL(enc_permute_w_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, nullptr, src, colscale, *dst, N, K, NT, kw);
             return hipGetLastError();
         };
         auto fold = [&](const float *w, const float *g, const float *b, const float *bias, float **c1, float **c2, int N, int K) -> hipError_t {

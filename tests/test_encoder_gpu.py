@@ -315,3 +315,44 @@ def test_split_bf16x3_kernel_makes_the_documented_operand():
         want = torch.nn.functional.gelu(x)
         got = g[:, :cols].float() + g[:, 2 * cols:3 * cols].float()
         assert ((got - want).abs() <= 2.0 ** -15 * want.abs() + 1e-30).all()
+
+
+@pytest.mark.parametrize("family", ["bert", "xlm-roberta"])
+def test_small_input_encoder_at_hidden_1024(family):
+    """the reference's CODE-default encoder is 1024-d (multilingual-e5-large: XLM-R large, services/embedding_service.py:26): the
+    small-input forward at hidden 1024 / 16 heads / inter 4096 (256 columns of K per wave), BERT and XLM-R flavours (positions
+    from padding_idx + 1, one token type), two seeded layers, against transformers' forward on the GPU"""
+    import torch
+    from transformers import BertConfig, BertModel, XLMRobertaConfig, XLMRobertaModel
+    from rag_project_icd10_amd import _native
+    torch.manual_seed(11)
+    if family == "bert":
+        model = BertModel(BertConfig(vocab_size=3000, hidden_size=1024, num_hidden_layers=2, num_attention_heads=16, intermediate_size=4096,
+                                     max_position_embeddings=512), add_pooling_layer=False)
+    else:
+        model = XLMRobertaModel(XLMRobertaConfig(vocab_size=3000, hidden_size=1024, num_hidden_layers=2, num_attention_heads=16, intermediate_size=4096,
+                                                 max_position_embeddings=514, type_vocab_size=1, pad_token_id=1, layer_norm_eps=1e-5), add_pooling_layer=False)
+    model = model.eval().cuda()
+    assert _native.SmallEncoder.supported(model)
+    enc = _native.SmallEncoder(model)
+    rng = np.random.default_rng(3)
+    try:
+        for lengths in ([1], [9], [16], [17], [40], [5, 11, 30], [3] * 20, [100, 60, 90], [256]):
+            ids = [[int(v) for v in rng.integers(5, 3000, size=n)] for n in lengths]
+            width = max(lengths)
+            tok = torch.full((len(ids), width), 1, dtype=torch.long)
+            mask = torch.zeros((len(ids), width), dtype=torch.long)
+            for r, x in enumerate(ids):
+                tok[r, :len(x)] = torch.tensor(x)
+                mask[r, :len(x)] = 1
+            with torch.no_grad():
+                hidden = model(input_ids=tok.cuda(), attention_mask=mask.cuda()).last_hidden_state
+            m = mask.cuda().unsqueeze(-1).float()
+            want = torch.nn.functional.normalize((hidden * m).sum(1) / m.sum(1), p=2, dim=1).cpu().numpy()
+            want_rows = torch.cat([hidden[r, :len(x)] for r, x in enumerate(ids)], 0).cpu().numpy()
+            got, rows = enc.encode(ids, pooling="mean", normalize=True, hidden=True)
+            assert got.shape == (len(ids), 1024)
+            assert np.max(np.abs(got - want)) <= TOL, (family, lengths)
+            assert np.max(np.abs(rows.cpu().numpy() - want_rows)) <= 5e-5, (family, lengths)
+    finally:
+        enc.close()
