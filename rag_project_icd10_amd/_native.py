@@ -559,8 +559,8 @@ class SmallEncoder:
 
     @staticmethod
     def supported(bert) -> bool:
-        cfg = bert.config
         try:
+            cfg = bert.config
             p = bert.embeddings.word_embeddings.weight
             import torch
             return (type(bert).__name__ in ("BertModel", "XLMRobertaModel", "RobertaModel") and p.is_cuda and p.dtype == torch.float32

@@ -55,3 +55,27 @@ def test_argument_validation_needs_no_gpu():
     assert lib.icd_index_create(buf.ctypes.data, 2, 64, None, 0, 0, 1, 500, 0, ctypes.byref(out)) == -1  # max_k
     assert lib.icd_index_destroy(None) == -5 and lib.icd_index_stats(None, None) == -5
     assert lib.icd_merge_topk(0, None, None, None, 1, 1, 1, None, None, None, None, None) == -1
+
+
+def test_encoder_argument_validation_needs_no_gpu():
+    """icd_encoder_*: the checks that need no device - NULL descriptor, shapes the small-input forward is not instantiated for,
+    NULL weight pointers, invalid handles - answer with a status and a message before any HIP call"""
+    lib = _native.load_library()
+    h = ctypes.c_void_p()
+    assert lib.icd_encoder_create(0, None, ctypes.byref(h)) == -1 and not h.value          # ICD_ERR_INVALID
+    d = _native._EncoderDesc()
+    d.layers, d.hidden, d.heads, d.inter, d.vocab, d.max_pos, d.pos_offset, d.ln_eps = 12, 512, 8, 2048, 1000, 512, 0, 1e-12
+    assert lib.icd_encoder_create(0, ctypes.byref(d), ctypes.byref(h)) == -4               # ICD_ERR_UNSUPPORTED
+    assert b"768 and 1024" in lib.icd_last_error()
+    d.hidden, d.heads, d.inter = 768, 12, 1000
+    assert lib.icd_encoder_create(0, ctypes.byref(d), ctypes.byref(h)) == -4 and b"inter=1000" in lib.icd_last_error()
+    d.inter = 3072
+    assert lib.icd_encoder_create(0, ctypes.byref(d), ctypes.byref(h)) == -1 and b"embedding pointer is NULL" in lib.icd_last_error()
+    d.heads = 16
+    assert lib.icd_encoder_create(0, ctypes.byref(d), ctypes.byref(h)) == -4 and b"64-wide heads" in lib.icd_last_error()
+    assert lib.icd_encoder_destroy(None) == -5
+    ids = np.array([101, 102], np.int32)
+    lens = np.array([2], np.int32)
+    out = np.zeros(768, np.float32)
+    assert lib.icd_encoder_encode(None, ids.ctypes.data, lens.ctypes.data, 1, 0, 1, out.ctypes.data, 0, None, None) == -5
+    assert not _native.SmallEncoder.supported(object())
