@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define ICD_ABI_VERSION 5   /* 5: icd_debug_unpack_query_slices, icd_debug_set_stream_one, icd_debug_set_pacing, icd_debug_set_exact_narrow, icd_debug_set_host_one, icd_split_bf16x3, icd_encoder_create / _encode / _destroy (round 5). 4: icd_debug_set_family_order, icd_debug_set_center, icd_stats.centered / mean_share appended, icd_group_prepare / icd_group_connect (round 4). 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
+#define ICD_ABI_VERSION 5   /* 5: icd_debug_unpack_query_slices, icd_debug_set_stream_one, icd_debug_set_pacing, icd_debug_set_exact_narrow, icd_debug_set_host_one, icd_split_bf16x3, icd_encoder_create / _encode / _destroy, icd_pack_winners (round 5). 4: icd_debug_set_family_order, icd_debug_set_center, icd_stats.centered / mean_share appended, icd_group_prepare / icd_group_connect (round 4). 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
 #define ICD_MAX_K 128
 
 typedef struct icd_index icd_index;
@@ -234,6 +234,15 @@ int icd_hier_rescore(int32_t device, const double *adj, const int64_t *ids, int6
  */
 int icd_score_stats(int32_t device, const double *scores, const int32_t *order, int64_t nq, int32_t k, int32_t use,
                     double *out, void *stream);
+
+/* The winners of a rescored batch for the host in ONE array (row N2: what MultiDiagnosisService.match_diagnoses_batch turns into
+ * Candidate objects - reference services/multi_diagnosis_service.py:147-176 builds them from the rescored hit dicts): for the
+ * top kk <= k positions of every query, out[c][q][j] (doubles, c = 0 .. 7) = id, raw score and level-reweighted score of the hit
+ * order[q][j] points at, order[q][j] itself, and enhanced / vector-similarity / hierarchy-boost / uncertainty-boost [q][j] of
+ * icd_hier_rescore's outputs. One launch and one device-to-host copy instead of three gathers, five slices and eight copies.
+ * All pointers device; order int32 [nq][k], ids int64 [nq][k], raw float32 [nq][k], the rest float64 [nq][k]; out [8][nq][kk]. */
+int icd_pack_winners(int32_t device, const int32_t *order, const int64_t *ids, const float *raw, const double *adj, const double *enhanced,
+                     const double *vs, const double *hb, const double *boost, int64_t nq, int32_t k, int32_t kk, double *out, void *stream);
 
 /* SURVEY.md row N3, semantic coherence. Replaces sklearn cosine_similarity([q], [c])[0][0] in
  * MultiDimensionalConfidenceService._calculate_semantic_factors (:273-280) for nq query vectors at once: rows

@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = (
     "icd_cosine_rows",
     "icd_index_set_second_pass",
     "icd_group_unique_id", "icd_group_create", "icd_group_prepare", "icd_group_connect", "icd_group_search", "icd_group_destroy",
-    "icd_debug_unpack_query_slices", "icd_debug_set_stream_one", "icd_debug_set_host_one", "icd_debug_set_pacing", "icd_debug_set_exact_narrow", "icd_split_bf16x3", "icd_encoder_create", "icd_encoder_encode", "icd_encoder_destroy",
+    "icd_debug_unpack_query_slices", "icd_debug_set_stream_one", "icd_debug_set_host_one", "icd_debug_set_pacing", "icd_debug_set_exact_narrow", "icd_split_bf16x3", "icd_encoder_create", "icd_encoder_encode", "icd_encoder_destroy", "icd_pack_winners",
 )
 GROUP_ROW_SHARD = 0
 GROUP_QUERY_SHARD = 1
@@ -126,6 +126,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.icd_encoder_destroy.argtypes = [vp]
     lib.icd_hier_rescore.argtypes = [i32, vp, vp, i64, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.icd_score_stats.argtypes = [i32, vp, vp, i64, i32, i32, vp, vp]
+    lib.icd_pack_winners.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp]
     lib.icd_cosine_rows.argtypes = [i32, vp, vp, i64, i64, i32, vp, vp]
     lib.icd_index_debug_counters.argtypes = [vp, vp, i32]
     lib.icd_index_set_profiling.argtypes = [vp, i32]
@@ -494,6 +495,21 @@ def hier_rescore(adj, ids, row_tags, q_params, weights, id_base: int = 0):
                                      row_tags.data_ptr(), q_params.data_ptr(), C.cast(w, C.c_void_p), order.data_ptr(),
                                      *[t.data_ptr() for t in outs], _current_stream_ptr(dev.index)))
     return (order, *outs)
+
+
+def pack_winners(order, ids, raw, adj, enhanced, vs, hb, boost, kk: int):
+    """The top kk rescored hits of every query as ONE float64 tensor [8, nq, kk] on the device (icd_pack_winners): id, raw score,
+    level-reweighted score (of the hit order points at), order, enhanced, vector similarity, hierarchy boost, uncertainty boost."""
+    import torch
+    lib = load_library()
+    nq, k = order.shape
+    dev = order.device
+    order = order.to(torch.int32).contiguous(); ids = ids.to(torch.int64).contiguous(); raw = raw.to(torch.float32).contiguous()
+    f64 = [t.to(torch.float64).contiguous() for t in (adj, enhanced, vs, hb, boost)]
+    out = torch.empty((8, nq, kk), dtype=torch.float64, device=dev)
+    _check(lib, lib.icd_pack_winners(dev.index, order.data_ptr(), ids.data_ptr(), raw.data_ptr(), *[t.data_ptr() for t in f64],
+                                     nq, k, kk, out.data_ptr(), _current_stream_ptr(dev.index)))
+    return out
 
 
 def score_stats(scores, order=None, use=None):

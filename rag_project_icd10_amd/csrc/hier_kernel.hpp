@@ -167,4 +167,31 @@ __global__ __launch_bounds__(256) void hier_rescore_kernel(HierArgs a) {
 }
 #pragma clang fp contract(fast)
 
+// The winners of a batch for the host: what MultiDiagnosisService.match_diagnoses_batch needs of the top `kk` rescored hits of
+// every query, as ONE array of doubles [8][nq][kk] (one device-to-host copy; exact for the int64 ids, the int32 order and the
+// float32 raw scores alike): 0 id, 1 raw score, 2 level-reweighted score (both of the hit the order points at), 3 order,
+// 4 enhanced, 5 vector similarity, 6 hierarchy boost, 7 uncertainty boost (the last four already in final order).
+struct PackWinnersArgs {
+    const int *order; const long long *ids; const float *raw; const double *adj, *enh, *vs, *hb, *boost;
+    int nq, k, kk;
+    double *out;
+};
+__global__ __launch_bounds__(256) void pack_winners_kernel(PackWinnersArgs a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long per = (long long)a.nq * a.kk;
+    if (i >= per) return;
+    const int q = (int)(i / a.kk), j = (int)(i - (long long)q * a.kk);
+    const size_t src = (size_t)q * a.k + j;
+    const int o = a.order[src];
+    const size_t hit = (size_t)q * a.k + (o < 0 ? 0 : o);   // (past the hits: a valid slot, the host stops at order < 0)
+    a.out[0 * per + i] = (double)a.ids[hit];
+    a.out[1 * per + i] = (double)a.raw[hit];
+    a.out[2 * per + i] = a.adj[hit];
+    a.out[3 * per + i] = (double)o;
+    a.out[4 * per + i] = a.enh[src];
+    a.out[5 * per + i] = a.vs[src];
+    a.out[6 * per + i] = a.hb[src];
+    a.out[7 * per + i] = a.boost[src];
+}
+
 }  // namespace icd

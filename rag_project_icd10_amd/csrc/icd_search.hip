@@ -1530,6 +1530,21 @@ int icd_hier_rescore(int32_t device, const double *adj, const int64_t *ids, int6
     return ICD_OK;
 }
 
+int icd_pack_winners(int32_t device, const int32_t *order, const int64_t *ids, const float *raw, const double *adj, const double *enhanced,
+                     const double *vs, const double *hb, const double *boost, int64_t nq, int32_t k, int32_t kk, double *out, void *stream) {
+    if (!order || !ids || !raw || !adj || !enhanced || !vs || !hb || !boost || !out) return fail(ICD_ERR_INVALID, "pointer is NULL");
+    if (k <= 0 || kk <= 0 || kk > k || nq < 0 || nq > 0x7FFFFFFF) return fail(ICD_ERR_INVALID, "nq=%lld k=%d kk=%d", (long long)nq, k, kk);
+    if (nq == 0) return ICD_OK;
+    HIP_TRY(hipSetDevice(device));
+    PackWinnersArgs a{};
+    a.order = order; a.ids = reinterpret_cast<const long long *>(ids); a.raw = raw; a.adj = adj; a.enh = enhanced; a.vs = vs; a.hb = hb; a.boost = boost;
+    a.nq = (int)nq; a.k = k; a.kk = kk; a.out = out;
+    const long long per = (long long)nq * kk;
+    hipLaunchKernelGGL(pack_winners_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    HIP_TRY(hipGetLastError());
+    return ICD_OK;
+}
+
 int icd_score_stats(int32_t device, const double *scores, const int32_t *order, int64_t nq, int32_t k, int32_t use,
                     double *out, void *stream) {
     if (!scores || !out) return fail(ICD_ERR_INVALID, "pointer is NULL");

@@ -170,11 +170,15 @@ class MultiDiagnosisService:
         # winners only: gather on the device, one copy to the host, plain Python lists for the object loop
         import torch
         kk = min(top_k, order.shape[1])
-        o = order[:, :kk].long().clamp(min=0)
         # (ONE copy: eight .tolist() calls were eight stream synchronisations, ~20 us each - a fifth of a one-diagnosis request.
         #  Everything travels as float64: exact for the int32 / int64 row indices and the float32 scores alike)
-        packed = torch.stack([torch.gather(ids, 1, o).double(), torch.gather(raw, 1, o).double(), torch.gather(adj, 1, o).double()]
-                             + [t[:, :kk].double() for t in (order, enh, vs, hb, boost)], 0).cpu()
+        if adj.is_cuda:
+            from .. import _native
+            packed = _native.pack_winners(order, ids, raw, adj, enh, vs, hb, boost, kk).cpu()   # (one launch: gathers, slices, stack)
+        else:
+            o = order[:, :kk].long().clamp(min=0)
+            packed = torch.stack([torch.gather(ids, 1, o).double(), torch.gather(raw, 1, o).double(), torch.gather(adj, 1, o).double()]
+                                 + [t[:, :kk].double() for t in (order, enh, vs, hb, boost)], 0)
         h_ids, h_ord = packed[0].long().tolist(), packed[3].long().tolist()
         h_raw, h_adj, h_enh, h_vs, h_hb, h_boost = (packed[i].tolist() for i in (1, 2, 4, 5, 6, 7))
         recs = self.milvus_service.client.records
