@@ -434,12 +434,13 @@ class EmbeddingService:
     def _encode_prepared(self, texts: List[str], batch_size: int, to_device: bool = False):
         """texts already carry their prefix. Returns float32 [n, dim] (numpy, or a tensor on self.device)."""
         n = len(texts)
-        out = torch.empty((n, self._dim), dtype=torch.float32, device=self.device)
         if n == 0:
+            out = torch.empty((0, self._dim), dtype=torch.float32, device=self.device)
             return out if to_device else out.cpu().numpy()
         ids = self._tokenize(texts)
         if self._small is not None and self._small.fits([len(x) for x in ids]):
             return self._small.encode(ids, pooling=self.pooling, normalize=True, to_device=to_device)
+        out = torch.empty((n, self._dim), dtype=torch.float32, device=self.device)
         order = sorted(range(n), key=lambda i: -len(ids[i]))  # length buckets: least padding per batch
         if self._packed is not None and batch_size > self._GRAPH_BATCHES[-1] and n > self._GRAPH_BATCHES[-1]:
             # chunks of at most PACK_TOKENS tokens (activation memory: ~40 KB per token in fp32), longest strings first
