@@ -9,13 +9,14 @@
 // one launch costs MORE than a boundary, 4-7 us, so this is not a persistent kernel). This file is that forward as FIVE
 // launches per layer, all fp32, the LayerNorms folded into their consumers:
 //
-//   enc_linear_kernel   Y = act(A W^T + b) (+ R): one work-group per NT (16, 8 or 4) output columns, its waves split K (192
-//                       columns each). A wave issues ALL its loads up front - its NT x 192 slice of W (12 x 16 B per lane:
-//                       the whole slice in flight at once), the first 16 tokens' operand rows, LayerNorm parameters - so
-//                       that the kernel is one memory round trip deep, then takes the tokens 16 at a time through
-//                       v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate: exact products; the sum's order differs from the
-//                       vendor GEMM's like any two GEMMs differ); the waves' partial sums meet in LDS, where bias and
-//                       erf-GELU are applied.
+//   enc_linear_kernel   Y = act(A W^T + b) (+ R): one work-group per NT (16 or 8) output columns and 16 tokens (grid.y: the token
+//                       tiles of a longer input side by side), its four waves split K (192 columns each; 256 at hidden 1 024). A
+//                       wave issues ALL its loads up front - its NT x 192 slice of W (12 x 16 B per lane: the whole slice in
+//                       flight at once) and its tokens' operand rows - so that the kernel is one memory round trip deep, then
+//                       runs v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate: exact products; the sum's order differs from the
+//                       vendor GEMM's like any two GEMMs differ); the waves' partial sums meet in LDS, where bias, erf-GELU and
+//                       the residual are applied. Operands are STORED in the order these loads want them (enc_pa / enc_pw);
+//                       the FFN-down GEMM splits K over four work-groups whose partial sums its readers add up (slabs).
 //       LNPRO           A = LayerNorm(X) without touching X: LN(x) W^T + b = rstd (x (W diag g)^T - mean c1) + c2 with c1, c2
 //                       and W diag(g) made once (enc_fold_ln_kernel). The MFMAs run on the PRE-norm rows of the previous
 //                       sublayer the moment they land; mean and 1/std of a row come from the same registers (the work-group's
@@ -23,8 +24,8 @@
 //                       barrier of the kernel. Work-group 0 leaves the two numbers per token for ...
 //       EPI == 2        ... the residual of the next GEMM (BertSelfOutput / BertOutput: dense(x) + LayerNorm-ed input),
 //                       rebuilt from the pre-norm row and those two numbers. No normalised activation is ever stored.
-//   enc_attention_kernel  softmax(q K^T / 8) V, one wave per (token, head): K rows and V columns of the sequence in
-//                       registers (the arithmetic of attention_kernel.hpp, one query per wave instead of a loop over them).
+//   enc_attention_kernel  softmax(q K^T / 8) V, one wave per (token, head), lane = head dimension: every key / value row one
+//                       coalesced 256-B load, a score one wave-wide sum (DPP), the softmax on wave-uniform numbers.
 //   enc_embed_kernel    (word + type) + position, pre-norm.        enc_pool_kernel   the last LayerNorm, masked-mean (or
 //                       [CLS]) pooling and L2 normalisation, one work-group per sequence.
 //
