@@ -1205,6 +1205,55 @@ def test_a_host_callers_one_query_in_the_kernel_arguments_and_the_polled_complet
         idx.close()
 
 
+def test_one_query_host_calls_stay_exact_beside_a_busy_gpu(oracle):
+    """the polled completion of a host caller's one query gives up after 0.5 ms and waits for the stream instead: with large
+    batches of ANOTHER index running on another stream from another thread, one-query host calls (their kernel queued behind
+    0.3-ms coarse launches) take both exits - every result stays exact, and the batches' too"""
+    import threading
+    import torch
+    dim = 768
+    corpus_a, levels_a = unit_rows(20000, dim, 301), icd_levels(20000, 302)
+    corpus_b, levels_b = unit_rows(20000, dim, 303), icd_levels(20000, 304)
+    qa = unit_rows(48, dim, 305)
+    qb = unit_rows(6000, dim, 306)
+    want_s, want_i = oracle.flat_ip_topk(corpus_a, qa, 10)
+    wb_s, wb_i = oracle.flat_ip_topk(corpus_b, qb[:64], 10)
+    ia = IcdIndex(corpus_a, levels_a, max_nq=64, max_k=16)
+    ib = IcdIndex(corpus_b, levels_b, max_nq=6000, max_k=16)
+    stop, errors, batches = threading.Event(), [], [0]
+
+    def load():
+        try:
+            st = torch.cuda.Stream()
+            dq = torch.from_numpy(qb).cuda()
+            with torch.cuda.stream(st):
+                while not stop.is_set():
+                    s, i = ib.search(dq, 10)
+                    st.synchronize()
+                    batches[0] += 1
+                    if batches[0] % 50 == 0 and not (np.array_equal(i[:64].cpu().numpy(), wb_i) and _bits(s[:64].cpu().numpy()) == _bits(wb_s)):
+                        errors.append("batch result differs")
+        except Exception as exc:   # pragma: no cover
+            errors.append(repr(exc))
+    th = threading.Thread(target=load)
+    th.start()
+    try:
+        import time
+        t_end, calls = time.time() + 30.0, 0
+        while (batches[0] < 40 or calls < 400) and time.time() < t_end and not errors:
+            j = calls % 48
+            s, i = ia.search(qa[j:j + 1], 10)
+            assert np.array_equal(i, want_i[j:j + 1]) and _bits(s) == _bits(want_s[j:j + 1]), (calls, j)
+            calls += 1
+    finally:
+        stop.set()
+        th.join(timeout=60)
+        ia.close()
+        ib.close()
+    assert not errors, errors
+    assert batches[0] >= 20, batches[0]
+
+
 @pytest.mark.parametrize("k", [33, 50, 64, 100])
 def test_exact_mode_above_k32_runs_certified_narrow_lists_and_stays_exact(oracle, k):
     """ICD_MODE_EXACT at k > 32 (the k range /query can ask for: top_k * 2 with top_k <= 50, models/icd_models.py:138,
