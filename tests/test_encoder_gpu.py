@@ -356,3 +356,37 @@ def test_small_input_encoder_at_hidden_1024(family):
             assert np.max(np.abs(rows.cpu().numpy() - want_rows)) <= 5e-5, (family, lengths)
     finally:
         enc.close()
+
+
+def test_small_input_encoder_from_several_threads(services):
+    """FastAPI serves /embed and /query from a thread pool: calls on one handle are serialised by the library (its descriptor and
+    result blocks are per handle); four threads x 60 calls of different strings, host and device outputs mixed, give what one
+    thread gives"""
+    import threading
+    import torch
+    gpu, _ = services
+    texts = _strings()[:24]
+    want = [gpu.encode_query(t) for t in texts]
+    errors = []
+
+    def work(seed):
+        try:
+            rng = np.random.default_rng(seed)
+            for _ in range(60):
+                j = int(rng.integers(0, len(texts)))
+                if rng.random() < 0.5:
+                    got = gpu.encode_query(texts[j])
+                else:
+                    got = gpu.encode_query_batch([texts[j]], to_device=True)
+                    torch.cuda.synchronize()
+                    got = got[0].cpu().numpy()
+                if not np.array_equal(got, want[j]):
+                    errors.append((seed, j, float(np.max(np.abs(got - want[j])))))
+        except Exception as exc:   # pragma: no cover
+            errors.append(repr(exc))
+    threads = [threading.Thread(target=work, args=(s,)) for s in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors[:5]
