@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define ICD_ABI_VERSION 5   /* 5: icd_debug_unpack_query_slices, icd_debug_set_stream_one, icd_debug_set_pacing, icd_debug_set_exact_narrow, icd_debug_set_host_one, icd_split_bf16x3, icd_encoder_create / _encode / _destroy, icd_pack_winners (round 5). 4: icd_debug_set_family_order, icd_debug_set_center, icd_stats.centered / mean_share appended, icd_group_prepare / icd_group_connect (round 4). 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
+#define ICD_ABI_VERSION 6   /* 6: icd_encoder_encode_many; ICD_ENCODER_MAX_TOKENS 512, ICD_ENCODER_MAX_SEQS 64 (round 6). 5: icd_debug_unpack_query_slices, icd_debug_set_stream_one, icd_debug_set_pacing, icd_debug_set_exact_narrow, icd_debug_set_host_one, icd_split_bf16x3, icd_encoder_create / _encode / _destroy, icd_pack_winners (round 5). 4: icd_debug_set_family_order, icd_debug_set_center, icd_stats.centered / mean_share appended, icd_group_prepare / icd_group_connect (round 4). 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
 #define ICD_MAX_K 128
 
 typedef struct icd_index icd_index;
@@ -367,8 +367,8 @@ typedef struct {
     const float *const *w_down; const float *const *b_down;   /* output dense [hidden][inter] */
     const float *const *ln2_g;  const float *const *ln2_b;
 } icd_encoder_desc;
-#define ICD_ENCODER_MAX_TOKENS 256   /* packed tokens per call */
-#define ICD_ENCODER_MAX_SEQS 32      /* sequences per call */
+#define ICD_ENCODER_MAX_TOKENS 512   /* packed tokens per call: any ONE sequence a BERT-style encoder takes fits */
+#define ICD_ENCODER_MAX_SEQS 64      /* sequences per call */
 int icd_encoder_create(int32_t device, const icd_encoder_desc *desc, icd_encoder **out);
 /* ids: HOST int32, the sequences' token ids back to back (special tokens included); lengths: HOST int32 [nseq], each >= 1,
  * their sum <= ICD_ENCODER_MAX_TOKENS. pooling 0 = mean over a sequence's tokens, 1 = its first token; normalize 1 =
@@ -377,6 +377,15 @@ int icd_encoder_create(int32_t device, const icd_encoder_desc *desc, icd_encoder
  * that receives the last hidden state of every token (token classification heads). Calls on one handle are serialised. */
 int icd_encoder_encode(icd_encoder *e, const int32_t *ids, const int32_t *lengths, int32_t nseq, int32_t pooling, int32_t normalize,
                        float *out, int32_t out_on_device, float *hidden_out, void *stream);
+/* ANY number of sequences through the same kernels, in calls of at most ICD_ENCODER_MAX_TOKENS tokens / ICD_ENCODER_MAX_SEQS
+ * sequences cut greedily in the given order. The arithmetic of a sequence does not depend on what else shares its call
+ * (every reduction runs over the sequence's own tokens in an order fixed by the kernels), so out[i] equals BIT FOR BIT what
+ * icd_encoder_encode returns for sequence i alone: the reference embeds corpus rows and queries through the same one-string
+ * call (tools/build_database.py:217-222, services/embedding_service.py:117-120) - identical text, identical vector - and this
+ * is how a corpus build or a batch of queries keeps that property. lengths[i] in 1 .. min(ICD_ENCODER_MAX_TOKENS, max_pos -
+ * pos_offset). out: [nseq][hidden] fp32, device (enqueued on `stream`, no synchronisation) or host (returns when filled). */
+int icd_encoder_encode_many(icd_encoder *e, const int32_t *ids, const int32_t *lengths, int64_t nseq, int32_t pooling, int32_t normalize,
+                            float *out, int32_t out_on_device, void *stream);
 int icd_encoder_destroy(icd_encoder *e);
 
 /* Diagnostic builds only (make ABLATE=1, env ICD_FLAT_VAR with bit 1024): per-wave cycle sums of the coarse kernel,

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libicdsearch.so")
 MODE_AUTO = 0   # fp16-MFMA coarse pass + certified exact rescoring (+ exact fallback); same results as EXACT
 MODE_EXACT = 1  # fp32-MFMA kernel only
 MAX_K = 128
-ABI_VERSION = 5   # include/icd_search.h ICD_ABI_VERSION: a stale libicdsearch.so is refused with a clear message
+ABI_VERSION = 6   # include/icd_search.h ICD_ABI_VERSION: a stale libicdsearch.so is refused with a clear message
 
 EXPORTED_SYMBOLS = (
     "icd_abi_version", "icd_last_error", "icd_device_count", "icd_index_create", "icd_index_destroy",
@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = (
     "icd_cosine_rows",
     "icd_index_set_second_pass",
     "icd_group_unique_id", "icd_group_create", "icd_group_prepare", "icd_group_connect", "icd_group_search", "icd_group_destroy",
-    "icd_debug_unpack_query_slices", "icd_debug_set_stream_one", "icd_debug_set_host_one", "icd_debug_set_pacing", "icd_debug_set_exact_narrow", "icd_split_bf16x3", "icd_encoder_create", "icd_encoder_encode", "icd_encoder_destroy", "icd_pack_winners",
+    "icd_debug_unpack_query_slices", "icd_debug_set_stream_one", "icd_debug_set_host_one", "icd_debug_set_pacing", "icd_debug_set_exact_narrow", "icd_split_bf16x3", "icd_encoder_create", "icd_encoder_encode", "icd_encoder_encode_many", "icd_encoder_destroy", "icd_pack_winners",
 )
 GROUP_ROW_SHARD = 0
 GROUP_QUERY_SHARD = 1
@@ -68,8 +68,8 @@ class _EncoderDesc(C.Structure):   # include/icd_search.h icd_encoder_desc
                 + [(name, C.POINTER(C.c_void_p)) for name in _ENC_LAYER_FIELDS])
 
 
-ENCODER_MAX_TOKENS = 256   # include/icd_search.h ICD_ENCODER_MAX_TOKENS
-ENCODER_MAX_SEQS = 32      # ... ICD_ENCODER_MAX_SEQS
+ENCODER_MAX_TOKENS = 512   # include/icd_search.h ICD_ENCODER_MAX_TOKENS
+ENCODER_MAX_SEQS = 64      # ... ICD_ENCODER_MAX_SEQS
 
 
 class _Profile(C.Structure):
@@ -123,6 +123,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.icd_packed_attention.argtypes = [i32, vp, i64, vp, i32, i32, i32, i32, vp, i64, vp]
     lib.icd_encoder_create.argtypes = [i32, C.POINTER(_EncoderDesc), C.POINTER(vp)]
     lib.icd_encoder_encode.argtypes = [vp, vp, vp, i32, i32, i32, vp, i32, vp, vp]
+    lib.icd_encoder_encode_many.argtypes = [vp, vp, vp, i64, i32, i32, vp, i32, vp]
     lib.icd_encoder_destroy.argtypes = [vp]
     lib.icd_hier_rescore.argtypes = [i32, vp, vp, i64, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.icd_score_stats.argtypes = [i32, vp, vp, i64, i32, i32, vp, vp]
@@ -658,6 +659,25 @@ class SmallEncoder:
                                                       1 if normalize else 0, optr, 1 if to_device else 0,
                                                       hid.data_ptr() if hidden else None, _current_stream_ptr(self.device)))
         return (out, hid) if hidden else out
+
+    def fits_each(self, lengths) -> bool:
+        """every sequence fits a call of its own: encode_many takes the list whatever its size"""
+        return len(lengths) > 0 and 1 <= min(lengths) and max(lengths) <= ENCODER_MAX_TOKENS
+
+    def encode_many(self, ids, pooling: str = "mean", normalize: bool = True, to_device: bool = False):
+        """ANY number of sequences (each of at most ENCODER_MAX_TOKENS tokens) through the same kernels, cut into calls by the
+        library (icd_encoder_encode_many): row i equals encode([ids[i]]) BIT FOR BIT - the arithmetic of a sequence does not
+        depend on what shares its call. -> float32 [n, hidden], numpy or (to_device) a CUDA tensor on the current stream."""
+        import torch
+        if not getattr(self, "_h", None) or not self._h.value:
+            raise IcdError(-5, "encoder is closed")
+        n = len(ids)
+        lengths = np.fromiter((len(x) for x in ids), dtype=np.int32, count=n)
+        flat = np.fromiter((t for x in ids for t in x), dtype=np.int32, count=int(lengths.sum()))
+        out = torch.empty((n, self.hidden), dtype=torch.float32, device=torch.device("cuda", self.device))
+        _check(self._lib, self._lib.icd_encoder_encode_many(self._h, flat.ctypes.data, lengths.ctypes.data, n, 1 if pooling == "cls" else 0,
+                                                           1 if normalize else 0, out.data_ptr(), 1, _current_stream_ptr(self.device)))
+        return out if to_device else out.cpu().numpy()
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -30,7 +30,7 @@
 //                       [CLS]) pooling and L2 normalisation, one work-group per sequence.
 //
 // Token ids, positions and sequence bounds come from a small descriptor in device memory (layout below) that the host
-// fills per call: the launches themselves depend only on the token BUCKET (16 / 32 / 64 / 128 / 256), so a forward is one replay
+// fills per call: the launches themselves depend only on the token BUCKET (16 / 32 / 64 / 128 / 256 / 512), so a forward is one replay
 // of a captured graph (icd_encoder.hpp). Arithmetic restated from transformers' BertModel - the published architecture
 // the reference reaches through sentence-transformers; the checkpoint's numerics are unpinned (no weights offline,
 // DESIGN.md section 7): the tests compare with the framework's fp32 forward of the same weights (1e-5).
@@ -40,8 +40,8 @@
 
 namespace icd {
 
-constexpr int ENC_TMAX = 256;   // packed tokens per call
-constexpr int ENC_BMAX = 32;    // sequences per call
+constexpr int ENC_TMAX = 512;   // packed tokens per call (any ONE sequence a BERT-style encoder takes fits: max_position_embeddings 512)
+constexpr int ENC_BMAX = 64;    // sequences per call
 // descriptor (int32 words): [0] T, [1] B, then per token (TMAX each): id, position, first row of its sequence, length of its
 // sequence (0 past the call's tokens), then BMAX + 1 sequence starts (starts[b] = T for b >= B)
 constexpr int ENC_META_IDS = 2, ENC_META_POS = 2 + ENC_TMAX, ENC_META_TOK_R0 = 2 + 2 * ENC_TMAX, ENC_META_TOK_LEN = 2 + 3 * ENC_TMAX;

@@ -28,8 +28,14 @@ struct icd_encoder {
     hipStream_t cap_stream = nullptr;
     hipEvent_t ev_done = nullptr;   // behind every launch: the next call may rewrite h_meta only after the copy node has run
     bool ev_pending = false;
-    static constexpr int NBUCKET = 5;   // 16, 32, 64, 128, 256 tokens
-    hipGraphExec_t exec[NBUCKET][2][2][2] = {};   // [bucket][pooling][normalize][one sequence]
+    static constexpr int NBUCKET = 6;   // 16, 32, 64, 128, 256, 512 tokens
+    hipGraphExec_t exec[NBUCKET][2][2][2][2] = {};   // [bucket][pooling][normalize][one sequence][with the descriptor / result copy nodes]
+    // icd_encoder_encode_many: the descriptors of consecutive calls come from a ring of pinned blocks, copied to d_meta on the
+    // caller's stream in front of a graph WITHOUT copy nodes - the host fills call i + 1 ... i + RING - 1 while call i runs
+    static constexpr int RING = 8;
+    int *h_ring[RING] = {};
+    hipEvent_t ev_ring[RING] = {};      // recorded behind the H2D copy of the slot: the slot may be refilled once it has run
+    bool ring_pending[RING] = {};
     unsigned long long *stamps = nullptr;   // diagnostic builds (ICD_ABLATE, env ICD_ENC_STAMPS=1): [4 GEMMs of layer 0][16] clock stamps
     std::mutex mu;
 };
@@ -42,13 +48,13 @@ inline bool enc_valid(const icd_encoder *e) { return e && e->magic == ENC_MAGIC;
 constexpr int ENC_SLABS = 4;   // K slices of the FFN-down GEMM = slabs of its output
 // ITER: 16-column k-steps per wave (12: hidden 768 / inter 3 072, 16: hidden 1 024 / inter 4 096); NV = hidden / 256
 template <int ITER, int NV>
-inline int enc_enqueue_t(icd_encoder *e, int bucket_tokens, int pooling, int normalize, bool single, hipStream_t s) {
+inline int enc_enqueue_t(icd_encoder *e, int bucket_tokens, int pooling, int normalize, bool single, bool copies, hipStream_t s) {
     constexpr int KW = 16 * ITER;
     const icd_encoder_desc &d = e->d;
     const int H = d.hidden, I = d.inter;
     const long long slab = (long long)ENC_TMAX * H;
     const int tiles = bucket_tokens / 16;   // grid.y of the GEMMs: the 16-token tiles of the bucket side by side
-    HIP_TRY(hipMemcpyAsync(e->d_meta, e->h_meta, ENC_META_WORDS * sizeof(int), hipMemcpyHostToDevice, s));
+    if (copies) HIP_TRY(hipMemcpyAsync(e->d_meta, e->h_meta, ENC_META_WORDS * sizeof(int), hipMemcpyHostToDevice, s));
     {
         EncEmbedArgs a{};
         a.meta = e->d_meta; a.word = d.word_emb; a.pos = d.pos_emb; a.type0 = d.type_emb0; a.H = H; a.KW = KW; a.y = e->yb[0];
@@ -105,17 +111,57 @@ inline int enc_enqueue_t(icd_encoder *e, int bucket_tokens, int pooling, int nor
         hipLaunchKernelGGL((enc_pool_kernel<NV, ENC_SLABS>), dim3(ENC_BMAX), dim3(ENC_POOL_WAVES * 64), 0, s, a);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(e->h_out, e->pooled, (size_t)ENC_BMAX * H * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (copies) HIP_TRY(hipMemcpyAsync(e->h_out, e->pooled, (size_t)ENC_BMAX * H * sizeof(float), hipMemcpyDeviceToHost, s));
     return ICD_OK;
 }
 
-inline int enc_enqueue(icd_encoder *e, int bucket_tokens, int pooling, int normalize, bool single, hipStream_t s) {
-    return e->d.hidden == 1024 ? enc_enqueue_t<16, 4>(e, bucket_tokens, pooling, normalize, single, s)
-                               : enc_enqueue_t<12, 3>(e, bucket_tokens, pooling, normalize, single, s);
+inline int enc_enqueue(icd_encoder *e, int bucket_tokens, int pooling, int normalize, bool single, bool copies, hipStream_t s) {
+    return e->d.hidden == 1024 ? enc_enqueue_t<16, 4>(e, bucket_tokens, pooling, normalize, single, copies, s)
+                               : enc_enqueue_t<12, 3>(e, bucket_tokens, pooling, normalize, single, copies, s);
+}
+
+// the token bucket of a call (index into icd_encoder::exec; its launches cover 16 << index tokens)
+inline int enc_bucket(int T) {
+    int bi = 0;
+    while ((16 << bi) < T) ++bi;
+    return bi;
+}
+
+// the graph of (bucket, pooling, normalize, one sequence, with / without the copy nodes): captured at first use on the private stream
+inline int enc_graph(icd_encoder *e, int bi, int pooling, int normalize, bool single, bool copies, hipGraphExec_t *out) {
+    hipGraphExec_t &gx = e->exec[bi][pooling][normalize][single ? 1 : 0][copies ? 1 : 0];
+    if (!gx) {
+        hipGraph_t g = nullptr;
+        HIP_TRY(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
+        const int rc = enc_enqueue(e, 16 << bi, pooling, normalize, single, copies, e->cap_stream);
+        const hipError_t ec = hipStreamEndCapture(e->cap_stream, &g);
+        if (rc) { if (g) hipGraphDestroy(g); return rc; }
+        HIP_TRY(ec);
+        const hipError_t ei = hipGraphInstantiate(&gx, g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (ei != hipSuccess) { gx = nullptr; return fail(ICD_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ei)); }
+    }
+    *out = gx;
+    return ICD_OK;
+}
+
+// the descriptor of one call (encoder_small.hpp, layout at ENC_META_*): sequences [b0, b0 + nb) of `lengths`, their ids at ids + t0
+inline void enc_fill_meta(int *m, const icd_encoder_desc &d, const int32_t *ids, const int32_t *lengths, int nb, int T) {
+    m[0] = T; m[1] = nb;
+    int t = 0;
+    for (int b = 0; b < nb; ++b) {
+        m[ENC_META_STARTS + b] = t;
+        const int first = t;
+        for (int i = 0; i < lengths[b]; ++i, ++t) { m[ENC_META_IDS + t] = ids[t]; m[ENC_META_POS + t] = d.pos_offset + i; m[ENC_META_TOK_R0 + t] = first; m[ENC_META_TOK_LEN + t] = lengths[b]; }
+    }
+    for (int b = nb; b <= ENC_BMAX; ++b) m[ENC_META_STARTS + b] = T;
+    for (int u = T; u < ENC_TMAX; ++u) { m[ENC_META_TOK_R0 + u] = 0; m[ENC_META_TOK_LEN + u] = 0; }
 }
 
 inline void enc_free(icd_encoder *e) {
-    for (auto &b : e->exec) for (auto &p : b) for (auto &n : p) for (auto &g : n) if (g) hipGraphExecDestroy(g);
+    for (auto &b : e->exec) for (auto &p : b) for (auto &n : p) for (auto &o : n) for (auto &g : o) if (g) hipGraphExecDestroy(g);
+    for (int *p : e->h_ring) if (p) hipHostFree(p);
+    for (hipEvent_t ev : e->ev_ring) if (ev) hipEventDestroy(ev);
     for (float *p : {e->yb[0], e->yb[1], e->yb[2], e->x, e->qkv, e->ctx, e->mid, e->pooled, e->sA, e->sB}) if (p) hipFree(p);
     for (auto *v : {&e->w_qkv, &e->w_ao, &e->w_up, &e->w_down, &e->c1_qkv, &e->c2_qkv, &e->c1_up, &e->c2_up}) for (float *p : *v) if (p) hipFree(p);
     if (e->d_meta) hipFree(e->d_meta);
@@ -208,6 +254,11 @@ int icd_encoder_create(int32_t device, const icd_encoder_desc *desc, icd_encoder
     ENC_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->h_meta), ENC_META_WORDS * sizeof(int), hipHostMallocDefault));
     ENC_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->h_out), (size_t)ENC_BMAX * H * sizeof(float), hipHostMallocDefault));
     memset(e->h_meta, 0, ENC_META_WORDS * sizeof(int));
+    for (int r = 0; r < icd_encoder::RING; ++r) {
+        ENC_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->h_ring[r]), ENC_META_WORDS * sizeof(int), hipHostMallocDefault));
+        memset(e->h_ring[r], 0, ENC_META_WORDS * sizeof(int));
+        ENC_TRY(hipEventCreateWithFlags(&e->ev_ring[r], hipEventDisableTiming));
+    }
 #ifdef ICD_ABLATE
     if (getenv("ICD_ENC_STAMPS") && atoi(getenv("ICD_ENC_STAMPS")) == 1) {
         ENC_TRY(hipMalloc(reinterpret_cast<void **>(&e->stamps), 64 * sizeof(unsigned long long)));
@@ -270,31 +321,9 @@ int icd_encoder_encode(icd_encoder *e, const int32_t *ids, const int32_t *length
     if (capturing) return fail(ICD_ERR_UNSUPPORTED, "icd_encoder_encode reads its token ids from host memory at call time: it cannot be captured into a graph");
     // the previous launch's copy node may not have read h_meta yet (device outputs: the call did not wait)
     if (e->ev_pending) { HIP_TRY(hipEventSynchronize(e->ev_done)); e->ev_pending = false; }
-    int *m = e->h_meta;
-    m[0] = T; m[1] = nseq;
-    int t = 0;
-    for (int b = 0; b < nseq; ++b) {
-        m[ENC_META_STARTS + b] = t;
-        const int first = t;
-        for (int i = 0; i < lengths[b]; ++i, ++t) { m[ENC_META_IDS + t] = ids[t]; m[ENC_META_POS + t] = d.pos_offset + i; m[ENC_META_TOK_R0 + t] = first; m[ENC_META_TOK_LEN + t] = lengths[b]; }
-    }
-    for (int b = nseq; b <= ENC_BMAX; ++b) m[ENC_META_STARTS + b] = T;
-    for (int u = T; u < ENC_TMAX; ++u) { m[ENC_META_TOK_R0 + u] = 0; m[ENC_META_TOK_LEN + u] = 0; }
-    const int bi = T <= 16 ? 0 : (T <= 32 ? 1 : (T <= 64 ? 2 : (T <= 128 ? 3 : 4)));
-    const int bucket = 16 << bi;
-    const bool single = nseq == 1;
-    hipGraphExec_t &gx = e->exec[bi][pooling][normalize][single ? 1 : 0];
-    if (!gx) {
-        hipGraph_t g = nullptr;
-        HIP_TRY(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
-        const int rc = enc_enqueue(e, bucket, pooling, normalize, single, e->cap_stream);
-        const hipError_t ec = hipStreamEndCapture(e->cap_stream, &g);
-        if (rc) { if (g) hipGraphDestroy(g); return rc; }
-        HIP_TRY(ec);
-        const hipError_t ei = hipGraphInstantiate(&gx, g, nullptr, nullptr, 0);
-        hipGraphDestroy(g);
-        if (ei != hipSuccess) { gx = nullptr; return fail(ICD_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ei)); }
-    }
+    enc_fill_meta(e->h_meta, d, ids, lengths, nseq, T);
+    hipGraphExec_t gx = nullptr;
+    { const int rc = enc_graph(e, enc_bucket(T), pooling, normalize, nseq == 1, true, &gx); if (rc) return rc; }
     HIP_TRY(hipGraphLaunch(gx, s));
     const size_t H = (size_t)d.hidden;
     if (hidden_out) HIP_TRY(hipMemcpyAsync(hidden_out, e->x, (size_t)T * H * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -306,6 +335,54 @@ int icd_encoder_encode(icd_encoder *e, const int32_t *ids, const int32_t *length
     }
     HIP_TRY(hipStreamSynchronize(s));
     memcpy(out, e->h_out, (size_t)nseq * H * sizeof(float));
+    return ICD_OK;
+}
+
+int icd_encoder_encode_many(icd_encoder *e, const int32_t *ids, const int32_t *lengths, int64_t nseq, int32_t pooling, int32_t normalize,
+                            float *out, int32_t out_on_device, void *stream) {
+    using namespace icd;
+    if (!enc_valid(e)) return fail(ICD_ERR_STATE, "invalid encoder handle");
+    std::lock_guard<std::mutex> guard(e->mu);
+    if (nseq < 0) return fail(ICD_ERR_INVALID, "nseq=%lld", (long long)nseq);
+    if (nseq == 0) return ICD_OK;
+    if (!ids || !lengths || !out) return fail(ICD_ERR_INVALID, "pointer is NULL");
+    if ((pooling != 0 && pooling != 1) || (normalize != 0 && normalize != 1)) return fail(ICD_ERR_INVALID, "pooling=%d normalize=%d", pooling, normalize);
+    const icd_encoder_desc &d = e->d;
+    const int max_len = d.max_pos - d.pos_offset < ENC_TMAX ? d.max_pos - d.pos_offset : ENC_TMAX;
+    int64_t total = 0;
+    for (int64_t b = 0; b < nseq; ++b) {
+        if (lengths[b] < 1 || lengths[b] > max_len) return fail(ICD_ERR_INVALID, "sequence %lld: %d tokens (1 .. %d)", (long long)b, lengths[b], max_len);
+        total += lengths[b];
+    }
+    for (int64_t t = 0; t < total; ++t)
+        if (ids[t] < 0 || ids[t] >= d.vocab) return fail(ICD_ERR_INVALID, "token %lld: id %d outside the vocabulary of %d", (long long)t, ids[t], d.vocab);
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (s != nullptr && hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive)
+        return fail(ICD_ERR_UNSUPPORTED, "icd_encoder_encode_many reads its token ids from host memory at call time: it cannot be captured into a graph");
+    // (a device-output call of icd_encoder_encode may still be reading h_meta / writing through d_meta's graph: same stream order
+    //  protects d_meta; h_meta is not touched here)
+    const size_t H = (size_t)d.hidden;
+    int64_t b0 = 0, t0 = 0;
+    int slot = 0;
+    while (b0 < nseq) {
+        // greedy, in the given order: as many sequences as fit the largest bucket
+        int nb = 0, T = 0;
+        while (b0 + nb < nseq && nb < ENC_BMAX && T + lengths[b0 + nb] <= ENC_TMAX) { T += lengths[b0 + nb]; ++nb; }
+        if (e->ring_pending[slot]) { HIP_TRY(hipEventSynchronize(e->ev_ring[slot])); e->ring_pending[slot] = false; }
+        enc_fill_meta(e->h_ring[slot], d, ids + t0, lengths + b0, nb, T);
+        hipGraphExec_t gx = nullptr;
+        { const int rc = enc_graph(e, enc_bucket(T), pooling, normalize, nb == 1, false, &gx); if (rc) return rc; }
+        HIP_TRY(hipMemcpyAsync(e->d_meta, e->h_ring[slot], ENC_META_WORDS * sizeof(int), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(e->ev_ring[slot], s));
+        e->ring_pending[slot] = true;
+        HIP_TRY(hipGraphLaunch(gx, s));
+        HIP_TRY(hipMemcpyAsync(out + (size_t)b0 * H, e->pooled, (size_t)nb * H * sizeof(float), out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+        b0 += nb; t0 += T;
+        slot = (slot + 1) % icd_encoder::RING;
+    }
+    if (!out_on_device) HIP_TRY(hipStreamSynchronize(s));
     return ICD_OK;
 }
 

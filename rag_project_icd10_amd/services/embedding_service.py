@@ -410,6 +410,9 @@ class EmbeddingService:
         # small-input forward, one graph launch (csrc/encoder_small.hpp through the C ABI; ICD_EMBEDDING_SMALL=0: the replayed
         # graph of the framework's forward). fp32 BERT-base shapes on a GPU only; anything else keeps the paths below.
         self._small = None
+        # batches beyond one small-input call: "canonical" (default) = the same kernels, cut into calls (bit-identical to one string
+        # per call); "fast" = the packed split-bf16 forward
+        self._batch_fast = os.getenv("ICD_EMBEDDING_BATCH", "canonical").strip().lower() == "fast"
         if os.getenv("ICD_EMBEDDING_SMALL", "1") == "1" and str(self.device).startswith("cuda") and dtype == torch.float32:
             try:
                 from .. import _native
@@ -431,15 +434,24 @@ class EmbeddingService:
             return enc["input_ids"]
         return [self._char_tok.encode(t) for t in texts]
 
-    def _encode_prepared(self, texts: List[str], batch_size: int, to_device: bool = False):
+    def _encode_prepared(self, texts: List[str], batch_size: int, to_device: bool = False, fast: Optional[bool] = None):
         """texts already carry their prefix. Returns float32 [n, dim] (numpy, or a tensor on self.device)."""
         n = len(texts)
         if n == 0:
             out = torch.empty((0, self._dim), dtype=torch.float32, device=self.device)
             return out if to_device else out.cpu().numpy()
         ids = self._tokenize(texts)
-        if self._small is not None and self._small.fits([len(x) for x in ids]):
-            return self._small.encode(ids, pooling=self.pooling, normalize=True, to_device=to_device)
+        if self._small is not None:
+            lens = [len(x) for x in ids]
+            if self._small.fits(lens):
+                return self._small.encode(ids, pooling=self.pooling, normalize=True, to_device=to_device)
+            # ONE embedding arithmetic whatever the call shape (the canonical one: csrc/encoder_small.hpp). The reference embeds
+            # corpus rows and queries through the same one-string call (tools/build_database.py:217-222, :117-120): identical text,
+            # identical vector. A batch goes through the same kernels cut into calls by the library - row i is bit for bit what
+            # encode_query(texts[i]) returns. `fast` (per call, or ICD_EMBEDDING_BATCH=fast) trades that for the packed split-bf16
+            # forward below: ~5 x the throughput, vectors within ~1.2e-6 of the canonical ones (DESIGN.md section 7).
+            if not (self._batch_fast if fast is None else fast) and self._small.fits_each(lens):
+                return self._small.encode_many(ids, pooling=self.pooling, normalize=True, to_device=to_device)
         out = torch.empty((n, self._dim), dtype=torch.float32, device=self.device)
         order = sorted(range(n), key=lambda i: -len(ids[i]))  # length buckets: least padding per batch
         if self._packed is not None and batch_size > self._GRAPH_BATCHES[-1] and n > self._GRAPH_BATCHES[-1]:
@@ -562,6 +574,7 @@ class EmbeddingService:
             "embedding_dimension": self._dim,
             "synthetic": self.synthetic,
             "pooling": self.pooling,
+            "batch_arithmetic": self.batch_arithmetic(),
         }
 
     def test_embedding(self, test_text: str = "测试文本") -> Dict[str, Any]:
@@ -573,10 +586,19 @@ class EmbeddingService:
             return {"success": False, "error": str(exc)}
 
     # ---- additive batch entry points ---------------------------------------------------
-    def encode_query_batch(self, queries: List[str], batch_size: int = 256, to_device: bool = False):
+    def encode_query_batch(self, queries: List[str], batch_size: int = 256, to_device: bool = False, fast: Optional[bool] = None):
         """encode_query for many strings at once: float32 [n, dim]; with to_device=True the result
-        stays on the GPU for the search kernel."""
-        return self._encode_prepared([f"query: {q}" for q in queries], batch_size, to_device)
+        stays on the GPU for the search kernel. Row i equals encode_query(queries[i]) bit for bit on the canonical path (the
+        default where the small-input encoder serves the model); fast=True (or ICD_EMBEDDING_BATCH=fast) takes the packed
+        split-bf16 forward instead: vectors within ~1.2e-6, near-tied hits may swap."""
+        return self._encode_prepared([f"query: {q}" for q in queries], batch_size, to_device, fast)
 
-    def encode_passage_batch(self, texts: List[str], batch_size: int = 256, to_device: bool = False):
-        return self._encode_prepared([self._prepare_text_for_embedding(t) for t in texts], batch_size, to_device)
+    def encode_passage_batch(self, texts: List[str], batch_size: int = 256, to_device: bool = False, fast: Optional[bool] = None):
+        return self._encode_prepared([self._prepare_text_for_embedding(t) for t in texts], batch_size, to_device, fast)
+
+    def batch_arithmetic(self) -> str:
+        """what a batch of more strings than one small-input call is embedded with: "canonical" (bit-identical to one string per
+        call), "fast" (packed split-bf16) or "framework" (no small-input encoder for this model / device)"""
+        if self._small is None:
+            return "framework"
+        return "fast" if self._batch_fast else "canonical"

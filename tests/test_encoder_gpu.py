@@ -48,23 +48,21 @@ def test_encode_query_graph_bucket_matches_cpu(services):
 
 
 def test_encode_query_through_the_replayed_framework_graph_matches_cpu(services, monkeypatch):
-    """ICD_EMBEDDING_SMALL=0 (and batches of <= 32 strings with more than 256 tokens in all): the framework's forward,
-    replayed from a HIP graph per (batch, width) bucket"""
+    """ICD_EMBEDDING_SMALL=0 (or a model the small-input encoder is not instantiated for): the framework's forward, replayed
+    from a HIP graph per (batch, width) bucket"""
     gpu, cpu = services
     monkeypatch.setattr(gpu, "_small", None)
     for t in _strings()[:12] + _strings()[-6:]:
         a, b = gpu.encode_query(t), cpu.encode_query(t)
         assert np.max(np.abs(a - b)) <= TOL, t
     assert gpu._graphs, "the one-string path should have captured a HIP graph"
-    texts = _strings()[:24]                                                 # 24 strings, > 256 tokens: the graph buckets with the small encoder ON
-    monkeypatch.undo()
-    assert sum(len(x) for x in gpu._tokenize([f"query: {t}" for t in texts])) > 256
+    texts = _strings()[:24]                                                 # 24 strings through the (batch, width) graph buckets
     a, b = gpu.encode_query_batch(texts, batch_size=32), cpu.encode_query_batch(texts, batch_size=32)
     assert np.max(np.abs(a - b)) <= TOL
 
 
 def test_small_input_encoder_matches_the_framework_forward(services):
-    """csrc/encoder_small.hpp through icd_encoder_encode: 1 ... 32 sequences, 1 ... 256 packed tokens, every token bucket and
+    """csrc/encoder_small.hpp through icd_encoder_encode: 1 ... 64 sequences, 1 ... 512 packed tokens, every token bucket and
     its edges - pooled rows (mean and [CLS], normalised or not) and the last hidden state of every token against
     transformers' padded BertModel forward of the same weights on the GPU (1e-5); host and device outputs identical; the
     descriptor's limits refused with a clear error."""
@@ -95,7 +93,8 @@ def test_small_input_encoder_matches_the_framework_forward(services):
         return pooled.cpu().numpy(), torch.nn.functional.normalize(pooled, p=2, dim=1).cpu().numpy(), rows.cpu().numpy()
 
     cases = [[1], [2], [3], [15], [16], [17], [31], [32], [33], [64], [65], [100], [128], [5, 9, 12, 30], [4] * 32, [1] * 32, [64, 64],
-             [17, 1, 40, 2, 23], [16, 16], [7] * 18, [100, 28], [129], [200], [130, 100], [8] * 32, [256], [90, 3, 128, 35]]
+             [17, 1, 40, 2, 23], [16, 16], [7] * 18, [100, 28], [129], [200], [130, 100], [8] * 32, [256], [90, 3, 128, 35],
+             [257], [300, 200], [512], [8] * 64, [1] * 64, [400, 100, 12], [128] * 4]
     for lengths in cases:
         ids = make(lengths)
         for pooling in ("mean", "cls"):
@@ -109,13 +108,14 @@ def test_small_input_encoder_matches_the_framework_forward(services):
             dev = enc.encode(ids, pooling=pooling, normalize=True, to_device=True)
             torch.cuda.synchronize()
             assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), got_unit)
-    with pytest.raises(_native.IcdError, match="256 tokens"):
-        enc.encode(make([200, 57]))
+    with pytest.raises(_native.IcdError, match="512 tokens"):
+        enc.encode(make([400, 113]))
     with pytest.raises(_native.IcdError, match="sequences per call"):
-        enc.encode(make([2] * 33))
+        enc.encode(make([2] * 65))
     with pytest.raises(_native.IcdError, match="vocabulary"):
         enc.encode([[101, vocab, 102]])
-    assert not enc.fits([200, 57]) and not enc.fits([2] * 33) and enc.fits([256]) and not enc.fits([])
+    assert not enc.fits([400, 113]) and not enc.fits([2] * 65) and enc.fits([512]) and not enc.fits([])
+    assert enc.fits_each([512] * 100) and not enc.fits_each([513]) and not enc.fits_each([])
 
 
 def test_encode_batch_32_matches_cpu(services):
@@ -126,8 +126,8 @@ def test_encode_batch_32_matches_cpu(services):
     assert a.shape == (len(texts), 768)
     assert np.max(np.abs(a - b)) <= TOL
     assert np.max(np.abs(np.linalg.norm(a, axis=1) - 1.0)) <= 1e-5
-    one = gpu.encode_single(texts[7])                                      # batching does not change a row
-    assert np.max(np.abs(one - a[7])) <= TOL
+    for i in (0, 7, 50, len(texts) - 6, len(texts) - 1):                   # batching does not change a row: not one bit
+        assert np.array_equal(gpu.encode_single(texts[i]).astype(np.float64), a[i]), i
 
 
 def test_encode_query_batch_256_matches_cpu_and_stays_on_device(services):
@@ -140,8 +140,9 @@ def test_encode_query_batch_256_matches_cpu_and_stays_on_device(services):
     b = cpu.encode_query_batch(texts, batch_size=256)
     assert np.max(np.abs(a - b)) <= TOL
     assert np.max(np.abs(np.linalg.norm(a, axis=1) - 1.0)) <= 1e-5
-    for i in (0, 17, len(texts) - 6, len(texts) - 3):                      # the batch row == the one-at-a-time call
-        assert np.max(np.abs(a[i] - gpu.encode_query(texts[i]))) <= TOL
+    assert gpu.batch_arithmetic() == "canonical"
+    for i in (0, 17, len(texts) - 6, len(texts) - 3):                      # the batch row == the one-at-a-time call, bit for bit
+        assert np.array_equal(a[i], gpu.encode_query(texts[i])), i
 
 
 def test_packed_forward_matches_the_padded_hf_forward(services, monkeypatch):
@@ -151,19 +152,24 @@ def test_packed_forward_matches_the_padded_hf_forward(services, monkeypatch):
     gpu, cpu = services
     texts = _strings()
     assert gpu._packed is not None and cpu._packed is not None
+    monkeypatch.setattr(gpu, "_batch_fast", True)                          # (ICD_EMBEDDING_BATCH=fast: the packed forward; the default is the canonical path)
     packed = gpu.encode_query_batch(texts, batch_size=256)
     monkeypatch.setattr(cpu, "_packed", None)
     monkeypatch.setattr(gpu, "_packed", None)
     padded_cpu = cpu.encode_query_batch(texts, batch_size=256)            # HF BertModel, padded, fp32 on the CPU
+    monkeypatch.setattr(gpu, "_small", None)                               # (the padded HF forward on the GPU: no small-input encoder, no packed one)
     padded_gpu = gpu.encode_query_batch(texts, batch_size=256)
     monkeypatch.undo()
     assert np.max(np.abs(packed - padded_cpu)) <= TOL and np.max(np.abs(packed - padded_gpu)) <= TOL
+    monkeypatch.setattr(gpu, "_batch_fast", True)
     monkeypatch.setattr(gpu, "PACK_TOKENS", 700)                           # many chunks
     assert np.max(np.abs(gpu.encode_query_batch(texts, batch_size=256) - packed)) <= TOL
     monkeypatch.undo()
+    monkeypatch.setattr(gpu, "_batch_fast", True)
     monkeypatch.setattr(gpu, "pooling", "cls")
     cls_packed = gpu.encode_query_batch(texts, batch_size=256)
     monkeypatch.setattr(gpu, "_packed", None)
+    monkeypatch.setattr(gpu, "_small", None)
     monkeypatch.setattr(gpu.model, "pooling", "cls")
     cls_padded = gpu.encode_query_batch(texts, batch_size=256)
     assert np.max(np.abs(cls_packed - cls_padded)) <= TOL and np.max(np.abs(cls_packed - packed)) > 1e-3
@@ -178,12 +184,16 @@ def test_split_bf16_gemms_of_the_packed_forward_stay_within_the_fp32_tolerance(s
     gpu, cpu = services
     texts = _strings()
     assert gpu._packed is not None
+    monkeypatch.setattr(gpu, "_batch_fast", True)
     got = gpu.encode_query_batch(texts, batch_size=256)
     if not gpu._packed.split_gemm:
         pytest.skip("this torch has no mm(out_dtype=...): the packed forward runs fp32 GEMMs")
     monkeypatch.setattr(gpu._packed, "split_gemm", False)
     fp32 = gpu.encode_query_batch(texts, batch_size=256)
     monkeypatch.undo()
+    canon = gpu.encode_query_batch(texts, batch_size=256)                  # the canonical path (the default): what the fast one is "within" of
+    print(f"split-bf16 GEMMs: max |d embedding| vs the canonical small-input forward {float(np.max(np.abs(got - canon))):.2e}")
+    assert np.max(np.abs(got - canon)) <= TOL
     ref = cpu.encode_query_batch(texts, batch_size=256)
     d_gpu, d_cpu = float(np.max(np.abs(got - fp32))), float(np.max(np.abs(got - ref)))
     d_cos = float(np.max(np.abs(got.astype(np.float64) @ got.astype(np.float64).T - ref.astype(np.float64) @ ref.astype(np.float64).T)))
@@ -233,6 +243,7 @@ def test_packed_forward_with_native_attention_matches_sdpa_groups(services, monk
     gpu, _ = services
     texts = _strings() + ["肺" * n for n in (54, 55, 56, 57, 58, 90, 119, 120, 121)]   # "query: " + CLS/SEP: 62 .. 66, 98, 127, 128 (and truncated to 128) tokens
     assert gpu._packed.native_attention is not None
+    monkeypatch.setattr(gpu, "_batch_fast", True)
     native = gpu.encode_query_batch(texts, batch_size=256)
     monkeypatch.setattr(gpu._packed, "native_attention", None)
     sdpa = gpu.encode_query_batch(texts, batch_size=256)
@@ -240,39 +251,63 @@ def test_packed_forward_with_native_attention_matches_sdpa_groups(services, monk
     monkeypatch.setattr(gpu, "pooling", "cls")
     cls_sdpa = gpu.encode_query_batch(texts, batch_size=256)
     monkeypatch.undo()
+    monkeypatch.setattr(gpu, "_batch_fast", True)
     monkeypatch.setattr(gpu, "pooling", "cls")
     assert np.max(np.abs(gpu.encode_query_batch(texts, batch_size=256) - cls_sdpa)) <= 2e-6
 
 
-@pytest.mark.parametrize("k", [10, 20])
-def test_search_on_an_encoder_made_corpus_is_bit_exact(k, tmp_path, monkeypatch):
-    """The reference searches rows produced by the SAME encoder that encodes the query (tools/build_database.py:217-222:
+@pytest.fixture(scope="module")
+def encoder_corpus(tmp_path_factory):
+    """The reference searches rows produced by the SAME encoder call that encodes the query (tools/build_database.py:217-222:
     encode_query(semantic_text) per record): anisotropic, family-shaped embeddings, not Gaussian rows. The full-size corpus
-    (40 474 rows of the real CSV's shape: scripts/bench_build.py synth_csv over tests/golden/csv_shape.json) is built on the
-    GPU by DatabaseBuilder, 1 000 golden diagnosis strings are encoded by the same service, and the batch search - whatever
-    mix of certified, second-pass and exact-re-search queries this data produces - must equal the oracle bit for bit."""
+    (40 474 rows of the real CSV's shape: scripts/bench_build.py synth_csv over tests/golden/csv_shape.json) built on the GPU
+    by DatabaseBuilder, once for the module; and the 1 000 golden diagnosis strings."""
     import json
+    import sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from bench_build import synth_csv
+    tmp = tmp_path_factory.mktemp("enc_corpus")
+    env = {"MILVUS_DB_PATH": str(tmp / "db"), "MILVUS_COLLECTION_NAME": "icd10_enc_test", "MILVUS_MODE": "local",
+           "EMBEDDING_MODEL_NAME": "shibing624/text2vec-base-chinese", "ICD_EMBEDDING_ALLOW_SYNTHETIC": "1"}
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    os.environ.pop("ICD_EMBEDDING_BATCH", None)
+    try:
+        shape = json.load(open(os.path.join(GOLDEN, "csv_shape.json"), encoding="utf-8"))
+        csv_path = str(tmp / "shape.csv")
+        nrows = synth_csv(csv_path, shape)
+        from rag_project_icd10_amd.tools.build_database import DatabaseBuilder
+        b = DatabaseBuilder()
+        assert b.build_full_database(csv_path, rebuild=True)
+        ms, es = b.milvus_service, b.embedding_service
+        assert es.batch_arithmetic() == "canonical"
+        corpus, levels = ms.client.matrix(), ms.client.levels()
+        assert corpus.shape == (nrows, 768) and nrows == 40474
+        strings = [l.strip() for l in open(os.path.join(GOLDEN, "diagnosis_strings.txt"), encoding="utf-8") if l.strip()][:1000]
+        yield b, ms, es, corpus, levels, strings
+        ms.disconnect()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("k", [10, 20])
+def test_search_on_an_encoder_made_corpus_is_bit_exact(k, encoder_corpus):
+    """1 000 golden diagnosis strings are encoded by the service that built the corpus, and the batch search - whatever mix of
+    certified, second-pass and exact-re-search queries this data produces - must equal the oracle bit for bit."""
     import sys
     import torch
     from conftest import ROOT
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import oracle as orc
-    from bench_build import synth_csv
-    monkeypatch.setenv("MILVUS_DB_PATH", str(tmp_path / "db"))
-    monkeypatch.setenv("MILVUS_COLLECTION_NAME", "icd10_enc_test")
-    monkeypatch.setenv("EMBEDDING_MODEL_NAME", "shibing624/text2vec-base-chinese")
-    monkeypatch.setenv("ICD_EMBEDDING_ALLOW_SYNTHETIC", "1")
-    shape = json.load(open(os.path.join(GOLDEN, "csv_shape.json"), encoding="utf-8"))
-    csv_path = str(tmp_path / "shape.csv")
-    nrows = synth_csv(csv_path, shape)
-    from rag_project_icd10_amd.tools.build_database import DatabaseBuilder
-    b = DatabaseBuilder()
-    assert b.build_full_database(csv_path, rebuild=True)
-    ms, es = b.milvus_service, b.embedding_service
-    corpus, levels = ms.client.matrix(), ms.client.levels()
-    assert corpus.shape == (nrows, 768) and nrows == 40474
-    strings = [l.strip() for l in open(os.path.join(GOLDEN, "diagnosis_strings.txt"), encoding="utf-8") if l.strip()][:1000]
+    b, ms, es, corpus, levels, strings = encoder_corpus
     dq = es.encode_query_batch(strings, batch_size=256, to_device=True)
     queries = dq.cpu().numpy()
     os_, oi = orc.flat_ip_topk(corpus, queries, k)
@@ -286,7 +321,102 @@ def test_search_on_an_encoder_made_corpus_is_bit_exact(k, tmp_path, monkeypatch)
         assert np.array_equal(lv.cpu().numpy(), want[3])
     print(f"encoder-made corpus k={k}: second pass {st['last_second_pass']} (x {st['last_second_pass_lists']} lists), "
           f"exact re-search {st['last_fallback']} of {len(strings)}, wide_mode {st['wide_mode']}")
-    ms.disconnect()
+
+
+def test_a_corpus_row_is_the_vector_its_text_gets_as_a_query(encoder_corpus):
+    """the reference's property (tools/build_database.py:217-222 and services/embedding_service.py:117-120 are the same call):
+    the vector stored for a record IS encode_query(its semantic_text) - bit for bit, although the build encodes thousands of
+    records per call; so a record searched with its own text scores itself first with a raw score equal to its own norm chain"""
+    b, ms, es, corpus, levels, strings = encoder_corpus
+    recs = ms.client.records
+    rng = np.random.default_rng(12)
+    for i in [0, 1, 2, len(recs) - 1] + [int(x) for x in rng.integers(0, len(recs), 60)]:
+        v = es.encode_query(recs[i]["semantic_text"])
+        assert np.array_equal(v, corpus[i]), (i, recs[i]["code"])
+    hits = ms.search(es.encode_query(recs[777]["semantic_text"]), top_k=5)
+    assert hits and hits[0]["code"] == recs[777]["code"]
+
+
+def test_batch_rows_equal_one_string_per_call_bit_for_bit(services):
+    """ONE embedding arithmetic whatever the call shape: encode_query_batch / encode_batch (thousands of tokens, cut into calls
+    by icd_encoder_encode_many) return for every string the bits encode_query / encode_single return for it alone - in any
+    order, next to any neighbours, host or device output"""
+    import torch
+    gpu, _ = services
+    assert gpu.batch_arithmetic() == "canonical"
+    texts = _strings() + ["肺" * n for n in (54, 55, 56, 57, 58, 90, 119, 120, 121)]
+    one = np.stack([gpu.encode_query(t) for t in texts])
+    got = gpu.encode_query_batch(texts)
+    assert got.dtype == np.float32 and np.array_equal(got, one)
+    dev = gpu.encode_query_batch(texts, to_device=True)
+    torch.cuda.synchronize()
+    assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), one)
+    perm = np.random.default_rng(3).permutation(len(texts))
+    assert np.array_equal(gpu.encode_query_batch([texts[i] for i in perm]), one[perm])          # other neighbours, other calls
+    assert np.array_equal(gpu.encode_query_batch(texts[:70]), one[:70])                         # 65+ strings: two calls of the library
+    emb = np.asarray(gpu.encode_batch(texts[:100], show_progress=False), dtype=np.float32)      # /embed: "passage: " prefixes
+    assert np.array_equal(emb, np.stack([gpu.encode_single(t) for t in texts[:100]]))
+    # the library entry point itself: sequences of 1 ... 512 tokens in one list
+    enc = gpu._small
+    rng = np.random.default_rng(9)
+    vocab = gpu.model.bert.config.vocab_size
+    lengths = [1, 2, 512, 3, 500, 13, 100, 412, 16, 17] + [int(x) for x in rng.integers(1, 130, 150)]
+    ids = [[int(v) for v in rng.integers(1000, vocab, size=n)] for n in lengths]
+    many = enc.encode_many(ids, pooling="mean", normalize=True)
+    for i in range(len(ids)):
+        assert np.array_equal(many[i], enc.encode([ids[i]])[0]), (i, lengths[i])
+    many_cls = enc.encode_many(ids[:40], pooling="cls", normalize=False)
+    assert np.array_equal(many_cls, np.concatenate([enc.encode([x], pooling="cls", normalize=False) for x in ids[:40]]))
+    from rag_project_icd10_amd import _native
+    with pytest.raises(_native.IcdError, match="tokens"):
+        enc.encode_many([[101] * 513])
+    assert enc.encode_many([], to_device=False).shape == (0, 768)
+
+
+@pytest.mark.parametrize("k", [10, 20])
+def test_both_encoder_paths_give_the_same_code_lists(k, encoder_corpus, monkeypatch):
+    """the 1 000 golden strings through BOTH query paths - encode_query one string per call (the reference's
+    shape, services/multi_diagnosis_service.py:152) and encode_query_batch - searched over the encoder-made 40 474-row corpus.
+    Canonical batch path (the default): the vectors are bit-identical, so codes AND scores of all 1 000 strings are. Fast path
+    (ICD_EMBEDDING_BATCH=fast, packed split-bf16 GEMMs): vectors within 1e-5; every string whose code list differs is
+    explained by a near-tie - the canonical scores of the two hits that swapped differ by less than BOUND - and counted."""
+    import sys
+    import torch
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    b, ms, es, corpus, levels, strings = encoder_corpus
+    BOUND = 1e-5   # = north_star's score tolerance: two hits closer than this are a tie at the precision the scores are specified to
+    single = np.stack([es.encode_query(t) for t in strings])
+    batched = es.encode_query_batch(strings, to_device=True)
+    assert np.array_equal(batched.cpu().numpy(), single)
+    codes = [r["code"] for r in ms.client.records]
+    adj_b, raw_b, ids_b, _ = (x.cpu().numpy() for x in ms.search_batch(batched, top_k=k))
+    one_by_one = [ms.search(single[i], top_k=k) for i in range(len(strings))]
+    for i, hits in enumerate(one_by_one):   # canonical: codes and scores, every string
+        assert [h["code"] for h in hits] == [codes[j] for j in ids_b[i]], strings[i]
+        assert [h["score"] for h in hits] == list(adj_b[i]) and [h["original_score"] for h in hits] == [float(x) for x in raw_b[i]]
+    # the fast path against it
+    fast = es.encode_query_batch(strings, to_device=True, fast=True)
+    d_vec = float(np.max(np.abs(fast.cpu().numpy() - single)))
+    assert 0.0 < d_vec <= 1e-5, d_vec                                   # (another arithmetic: not bit-identical, inside the tolerance)
+    adj_f, raw_f, ids_f, _ = (x.cpu().numpy() for x in ms.search_batch(fast, top_k=k))
+    assert float(np.max(np.abs(raw_f.astype(np.float64) - raw_b.astype(np.float64))[ids_f == ids_b], initial=0.0)) <= 1e-5
+    differ = [i for i in range(len(strings)) if not np.array_equal(ids_f[i], ids_b[i])]
+    w = np.where(levels == 1, 1.2, np.where(levels == 3, 0.8, 1.0))
+    if differ:
+        os_, oi = orc.flat_ip_topk(corpus, single[differ], k + 1)       # canonical raw scores of the top k + 1, descending
+        for r, i in enumerate(differ):
+            raw_gaps = os_[r][:-1].astype(np.float64) - os_[r][1:].astype(np.float64)
+            adj_sorted = np.sort(os_[r][:k].astype(np.float64) * w[oi[r][:k]])[::-1]
+            adj_gaps = adj_sorted[:-1] - adj_sorted[1:]
+            # a different list needs two hits to change places: in the raw order (membership: the k-th against the k + 1-th, or any
+            # pair inside) or in the reweighted order of the k members - and those two were closer than the arithmetic's reach
+            assert min(float(raw_gaps.min()), float(adj_gaps.min())) <= BOUND, (strings[i], raw_gaps.min(), adj_gaps.min())
+    print(f"k={k}: canonical batch == one string per call on {len(strings)}/{len(strings)} strings (codes and scores, bit for bit); "
+          f"fast (split-bf16) path: max |d vector| {d_vec:.2e}, {len(strings) - len(differ)}/{len(strings)} identical code lists, "
+          f"{len(differ)} near-tie swaps (canonical gap <= {BOUND:g})")
+    assert len(differ) <= 150   # (measured: 11 at k = 10, 50 at k = 20 on the synthetic-weight corpus, whose families are tight)
 
 
 def test_split_bf16x3_kernel_makes_the_documented_operand():

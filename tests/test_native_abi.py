@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_native.EXPORTED_SYMBOLS)
-    assert lib.icd_abi_version() == _native.ABI_VERSION == 5
+    assert lib.icd_abi_version() == _native.ABI_VERSION == 6
 
 
 def test_error_reporting_without_gpu():
@@ -78,4 +78,5 @@ def test_encoder_argument_validation_needs_no_gpu():
     lens = np.array([2], np.int32)
     out = np.zeros(768, np.float32)
     assert lib.icd_encoder_encode(None, ids.ctypes.data, lens.ctypes.data, 1, 0, 1, out.ctypes.data, 0, None, None) == -5
+    assert lib.icd_encoder_encode_many(None, ids.ctypes.data, lens.ctypes.data, 1, 0, 1, out.ctypes.data, 0, None) == -5
     assert not _native.SmallEncoder.supported(object())

@@ -79,6 +79,13 @@ def test_bert_base_classifier_small_input_forward_equals_the_framework_forward(m
             assert float(np.abs(gs - ws).max()) <= 5e-5
             assert np.mean(np.array(gl) == np.array(wl)) >= 0.9    # (random-init logits: near-ties may flip)
     long_enc = [clf._encode("高血压" * 100)]
-    assert not small.fits([len(long_enc[0][0])])                  # more than 256 tokens: the framework's forward
-    assert len(clf._forward(long_enc)[0][0]) == len(long_enc[0][0])
+    assert small.fits([len(long_enc[0][0])]) and len(long_enc[0][0]) == 302   # any one sequence the model takes fits a call (512 tokens)
+    got = clf._forward(long_enc)
+    clf._small = None
+    want = clf._forward(long_enc)
+    clf._small = small
+    assert len(got[0][0]) == len(long_enc[0][0]) and float(np.abs(got[0][1] - want[0][1]).max()) <= 5e-5
+    many = [clf._encode("高血压" * 100) for _ in range(2)]
+    assert not small.fits([len(e[0]) for e in many])                # 604 tokens in all: the framework's forward
+    assert len(clf._forward(many)[1][0]) == 302
     assert svc.extract_medical_entities_batch(strings[:3]) == [svc.extract_medical_entities(s) for s in strings[:3]]
