@@ -144,10 +144,29 @@ def cpu_baseline(corpus, levels, queries, k, budget_s=12.0, with_encoder=True):
             emb = EmbeddingService(allow_synthetic=True, device="cpu")
             texts = [l.strip() for l in open(os.path.join(ROOT, "tests", "golden", "diagnosis_strings.txt"), encoding="utf-8")][:160]
             emb.encode_query(texts[0])
-            t0 = time.perf_counter()
+            # BASELINE configs[0] on the host: per string encode_query (batch 1) -> the reference-shaped search, k = 5, over 40 474
+            # rows (Gaussian unit rows: the scan's cost does not depend on the data; the GPU's leg, extra.config0, runs over the
+            # database it builds). A bounded sample of the 100 strings.
+            c40 = unit_rows(40474, corpus.shape[1], 1234)
+            l40 = icd_levels(40474, 1235)
+            orc.reference_shaped_search(c40, l40, queries[0], 5)
+            vecs, d_enc, d_search = [], 0.0, 0.0
             for t in texts[:32]:
-                emb.encode_query(t)
-            d1 = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                v = emb.encode_query(t)
+                t1 = time.perf_counter()
+                orc.reference_shaped_search(c40, l40, v, 5)
+                t2 = time.perf_counter()
+                d_enc += t1 - t0
+                d_search += t2 - t1
+                vecs.append(v)
+            _CPU_CONFIG0["vectors"] = np.stack(vecs)
+            d1 = d_enc
+            extra["config0"] = {"value": 32 / (d_enc + d_search), "unit": "strings/s", "kind": "port",
+                                "sample": "32 of the 100 golden strings: encode_query one per call (HF BertModel fp32 on the CPU, synthetic weights) -> "
+                                          "reference-shaped search (oracle/oracle.py), top_k=5, 40474x768 fp32 rows",
+                                "encode_ms_per_string": d_enc / 32 * 1e3, "search_ms_per_string": d_search / 32 * 1e3,
+                                "cores": int(np_threads or os.cpu_count() or threads)}
             t0 = time.perf_counter()
             emb.encode_batch(texts[32:160], show_progress=False)
             d2 = time.perf_counter() - t0
@@ -345,7 +364,7 @@ def side_workload(*a, **kw):
         return {"workload": a[3] if len(a) > 3 else "?", "error": f"{type(exc).__name__}: {exc}", "traceback": traceback.format_exc()[-1500:]}
 
 
-def embed_one_string_extra(ctx):
+def embed_one_string_extra(ctx, es=None):
     """The embed step at the reference's own call shape: EmbeddingService.encode_query(ONE string) -> SentenceTransformer.encode
     (services/embedding_service.py:97-102,117-120), 100 golden diagnosis strings one call at a time, through the hand-written
     small-input forward (csrc/encoder_small.hpp, icd_encoder_encode: one graph launch) and through the framework's forward
@@ -357,7 +376,8 @@ def embed_one_string_extra(ctx):
     os.environ.update({"EMBEDDING_MODEL_NAME": "shibing624/text2vec-base-chinese", "ICD_EMBEDDING_ALLOW_SYNTHETIC": "1"})
     try:
         from rag_project_icd10_amd.services.embedding_service import EmbeddingService
-        es = EmbeddingService(allow_synthetic=True, device=f"cuda:{ctx.local_rank}" if ctx.local_rank else "cuda")
+        if es is None:
+            es = EmbeddingService(allow_synthetic=True, device=f"cuda:{ctx.local_rank}" if ctx.local_rank else "cuda")
         strings = [l.strip() for l in open(os.path.join(ROOT, "tests", "golden", "diagnosis_strings.txt"), encoding="utf-8") if l.strip()][:100]
         small = getattr(es, "_small", None)
         out = {"workload": "EmbeddingService.encode_query, ONE string per call, 100 golden diagnosis strings, synthetic BERT-base weights",
@@ -390,6 +410,98 @@ def embed_one_string_extra(ctx):
                 os.environ.pop(v, None)
             else:
                 os.environ[v] = val
+
+
+_CPU_CONFIG0 = {}   # cpu_baseline's leg leaves its vectors of the first golden strings here: config0_extra compares the GPU's with them
+
+
+def config0_extra(ctx):
+    """BASELINE configs[0] as ONE composed workload, the reference's own call shape (services/multi_diagnosis_service.py:152-153,
+    services/milvus_service.py:280-285): 100 golden diagnosis strings, per string EmbeddingService.encode_query (one string per
+    call) -> MilvusService.search(vector, top_k=5) (one query per call, hit dicts out), over a full-size database - the 40 474
+    rows of a CSV of the real one's shape (scripts/bench_build.py synth_csv over tests/golden/csv_shape.json), built in this run
+    by DatabaseBuilder.build_full_database (tools/build_database.py:297-337; its seconds are reported, not timed into the loop).
+    Synthetic BERT-base weights (no checkpoint offline). Checked in the same run, all 100 strings: the hits' codes and scores
+    against the CPU oracle over the stored corpus (bit for bit), a stored row against encode_query of its own text (bit for
+    bit), and the GPU's vectors of the first strings against the CPU fp32 forward of the same weights (1e-5; cpu_baseline's leg)."""
+    import shutil
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import oracle as orc
+    from bench_build import synth_csv
+    tmp = tempfile.mkdtemp(prefix="icd_bench_config0_")
+    env = {"MILVUS_MODE": "local", "MILVUS_DB_PATH": os.path.join(tmp, "db"), "MILVUS_COLLECTION_NAME": "icd10_config0",
+           "EMBEDDING_MODEL_NAME": "shibing624/text2vec-base-chinese", "ICD_EMBEDDING_ALLOW_SYNTHETIC": "1",
+           "EMBEDDING_DEVICE": f"cuda:{ctx.local_rank}" if ctx.local_rank else "cuda"}
+    saved = {v: os.environ.get(v) for v in env}
+    os.environ.update(env)
+    try:
+        from rag_project_icd10_amd.tools.build_database import DatabaseBuilder
+        shape = json.load(open(os.path.join(ROOT, "tests", "golden", "csv_shape.json"), encoding="utf-8"))
+        csv_path = os.path.join(tmp, "icd_shape.csv")
+        nrows = synth_csv(csv_path, shape)
+        b = DatabaseBuilder()
+        t0 = time.perf_counter()
+        ok = b.build_full_database(csv_path, rebuild=True)
+        build_s = time.perf_counter() - t0
+        if not ok:
+            return {"error": "build_full_database failed"}, None
+        es, ms = b.embedding_service, b.milvus_service
+        strings = [l.strip() for l in open(os.path.join(ROOT, "tests", "golden", "diagnosis_strings.txt"), encoding="utf-8") if l.strip()][:100]
+        k = 5
+        for t in strings[:10]:
+            ms.search(es.encode_query(t), top_k=k)
+        ctx.sync()
+        lat, enc_us, vecs, hits_all = [], [], [], []
+        t_all = time.perf_counter()
+        for t in strings:
+            t0 = time.perf_counter()
+            v = es.encode_query(t)
+            t1 = time.perf_counter()
+            hits = ms.search(v, top_k=k)
+            t2 = time.perf_counter()
+            lat.append((t2 - t0) * 1e6)
+            enc_us.append((t1 - t0) * 1e6)
+            vecs.append(v)
+            hits_all.append(hits)
+        total_s = time.perf_counter() - t_all
+        corpus, levels = ms.client.matrix(), ms.client.levels()
+        codes = [r["code"] for r in ms.client.records]
+        V = np.stack(vecs)
+        os_, oi = orc.flat_ip_topk(corpus, V, k)
+        want = orc.reweight(os_, oi, levels)
+        hits_ok = all([h["code"] for h in hits_all[i]] == [codes[j] for j in want[2][i]]
+                      and [h["score"] for h in hits_all[i]] == list(want[0][i])
+                      and [h["original_score"] for h in hits_all[i]] == [float(x) for x in want[1][i]] for i in range(len(strings)))
+        rows = [0, 1, nrows // 2, nrows - 1]
+        row_ok = all(np.array_equal(es.encode_query(ms.client.records[i]["semantic_text"]), corpus[i]) for i in rows)
+        lat.sort()
+        enc_sorted = sorted(enc_us)
+        out = {"workload": f"BASELINE configs[0] on the GPU: {len(strings)} golden diagnosis strings, per string encode_query (one string per call) -> "
+                           f"MilvusService.search(top_k={k}) (one query per call) over the {nrows}-row database built in this run",
+               "strings": len(strings), "top_k": k, "corpus_rows": int(nrows), "synthetic_weights": bool(es.synthetic),
+               "strings_per_sec": len(strings) / total_s, "ms_for_all": total_s * 1e3,
+               "us_per_string": {"median": lat[len(lat) // 2], "p10": lat[len(lat) // 10], "p90": lat[len(lat) * 9 // 10]},
+               "encode_query_us": {"median": enc_sorted[len(enc_sorted) // 2], "p90": enc_sorted[len(enc_sorted) * 9 // 10]},
+               "search_us_median": lat[len(lat) // 2] - enc_sorted[len(enc_sorted) // 2],
+               "build_full_database_s": round(build_s, 2), "batch_arithmetic": es.batch_arithmetic(),
+               "hits_exact": bool(hits_ok), "parity_checked_strings": len(strings),
+               "parity": "codes, adjusted and raw scores of every hit == oracle/icd_oracle.c over the stored corpus, bit for bit",
+               "stored_row_equals_encode_query_of_its_text": bool(row_ok)}
+        if _CPU_CONFIG0.get("vectors") is not None:
+            m = min(len(_CPU_CONFIG0["vectors"]), len(V))
+            out["max_abs_d_vector_vs_cpu_fp32_forward"] = float(np.max(np.abs(V[:m] - _CPU_CONFIG0["vectors"][:m])))
+            out["vectors_checked_against_cpu"] = m
+        ms.disconnect()
+        return out, es
+    finally:
+        for v, old in saved.items():
+            if old is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = old
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def single_query_extra(ctx, args, index_factory):
@@ -669,6 +781,16 @@ def run_replicated(ctx, args, index_factory=hip_index_factory):
         if mode == MODE_AUTO:
             ex["exact_mode"] = side_workload(ctx, args, index_factory, f"--mode exact: the fp32-MFMA kernel alone, {nq} x {n}x768",
                                              corpus, levels, queries, k, MODE_EXACT, max(3, steps_x // 4))
+    if line is not None and ctx.world == 1 and not args.no_extras and not args.no_rowshard and not ctx.cpu_only and mode == MODE_AUTO:
+        # BASELINE configs[4]'s per-GPU share - one 1.25 M-row shard, the 100 000-query batch in slices - in the N = 1 line too
+        # (reduced passes), through the C-ABI group (one rank: its all-gather step degenerates, everything else is the N > 1 path)
+        try:
+            rs_args = argparse.Namespace(**vars(args))
+            rs_args.rowshard_steps = max(1, min(args.rowshard_steps, args.rowshard_steps_n1))
+            line["extra"]["rowshard"] = run_rowshard(ctx, rs_args, index_factory=index_factory)
+        except Exception as exc:   # pragma: no cover - reported, never fatal
+            import traceback
+            line["extra"]["rowshard"] = {"error": f"{type(exc).__name__}: {exc}", "traceback": traceback.format_exc()[-1500:]}
     if line is not None and ctx.world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(corpus, levels, queries, k)
     # LAST, behind the CPU baseline: with the GPU encoder built BEFORE it in this process the baseline's CPU forward ran 60 x slower
@@ -676,8 +798,14 @@ def run_replicated(ctx, args, index_factory=hip_index_factory):
     # (GPU service first, then a new CPU service: 100-150 ms per string either way), so the order is what guards the baseline.
     if (line is not None and ctx.world == 1 and not ctx.cpu_only and mode == MODE_AUTO and not args.no_extras and not args.no_family
             and not getattr(args, "no_embed_extra", False)):
+        es0 = None
         try:
-            line.setdefault("extra", {})["embed_one_string"] = embed_one_string_extra(ctx)
+            line.setdefault("extra", {})["config0"], es0 = config0_extra(ctx)
+        except Exception as exc:   # pragma: no cover - reported, never fatal
+            import traceback
+            line.setdefault("extra", {})["config0"] = {"error": f"{type(exc).__name__}: {exc}", "traceback": traceback.format_exc()[-1500:]}
+        try:
+            line.setdefault("extra", {})["embed_one_string"] = embed_one_string_extra(ctx, es0)
         except Exception as exc:   # pragma: no cover - reported, never fatal
             line.setdefault("extra", {})["embed_one_string"] = {"error": f"{type(exc).__name__}: {exc}"}
     return line
@@ -728,16 +856,19 @@ def run_config3(ctx, args, index_factory=hip_index_factory):
     return line
 
 
-def native_group_trial(ctx, index, queries, sl, k, ref_out, limit_s):
-    """N > 1 only, AFTER the row-sharded measurement (which runs on the torch.distributed engine): the same slice through the
-    C-ABI group (icd_group_*: RCCL opened by the library, ncclCommInitRank + one grouped ncclAllGather + merge on one
-    stream). It has never run on more than one GPU, so it runs in a side thread under a time limit: the ranks agree on
-    prepare / connect (ShardedSearch._open_native), the first slice must equal the torch engine's output bit for bit, three
-    passes of the slice are timed. A hang costs `limit_s` seconds and is reported; the measurement above is untouched."""
+def native_group_trial(ctx, index, queries, sl, k, ref_outs, limit_s, steps=1):
+    """N > 1 only, AFTER the row-sharded measurement on the torch.distributed engine: the same workload through the C-ABI group
+    (icd_group_*: RCCL opened by the library, ncclCommInitRank + one grouped ncclAllGather + merge on one stream). It has never
+    run on more than one GPU, so it runs in a side thread under a time limit: the ranks agree on prepare / connect
+    (ShardedSearch._open_native), EVERY slice must equal the torch engine's output bit for bit, and then the whole query batch
+    is timed under the same contract as the measurement before it (warm-up pass, barrier + synchronize on both sides, max over
+    ranks). When all of that holds, run_rowshard reports THIS engine's number as the leg's `value` (config.engine says so) and
+    keeps the torch engine's next to it. A hang costs `limit_s` seconds and is reported; the measurement above is untouched."""
     import threading
     from rag_project_icd10_amd.sharded import ROW_SHARD, ShardedSearch
     torch = ctx.torch
     res = {"status": "started"}
+    nq = int(queries.shape[0])
 
     def body():
         try:
@@ -745,16 +876,16 @@ def native_group_trial(ctx, index, queries, sl, k, ref_out, limit_s):
             if sh.native_group is None:
                 res["status"] = "not opened: the ranks agreed on the torch.distributed engine (see the warning on stderr)"
                 return
-            qs = queries[:sl]
-            out = sh.search_reweighted(qs, k)
+            outs = [sh.search_reweighted(queries[s:s + sl], k) for s in range(0, nq, sl)]
             ctx.sync()
-            res["equals_torch_engine"] = bool(all(torch.equal(a, b) for a, b in zip(out, ref_out)))
-            t0 = time.perf_counter()
-            for _ in range(3):
-                sh.search_reweighted(qs, k)
-            ctx.sync()
-            res["ms_per_slice"] = (time.perf_counter() - t0) / 3 * 1e3
-            res["slice"] = int(qs.shape[0])
+            res["equals_torch_engine"] = bool(all(torch.equal(a, b) for o, r in zip(outs, ref_outs) for a, b in zip(o, r)))
+            res["slices_compared"] = len(outs)
+            elapsed, _, _ = ctx.timed(lambda: [sh.search_reweighted(queries[s:s + sl], k) for s in range(0, nq, sl)], steps, 1)
+            res["steps"] = int(steps)
+            res["ms_per_step"] = elapsed / steps * 1e3
+            res["value"] = nq * steps / elapsed
+            res["ms_per_slice"] = elapsed / steps / len(outs) * 1e3
+            res["slice"] = int(min(sl, nq))
             sh.close()
             res["status"] = "ok"
         except Exception as exc:   # reported, never fatal: the line's numbers do not depend on this engine
@@ -873,7 +1004,11 @@ def run_rowshard(ctx, args, index_factory=hip_index_factory, sharded_factory=Non
     stats = index.stats() if hasattr(index, "stats") else {}
     trial = None
     if ctx.world > 1 and sharded_factory is None and getattr(sharded, "native_group", None) is None and not args.no_native_trial:
-        trial = native_group_trial(ctx, index, queries, sl, k, outs[0], args.native_trial_limit)
+        trial = native_group_trial(ctx, index, queries, sl, k, outs, args.native_trial_limit, steps)
+    # the C-ABI group becomes the leg's engine when its trial passed on EVERY rank: opened, every slice bit-identical to the torch
+    # engine's, the timed passes finished (the ranks agree over the CPU side channel: a rank-0-only decision would be a lie)
+    trial_ok = bool(trial) and trial.get("status") == "ok" and bool(trial.get("equals_torch_engine"))
+    native_default = ctx.world > 1 and trial is not None and not ctx.any_rank(not trial_ok)
     line = None
     if ctx.rank == 0:
         flops_gpu = 2.0 * nq * n * dim
@@ -882,18 +1017,25 @@ def run_rowshard(ctx, args, index_factory=hip_index_factory, sharded_factory=Non
         # (slices differ in size only in the last one: price the mean launch against the mean slice)
         achieved = (flops_gpu / launches) / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         traffic, traffic_src = pmc_traffic("coarse_flat_kernel", sl, n, "_rowshard")
+        native_engine = getattr(sharded, "native_group", None) is not None
+        value, ms_step = nq * steps / elapsed, elapsed / steps * 1e3
+        torch_leg = None
+        if native_default:   # (the trial's number: the same passes, the same timing contract, the C-ABI collective)
+            torch_leg = {"value": value, "ms_per_step": ms_step, "what": "the same passes on all_gather_into_tensor (torch.distributed), measured first"}
+            value, ms_step, native_engine = float(trial["value"]), float(trial["ms_per_step"]), True
         line = {
-            "metric": "queries_per_sec", "value": nq * steps / elapsed, "unit": "queries/s",
-            "n_gpus": ctx.world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+            "metric": "queries_per_sec", "value": value, "unit": "queries/s",
+            "n_gpus": ctx.world, "steps": steps, "warmup": warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[4]: {ctx.world} x {n} rows x {dim} corpus row-sharded (generated on device), "
                                    f"{nq} queries replicated, top_k={k}, slices of {sl}: local top-k -> all_gather -> merge + reweight",
                        "rows_per_gpu": n, "corpus_rows_total": ctx.world * n, "queries": nq, "slice": sl, "dim": dim, "top_k": k,
-                       "parallelism": f"row-sharded x{ctx.world}", "collective": ("ncclAllGather inside icd_group_search (C ABI, RCCL opened by the library)" if getattr(sharded, "native_group", None) is not None
+                       "parallelism": f"row-sharded x{ctx.world}", "collective": ("ncclAllGather inside icd_group_search (C ABI, RCCL opened by the library)" if native_engine
                                       else "all_gather_into_tensor (torch.distributed)") if ctx.world > 1 else "none (one shard)",
                        "collective_ranks": dist.get_world_size() if ctx.world > 1 else 1,
-                       "engine": getattr(sharded, "engine", "torch.distributed") if ctx.world > 1 or getattr(sharded, "native_group", None) is not None else "icd_group (C ABI)"},
-            "whole_job_tflops": ctx.world * flops_gpu * steps / elapsed / 1e12,
+                       "engine": "icd_group (C ABI)" if native_engine or ctx.world == 1 else getattr(sharded, "engine", "torch.distributed")},
+            "torch_distributed_engine": torch_leg,
+            "whole_job_tflops": ctx.world * flops_gpu / (ms_step * 1e-3) / 1e12,
             "ids_exact_on_sample": ids_ok, "raw_scores_exact_on_sample": raw_ok, "adjusted_sorted": sorted_ok,
             "adjusted_scores_exact_on_sample": adj_ok, "sample_queries": int(m), "sample_slices": int(len(starts)),
             "sample_rule": f"{per} queries of every slice of {sl} (the last slice has {nq - starts[-1]}), spread by stride",
@@ -1073,7 +1215,8 @@ def main(argv=None):
     ap.add_argument("--rowshard-queries", type=int, default=100_000)
     ap.add_argument("--rowshard-slice", type=int, default=16384)
     ap.add_argument("--rowshard-steps", type=int, default=3, help="passes of the row-sharded workload (each ~0.2 s per GPU)")
-    ap.add_argument("--no-rowshard", action="store_true", help="N > 1: skip the row-sharded leg of the default run")
+    ap.add_argument("--no-rowshard", action="store_true", help="skip the row-sharded leg of the default run (N > 1: `rowshard`; N = 1: `extra.rowshard`)")
+    ap.add_argument("--rowshard-steps-n1", type=int, default=2, help="N = 1: passes of the row-sharded leg inside the default line (extra.rowshard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the real-size / clustered / k = 20 / family / exact-mode side workloads")
     ap.add_argument("--no-family", action="store_true", help="N = 1: skip the k = 20 and ICD-shaped (family) side workloads")

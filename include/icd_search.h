@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define ICD_ABI_VERSION 6   /* 6: icd_encoder_encode_many; ICD_ENCODER_MAX_TOKENS 512, ICD_ENCODER_MAX_SEQS 64 (round 6). 5: icd_debug_unpack_query_slices, icd_debug_set_stream_one, icd_debug_set_pacing, icd_debug_set_exact_narrow, icd_debug_set_host_one, icd_split_bf16x3, icd_encoder_create / _encode / _destroy, icd_pack_winners (round 5). 4: icd_debug_set_family_order, icd_debug_set_center, icd_stats.centered / mean_share appended, icd_group_prepare / icd_group_connect (round 4). 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
+#define ICD_ABI_VERSION 6   /* 6: icd_encoder_encode_many; the process-wide icd_debug_set_* switches became per-index options (icd_index_create flags, icd_index_set_option); ICD_ENCODER_MAX_TOKENS 512, ICD_ENCODER_MAX_SEQS 64 (round 6). 5: icd_unpack_query_slices, icd_debug_set_stream_one, icd_debug_set_pacing, icd_debug_set_exact_narrow, icd_debug_set_host_one, icd_split_bf16x3, icd_encoder_create / _encode / _destroy, icd_pack_winners (round 5). 4: icd_debug_set_family_order, icd_debug_set_center, icd_stats.centered / mean_share appended, icd_group_prepare / icd_group_connect (round 4). 3: icd_stats.sparse_fallback_armed appended, icd_debug_set_create_probe, icd_packed_attention (round 3). 2: + icd_hier_rescore, icd_score_stats, icd_cosine_rows, icd_debug_set_permute (round 2), the group entry points (round 3) */
 #define ICD_MAX_K 128
 
 typedef struct icd_index icd_index;
@@ -131,10 +131,19 @@ int icd_device_count(void);
  * services/milvus_service.py:247). The corpus is copied to HBM; the caller's buffer is not retained.
  * max_nq: largest query batch a single search call will receive (workspace is sized for it).
  * max_k:  largest k (<= ICD_MAX_K).
+ * flags:  ICD_CREATE_CORPUS_ON_DEVICE - `corpus` (and `levels`) are device pointers; the rest are A/B and test options of
+ *         THIS index (results are identical with or without them): ICD_CREATE_ROW_ORDER keeps the fp16 corpus copy in row
+ *         order instead of the golden-ratio permutation (only the share of certified queries changes); ICD_CREATE_NO_PROBE
+ *         skips the corpus-shape probe (with it, an index whose max_nq allows batches of >= 2 048 queries searches 2 048
+ *         evenly spaced rows of its own corpus once and starts large batches on the wide partition, icd_stats.wide_mode, when
+ *         most of them could not be certified from the narrow plan's lists - a corpus of tight families of near-identical
+ *         rows; later searches keep deciding from their own counters); ICD_CREATE_NO_CENTER keeps the fp16 image uncentred
+ *         whatever the rows look like (icd_stats.centered).
  */
+enum { ICD_CREATE_CORPUS_ON_DEVICE = 1, ICD_CREATE_ROW_ORDER = 2, ICD_CREATE_NO_PROBE = 4, ICD_CREATE_NO_CENTER = 8 };
 int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t *levels,
                      int64_t id_base, int32_t device, int32_t max_nq, int32_t max_k,
-                     int32_t corpus_on_device, icd_index **out);
+                     int32_t flags, icd_index **out);
 
 int icd_index_destroy(icd_index *idx);
 
@@ -237,7 +246,8 @@ int icd_score_stats(int32_t device, const double *scores, const int32_t *order, 
 
 /* The winners of a rescored batch for the host in ONE array (row N2: what MultiDiagnosisService.match_diagnoses_batch turns into
  * Candidate objects - reference services/multi_diagnosis_service.py:147-176 builds them from the rescored hit dicts): for the
- * top kk <= k positions of every query, out[c][q][j] (doubles, c = 0 .. 7) = id, raw score and level-reweighted score of the hit
+ * top kk <= k positions of every query, out[c][q][j] (8-byte slots, c = 0 .. 7; doubles except c = 0, which holds the int64 id's
+ * BIT PATTERN: reinterpret that plane as int64) = id, raw score and level-reweighted score of the hit
  * order[q][j] points at, order[q][j] itself, and enhanced / vector-similarity / hierarchy-boost / uncertainty-boost [q][j] of
  * icd_hier_rescore's outputs. One launch and one device-to-host copy instead of three gathers, five slices and eight copies.
  * All pointers device; order int32 [nq][k], ids int64 [nq][k], raw float32 [nq][k], the rest float64 [nq][k]; out [8][nq][kk]. */
@@ -289,50 +299,30 @@ int icd_index_set_chunks(icd_index *idx, int32_t chunks);
  * second pass but never switches to the wide partition (every large batch runs narrow plan + second pass). */
 int icd_index_set_second_pass(icd_index *idx, int32_t enabled);
 
-/* Test switch, process-wide, read by icd_index_create: 0 keeps the fp16 corpus copy in row order instead of the
- * golden-ratio permutation (results are identical; only the share of certified queries changes). Default 1. */
-int icd_debug_set_permute(int32_t enabled);
-
-/* Test switch, process-wide, read by icd_index_create (default 1): 0 skips the corpus-shape probe. With it, an index whose
- * max_nq allows large batches (>= 2 048 queries) searches 2 048 evenly spaced rows of its own corpus once at create and
- * starts large batches on the wide partition (icd_stats.wide_mode) when most of them could not be certified from the
- * narrow plan's lists - a corpus of tight families of near-identical rows. A performance decision only: results are
- * identical either way, and later searches keep deciding from their own counters. */
-int icd_debug_set_create_probe(int32_t enabled);
-
-/* Test switch, process-wide, read by every search (default 1): 0 keeps the wide-window finalize of a family-shaped corpus
- * (icd_stats.wide_mode) in batch order instead of visiting the queries family by family, XCD by XCD (finalize.hpp,
- * order_keys_kernel / order_scatter_kernel). A performance decision only: results are identical either way. */
-int icd_debug_set_family_order(int32_t enabled);
-
-/* Test switch, process-wide, read by icd_index_create (default 1): 0 keeps the fp16 corpus image uncentred whatever the
- * rows look like (icd_stats.centered). A performance decision only: results are identical either way. */
-int icd_debug_set_center(int32_t enabled);
-
-/* Test / A-B switch, process-wide, read by every search (default 1): 0 sends calls of one or two queries (the reference's own
- * call shape, services/milvus_service.py:280-285) through the general streaming path - memset, stream_topk, reduce_lists,
- * finalize: four operations - instead of the single-launch kernel that folds all of it. Results are identical either way. */
-int icd_debug_set_stream_one(int32_t enabled);
-
-/* Test / A-B switch, process-wide, read by every search (default 3 = both bits): how a HOST caller's ONE query - the reference's
- * own call shape, MilvusClient.search(data=[query_vector.tolist()]), services/milvus_service.py:280-285 - reaches and leaves the
- * single-launch kernel. Bit 1: the vector travels in the kernel's arguments (no host-to-device copy command in front of the
- * launch). Bit 2: the call returns when the kernel's last work-group has stored the call's sequence number behind the outputs
- * in the index's mapped host block (polled for a bounded time, then the stream synchronisation as before) instead of waiting for
- * the stream's completion signal. 0 = the copy + hipStreamSynchronize form. Results are identical either way. */
-int icd_debug_set_host_one(int32_t bits);
-
-/* Test / A-B switch, process-wide, read by every search (default 3, 2: epochs of 8 tiles, classes within 16 tiles): the coarse sweep over an fp16 image that does not stay
- * in the Infinity Cache (a row shard) paces the work-groups that sweep the same corpus tiles: epochs of 2^shift tiles, a
- * class stays within `lead` epochs, so that a tile is fetched once per XCD (csrc/coarse_flat_kernel.hpp, VAR 67108864).
- * shift < 0 turns pacing off. A performance decision only: results are identical either way. No reference counterpart. */
-int icd_debug_set_pacing(int32_t shift, int32_t lead);
-
-/* Test / A-B switch, process-wide, read by every search (default 1): 0 makes ICD_MODE_EXACT at k > 32 keep lists of KP >= k
- * (64- / 128-entry candidate buffers, one work-group per CU) instead of certified lists of 32 over row-strided chunks with a
- * re-search of the queries the certificate cannot clear. Results are identical either way (the k range is the reference's:
- * /query searches top_k * 2 with top_k <= 50, models/icd_models.py:138, services/multi_diagnosis_service.py:153). */
-int icd_debug_set_exact_narrow(int32_t enabled);
+/* A/B and test options of ONE index (round 6: these were process-wide icd_debug_set_* switches; a serving process with two
+ * indexes must not have one caller's test hook change the other's behaviour). Every one is a performance decision only:
+ * results are identical whatever it is set to. Defaults in brackets. Calls on one handle are serialised with its searches.
+ *   ICD_OPT_FAMILY_ORDER [1]  0 keeps the wide-window finalize of a family-shaped corpus (icd_stats.wide_mode) in batch order
+ *                             instead of visiting the queries family by family, XCD by XCD (finalize.hpp, order_*_kernel).
+ *   ICD_OPT_STREAM_ONE   [1]  0 sends calls of one or two queries (the reference's own call shape,
+ *                             services/milvus_service.py:280-285) through the general streaming path - memset, stream_topk,
+ *                             reduce_lists, finalize: four operations - instead of the single-launch kernel that folds all of it.
+ *   ICD_OPT_HOST_ONE     [3]  how a HOST caller's ONE query reaches and leaves the single-launch kernel. Bit 1: the vector
+ *                             travels in the kernel's arguments (no host-to-device copy command in front of the launch). Bit 2:
+ *                             the call returns when the kernel's last work-group has stored the call's sequence number behind
+ *                             the outputs in the index's mapped host block (polled for a bounded time, then the stream
+ *                             synchronisation as before). 0 = the copy + hipStreamSynchronize form.
+ *   ICD_OPT_PACING_SHIFT [3], ICD_OPT_PACING_LEAD [2]  the coarse sweep over an fp16 image that does not stay in the Infinity
+ *                             Cache (a row shard) paces the work-groups that sweep the same corpus tiles: epochs of 2^shift
+ *                             tiles, a class stays within `lead` epochs, so that a tile is fetched once per XCD
+ *                             (csrc/coarse_flat_kernel.hpp). shift < 0 turns pacing off.
+ *   ICD_OPT_EXACT_NARROW [1]  0 makes ICD_MODE_EXACT at k > 32 keep lists of KP >= k (64- / 128-entry candidate buffers, one
+ *                             work-group per CU) instead of certified lists of 32 over row-strided chunks with a re-search of
+ *                             the queries the certificate cannot clear (k range: /query searches top_k * 2 with top_k <= 50,
+ *                             models/icd_models.py:138, services/multi_diagnosis_service.py:153).
+ * No reference counterpart (the reference delegates the search to Milvus Lite). */
+enum { ICD_OPT_FAMILY_ORDER = 1, ICD_OPT_STREAM_ONE = 2, ICD_OPT_HOST_ONE = 3, ICD_OPT_PACING_SHIFT = 4, ICD_OPT_PACING_LEAD = 5, ICD_OPT_EXACT_NARROW = 6 };
+int icd_index_set_option(icd_index *idx, int32_t option, int32_t value);
 
 /* Test entry: the unpack step of a query-sharded icd_group_search (one kernel: the all-gathered PADDED slices -> the
  * contiguous [nq][k] outputs) on a caller-made receive buffer, so that its index arithmetic can be checked for any world
@@ -340,7 +330,7 @@ int icd_debug_set_exact_narrow(int32_t enabled);
  * per = width * k, four arrays back to back - adj f64 [world][per] | ids i64 [world][per] | raw f32 [world][per] |
  * levels i32 [world][per]; rank r's slice holds queries [lo_r, hi_r) (contiguous split, the first nq % world ranks one
  * more) in its first hi_r - lo_r rows. Outputs: device pointers, [nq][k]. No reference counterpart (single process). */
-int icd_debug_unpack_query_slices(int32_t device, const void *gathered, int32_t world, int64_t nq, int32_t k, double *out_adj,
+int icd_unpack_query_slices(int32_t device, const void *gathered, int32_t world, int64_t nq, int32_t k, double *out_adj,
                                   float *out_raw, int64_t *out_ids, int32_t *out_levels, void *stream);
 
 /* ---- the sentence encoder for SMALL inputs ------------------------------------------------

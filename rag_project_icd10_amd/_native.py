@@ -26,14 +26,17 @@ EXPORTED_SYMBOLS = (
     "icd_abi_version", "icd_last_error", "icd_device_count", "icd_index_create", "icd_index_destroy",
     "icd_index_search", "icd_index_search_reweighted", "icd_merge_topk", "icd_index_lookup_levels",
     "icd_index_stats", "icd_index_set_chunks", "icd_index_debug_counters", "icd_index_set_profiling",
-    "icd_index_last_profile", "icd_index_profile_summary", "icd_debug_set_permute", "icd_debug_set_create_probe", "icd_debug_set_family_order", "icd_debug_set_center", "icd_packed_attention",
+    "icd_index_last_profile", "icd_index_profile_summary", "icd_index_set_option", "icd_packed_attention",
     "icd_hier_rescore",
     "icd_score_stats",
     "icd_cosine_rows",
     "icd_index_set_second_pass",
     "icd_group_unique_id", "icd_group_create", "icd_group_prepare", "icd_group_connect", "icd_group_search", "icd_group_destroy",
-    "icd_debug_unpack_query_slices", "icd_debug_set_stream_one", "icd_debug_set_host_one", "icd_debug_set_pacing", "icd_debug_set_exact_narrow", "icd_split_bf16x3", "icd_encoder_create", "icd_encoder_encode", "icd_encoder_encode_many", "icd_encoder_destroy", "icd_pack_winners",
+    "icd_unpack_query_slices", "icd_split_bf16x3", "icd_encoder_create", "icd_encoder_encode", "icd_encoder_encode_many", "icd_encoder_destroy", "icd_pack_winners",
 )
+# include/icd_search.h: icd_index_create flags and icd_index_set_option ids (A/B and test options of ONE index)
+CREATE_CORPUS_ON_DEVICE, CREATE_ROW_ORDER, CREATE_NO_PROBE, CREATE_NO_CENTER = 1, 2, 4, 8
+OPTIONS = {"family_order": 1, "stream_one": 2, "host_one": 3, "pacing_shift": 4, "pacing_lead": 5, "exact_narrow": 6}
 GROUP_ROW_SHARD = 0
 GROUP_QUERY_SHARD = 1
 GROUP_ID_BYTES = 128
@@ -104,22 +107,15 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.icd_index_stats.argtypes = [vp, C.POINTER(_Stats)]
     lib.icd_index_set_chunks.argtypes = [vp, i32]
     lib.icd_index_set_second_pass.argtypes = [vp, i32]
+    lib.icd_index_set_option.argtypes = [vp, i32, i32]
     lib.icd_group_unique_id.argtypes = [vp]
     lib.icd_group_create.argtypes = [vp, vp, i32, i32, i32, i32, i32, C.POINTER(vp)]
     lib.icd_group_prepare.argtypes = [vp, i32, i32, i32, i32, i32, i32, C.POINTER(vp)]
     lib.icd_group_connect.argtypes = [vp, vp]
     lib.icd_group_search.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, vp, vp]
     lib.icd_group_destroy.argtypes = [vp]
-    lib.icd_debug_set_permute.argtypes = [i32]
-    lib.icd_debug_set_create_probe.argtypes = [i32]
-    lib.icd_debug_set_family_order.argtypes = [i32]
-    lib.icd_debug_set_center.argtypes = [i32]
-    lib.icd_debug_set_stream_one.argtypes = [i32]
-    lib.icd_debug_set_host_one.argtypes = [i32]
-    lib.icd_debug_set_pacing.argtypes = [i32, i32]
-    lib.icd_debug_set_exact_narrow.argtypes = [i32]
     lib.icd_split_bf16x3.argtypes = [i32, vp, i64, i32, i64, i32, vp, vp]
-    lib.icd_debug_unpack_query_slices.argtypes = [i32, vp, i32, i64, i32, vp, vp, vp, vp, vp]
+    lib.icd_unpack_query_slices.argtypes = [i32, vp, i32, i64, i32, vp, vp, vp, vp, vp]
     lib.icd_packed_attention.argtypes = [i32, vp, i64, vp, i32, i32, i32, i32, vp, i64, vp]
     lib.icd_encoder_create.argtypes = [i32, C.POINTER(_EncoderDesc), C.POINTER(vp)]
     lib.icd_encoder_encode.argtypes = [vp, vp, vp, i32, i32, i32, vp, i32, vp, vp]
@@ -175,7 +171,9 @@ class IcdIndex:
     """
 
     def __init__(self, corpus, levels=None, *, device: int = 0, max_nq: int = 16384, max_k: int = 100,
-                 id_base: int = 0):
+                 id_base: int = 0, permute: bool = True, probe: bool = True, center: bool = True):
+        """permute / probe / center: A/B and test options of THIS index (icd_index_create flags ICD_CREATE_ROW_ORDER / _NO_PROBE /
+        _NO_CENTER): performance decisions only, results are identical either way"""
         self._lib = load_library()
         self._h = C.c_void_p()
         on_dev = 0
@@ -210,7 +208,9 @@ class IcdIndex:
             lptr = lv.ctypes.data if lv is not None else None
         self.n, self.dim, self.device, self.max_nq, self.max_k = int(n), int(dim), int(device), int(max_nq), int(max_k)
         self.id_base = int(id_base)
-        _check(self._lib, self._lib.icd_index_create(cptr, n, dim, lptr, id_base, device, max_nq, max_k, on_dev,
+        flags = ((CREATE_CORPUS_ON_DEVICE if on_dev else 0) | (0 if permute else CREATE_ROW_ORDER) | (0 if probe else CREATE_NO_PROBE)
+                 | (0 if center else CREATE_NO_CENTER))
+        _check(self._lib, self._lib.icd_index_create(cptr, n, dim, lptr, id_base, device, max_nq, max_k, flags,
                                                       C.byref(self._h)))
 
     # -- lifecycle -----------------------------------------------------------------------------------
@@ -351,6 +351,11 @@ class IcdIndex:
         """test / A-B switch: the second coarse pass over uncertified queries (default on), and the adaptive list count of
         large batches that follows from its counters"""
         _check(self._lib, self._lib.icd_index_set_second_pass(self._h, 0 if not enabled else (1 if adaptive else 2)))
+
+    def set_option(self, name: str, value: int):
+        """A/B and test options of this index (icd_index_set_option; `name` one of OPTIONS): family_order, stream_one, host_one,
+        pacing_shift, pacing_lead, exact_narrow - performance decisions only, results are identical whatever they are set to"""
+        _check(self._lib, self._lib.icd_index_set_option(self._h, OPTIONS[name], int(value)))
 
     def set_profiling(self, enabled, every: int = 1):
         """hipEvents around the kernels of every `every`-th search (read back by profile_summary / last_profile)"""
@@ -499,7 +504,8 @@ def hier_rescore(adj, ids, row_tags, q_params, weights, id_base: int = 0):
 
 
 def pack_winners(order, ids, raw, adj, enhanced, vs, hb, boost, kk: int):
-    """The top kk rescored hits of every query as ONE float64 tensor [8, nq, kk] on the device (icd_pack_winners): id, raw score,
+    """The top kk rescored hits of every query as ONE float64 tensor [8, nq, kk] on the device (icd_pack_winners): id (plane 0
+    holds the int64 ids' BIT PATTERNS: read it with .view(torch.int64)), raw score,
     level-reweighted score (of the hit order points at), order, enhanced, vector similarity, hierarchy boost, uncertainty boost."""
     import torch
     lib = load_library()

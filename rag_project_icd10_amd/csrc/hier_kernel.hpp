@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void hier_rescore_kernel(HierArgs a) {
 #pragma clang fp contract(fast)
 
 // The winners of a batch for the host: what MultiDiagnosisService.match_diagnoses_batch needs of the top `kk` rescored hits of
-// every query, as ONE array of doubles [8][nq][kk] (one device-to-host copy; exact for the int64 ids, the int32 order and the
+// every query, as ONE array of doubles [8][nq][kk] (one device-to-host copy; the int64 ids travel as bit patterns in their slots - read them back as int64 -, exact for the int32 order and the
 // float32 raw scores alike): 0 id, 1 raw score, 2 level-reweighted score (both of the hit the order points at), 3 order,
 // 4 enhanced, 5 vector similarity, 6 hierarchy boost, 7 uncertainty boost (the last four already in final order).
 struct PackWinnersArgs {
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void pack_winners_kernel(PackWinnersArgs a) {
     const size_t src = (size_t)q * a.k + j;
     const int o = a.order[src];
     const size_t hit = (size_t)q * a.k + (o < 0 ? 0 : o);   // (past the hits: a valid slot, the host stops at order < 0)
-    a.out[0 * per + i] = (double)a.ids[hit];
+    a.out[0 * per + i] = __longlong_as_double(a.ids[hit]);   // the id's BIT PATTERN in the slot (ids are arbitrary int64: id_base of a shard; a double holds integers to 2^53 only)
     a.out[1 * per + i] = (double)a.raw[hit];
     a.out[2 * per + i] = a.adj[hit];
     a.out[3 * per + i] = (double)o;

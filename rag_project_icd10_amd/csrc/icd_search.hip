@@ -43,15 +43,6 @@ using namespace icd;
 namespace {
 
 thread_local std::string g_err = "";
-bool g_permute = true;   // test switch (icd_debug_set_permute): row order of the fp16 corpus copy
-bool g_probe = true;     // test switch (icd_debug_set_create_probe): the corpus-shape probe of icd_index_create
-bool g_center = true;         // test switch (icd_debug_set_center): the fp16 corpus image is centred when the rows share a large common component
-int g_pace_shift = 3, g_pace_lead = 2;   // test switch (icd_debug_set_pacing): epochs of 2^shift tiles, classes kept within `lead` epochs; shift < 0: no pacing
-bool g_exact_narrow = true;   // test switch (icd_debug_set_exact_narrow): EXACT mode at k > 32 runs certified lists of 32 over row-strided chunks
-int g_host_one = 3;           // test switch (icd_debug_set_host_one): a host caller's ONE query 1 = travels in the kernel arguments, 2 = completion by a polled word
-bool g_stream_one = true;     // test switch (icd_debug_set_stream_one): one or two queries per call take the single-launch streaming kernel
-bool g_family_order = true;   // test switch (icd_debug_set_family_order): the wide-window finalize visits the queries in family order
-
 int fail(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
@@ -155,6 +146,16 @@ hipError_t dmalloc(T **p, size_t count) {
 struct icd_index {
     uint32_t magic = 0x1CD10A3Du;
     int device = 0;
+    // A/B and test options, PER HANDLE (icd_index_create flags, icd_index_set_option): performance decisions only, results are
+    // identical whatever they are set to. Read and written under `mu`.
+    bool opt_permute = true;        // ICD_CREATE_ROW_ORDER clears it: row order of the fp16 corpus copy
+    bool opt_probe = true;          // ICD_CREATE_NO_PROBE: the corpus-shape probe of icd_index_create
+    bool opt_center = true;         // ICD_CREATE_NO_CENTER: the fp16 image is centred when the rows share a large common component
+    int opt_pace_shift = 3, opt_pace_lead = 2;   // ICD_OPT_PACING_*: epochs of 2^shift tiles, classes kept within `lead` epochs; shift < 0: no pacing
+    bool opt_exact_narrow = true;   // ICD_OPT_EXACT_NARROW: EXACT mode at k > 32 runs certified lists of 32 over row-strided chunks
+    int opt_host_one = 3;           // ICD_OPT_HOST_ONE: a host caller's ONE query 1 = travels in the kernel arguments, 2 = completion by a polled word
+    bool opt_stream_one = true;     // ICD_OPT_STREAM_ONE: one or two queries per call take the single-launch streaming kernel
+    bool opt_family_order = true;   // ICD_OPT_FAMILY_ORDER: the wide-window finalize visits the queries in family order
     int64_t n = 0, id_base = 0;
     int n_pad = 0;
     int dim = 0;
@@ -717,14 +718,14 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         // (up to FOUR queries: at eight the sweep is bound by the lanes' fmaf chains, not by memory - 40 of a wave's 64 lanes hold
         //  rows in this form - and the general path is 12 us faster: profiles/r05_single_query.log)
         const int qb1 = nq <= 1 ? 1 : (nq <= 2 ? 2 : 4);
-        bool one = nq <= 4 && kpx == 16 && g_stream_one && plan_stream_one((int)x->n, x->dim, x->num_cu, qb1, 64 * 2, &pl) &&
+        bool one = nq <= 4 && kpx == 16 && x->opt_stream_one && plan_stream_one((int)x->n, x->dim, x->num_cu, qb1, 64 * 2, &pl) &&
                    (size_t)nq * pl.nwg * kpx * 2 <= x->lists_cap;
         if (one) {   // up to four queries (the reference's call shape is ONE; a /query request batches its D diagnoses): ONE launch,
                      // no memset, no reduction, no finalize
             rec(x, 3, s);
             const float *hq = qb1 == 1 ? x->host_q : nullptr;   // (a host caller's ONE query: search_common left the copy out)
             if (!hq) { const int rcq = stage_host_query(); if (rcq) return rcq; }
-            const bool poll = x->host_one_call && (g_host_one & 2) != 0;
+            const bool poll = x->host_one_call && (x->opt_host_one & 2) != 0;
             const int rc1 = qb1 == 1 ? launch_stream_one<16, 2, 1>(x, dq, 1, f, s, hq, poll) : qb1 == 2 ? launch_stream_one<16, 2, 2>(x, dq, 2, f, s)
                           : launch_stream_one<16, 2, 4>(x, dq, (int)nq, f, s);
             rec(x, 4, s);
@@ -737,7 +738,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         return run_exact(nullptr, nullptr, p_sparse, false, true);
     }
     { const int rcq = stage_host_query(); if (rcq) return rcq; }
-    if (!use_fast && kpx > 32 && g_exact_narrow && nq > ST_MAX_ACTIVE && row_tiles >= 64) {
+    if (!use_fast && kpx > 32 && x->opt_exact_narrow && nq > ST_MAX_ACTIVE && row_tiles >= 64) {
         // ---- k > 32: NARROW certified lists -----------------------------------------------------------------------------------
         // Lists of KP >= k need 64- or 128-entry candidate buffers: one work-group of four waves per CU at k <= 64, of two above
         // (0.39 / 0.15 of the fp32 MFMA peak at k = 50 / 100, against 0.59 at k = 20). Instead: the k <= 32 configuration (lists
@@ -748,12 +749,13 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         // Results are the exact top-k either way.
         HIP_TRY(hipMemsetAsync(x->nflag, 0, sizeof(int), s));
         const int slots = x->num_cu * 2;
+        const int mtx_n = (nq + 127) / 128;                   // query tiles of THIS configuration (four waves x 32 queries; `mtx` above counts the KP >= k configuration's tiles, 64 queries at k > 64: ADVICE r5)
         const int p_need = std::max(2, (k + 7) / 8);          // ~8 members of the top-k per list when they spread evenly
         int pn = p_need;
         {   // the count at or above p_need whose last round of work-groups is fullest
             double best = 0;
-            for (int c = p_need; c <= std::min(FIN_MAX_CAND_X / 32, std::max(p_need + 8, slots / std::max(1, mtx))); ++c) {   // (a short batch: enough chunks to fill the chip)
-                const long items = (long)mtx * c;
+            for (int c = p_need; c <= std::min(FIN_MAX_CAND_X / 32, std::max(p_need + 8, slots / std::max(1, mtx_n))); ++c) {   // (a short batch: enough chunks to fill the chip)
+                const long items = (long)mtx_n * c;
                 const double util = (double)items / (double)(((items + slots - 1) / slots) * slots);
                 if (util > best + 1e-9) { best = util; pn = c; }
             }
@@ -766,7 +768,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             a.corpus = x->corpus; a.queries = dq; a.nq = nq; a.n = (int)x->n; a.dim = x->dim; a.P = pn; a.strided = 1;
             a.rows_per_chunk = 128;   // (unused by the strided form)
             a.part_scores = x->partx_s; a.part_rows = x->partx_r;
-            int rc = launch_exact<32, 1, 4, 62, 16, 2, 16>(x, a, mtx, s);
+            int rc = launch_exact<32, 1, 4, 62, 16, 2, 16>(x, a, mtx_n, s);
             if (rc) return rc;
             rec(x, 4, s);
             FinArgs g = f;
@@ -1036,9 +1038,9 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
             // tile is fetched once per XCD instead of once per work-group (coarse_flat_kernel.hpp, VAR 67108864)
             const int t0 = flat_class_period(U, ctiles);
             const int members0 = t0 > 0 ? nwg / t0 : 0;
-            const int epochs = g_pace_shift >= 0 ? (U >> g_pace_shift) + 1 : 0;
-            if (g_pace_shift >= 0 && members0 >= 4 && (size_t)t0 * epochs <= PACE_WORDS) {
-                a.pace = x->pace; a.pace_period = t0; a.pace_epochs = epochs; a.pace_shift = g_pace_shift; a.pace_lead = std::max(1, g_pace_lead);
+            const int epochs = x->opt_pace_shift >= 0 ? (U >> x->opt_pace_shift) + 1 : 0;
+            if (x->opt_pace_shift >= 0 && members0 >= 4 && (size_t)t0 * epochs <= PACE_WORDS) {
+                a.pace = x->pace; a.pace_period = t0; a.pace_epochs = epochs; a.pace_shift = x->opt_pace_shift; a.pace_lead = std::max(1, x->opt_pace_lead);
                 HIP_TRY(hipMemsetAsync(x->pace, 0, (size_t)t0 * epochs * sizeof(unsigned int), s));
             }
             rc = launch_coarse_flat<768, CF_PACED_VAR>(x, a, nwg, s);
@@ -1059,7 +1061,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
 #ifdef ICD_ABLATE
         if (getenv("ICD_FIN_SKIP_WALK")) g.skip_walk = 1;
 #endif
-        if (wide_fin && g_family_order && nq >= 1024) {
+        if (wide_fin && x->opt_family_order && nq >= 1024) {
             // every query's window is its family (the corpus is in code order): visit the queries family by family, XCD by XCD
             OrderArgs o{};
             o.part_scores = g.part_scores; o.part_rows = g.part_rows; o.P = g.P; o.KP = g.KP; o.nq = nq;
@@ -1156,10 +1158,12 @@ int icd_device_count(void) {
 }
 
 int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t *levels, int64_t id_base,
-                     int32_t device, int32_t max_nq, int32_t max_k, int32_t corpus_on_device,
+                     int32_t device, int32_t max_nq, int32_t max_k, int32_t flags,
                      icd_index **out) {
     if (!out) return fail(ICD_ERR_INVALID, "out is NULL");
     *out = nullptr;
+    if (flags & ~(ICD_CREATE_CORPUS_ON_DEVICE | ICD_CREATE_ROW_ORDER | ICD_CREATE_NO_PROBE | ICD_CREATE_NO_CENTER)) return fail(ICD_ERR_INVALID, "flags=0x%x: unknown bits", flags);
+    const int32_t corpus_on_device = flags & ICD_CREATE_CORPUS_ON_DEVICE;
     if (!corpus || n <= 0 || n > 0x7FFFFF00ll) return fail(ICD_ERR_INVALID, "corpus NULL or n=%lld out of range", (long long)n);
     if (dim <= 0 || dim % 32 != 0 || dim > 4096) return fail(ICD_ERR_UNSUPPORTED, "dim=%d: must be a multiple of 32, <= 4096", dim);
     if (max_nq <= 0 || max_k <= 0 || max_k > ICD_MAX_K) return fail(ICD_ERR_INVALID, "max_nq=%d max_k=%d (max_k <= %d)", max_nq, max_k, ICD_MAX_K);
@@ -1175,6 +1179,7 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     icd_index *x = new (std::nothrow) icd_index();
     if (!x) return fail(ICD_ERR_NOMEM, "host allocation failed");
     x->device = device; x->n = n; x->id_base = id_base; x->dim = dim;
+    x->opt_permute = !(flags & ICD_CREATE_ROW_ORDER); x->opt_probe = !(flags & ICD_CREATE_NO_PROBE); x->opt_center = !(flags & ICD_CREATE_NO_CENTER);
     x->n_pad = (int)(((n + 127) / 128 + FLAT_SPARE_TILES) * 128);   // (zero tiles behind the fp16 image: plan_flat_tiles)
     x->max_nq = max_nq; x->max_nq_pad = ((max_nq + 127) / 128) * 128; x->max_k = max_k;
     x->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1212,9 +1217,9 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
         // Row order of the fp16 copy: a corpus in code order keeps families of near-identical rows next to each
         // other, so ONE candidate list would collect a query's whole family, end on a bound inside it and fail the
         // certificate. An affine permutation with a golden-ratio stride spreads neighbours evenly over the lists;
-        // finalize maps list positions back with the same formula (no table). (icd_debug_set_permute(0) keeps the order:
+        // finalize maps list positions back with the same formula (no table). (ICD_CREATE_ROW_ORDER keeps the order:
         // a process-wide test switch, read at create; results are identical either way.)
-        if (n > 2 && g_permute) {
+        if (n > 2 && x->opt_permute) {
             long long a_ = (long long)(0.6180339887498949 * (double)n) | 1;
             auto gcd = [](long long u, long long v) { while (v) { const long long t = u % v; u = v; v = t; } return u; };
             while (gcd(a_, n) != 1) a_ += 2;
@@ -1237,7 +1242,7 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
             float h2[2] = {0.f, 0.f};
             CR_TRY(hipMemcpy(h2, out2, sizeof h2, hipMemcpyDeviceToHost));
             x->mean_share = h2[1] > 0.f ? h2[0] / h2[1] : 0.f;
-            if (!g_center || !(x->mean_share >= CENTER_MIN_SHARE) || !std::isfinite(h2[0]) || !std::isfinite(h2[1])) { hipFree(x->cmean); x->cmean = nullptr; }
+            if (!x->opt_center || !(x->mean_share >= CENTER_MIN_SHARE) || !std::isfinite(h2[0]) || !std::isfinite(h2[1])) { hipFree(x->cmean); x->cmean = nullptr; }
         }
         // pass 1: largest component of the corpus -> ONE power-of-two scale for its fp16 image; pass 2: convert
         ConvertArgs cv{};
@@ -1333,7 +1338,7 @@ int icd_index_create(const float *corpus, int64_t n, int32_t dim, const int32_t 
     // large batch (each finds itself and its family), and the same rule decides. A fresh index on a family corpus then
     // answers its FIRST large batch in 1.5 ms per 10 000 queries instead of 2.0-2.2; a Gaussian corpus flags nothing
     // and stays narrow. Costs one 2 048-query search at create; state and counters are reset afterwards.
-    if (x->fast && max_nq >= WIDE_MIN_NQ && n >= (int64_t)4 * WIDE_MIN_NQ && dim % 4 == 0 && g_probe) {
+    if (x->fast && max_nq >= WIDE_MIN_NQ && n >= (int64_t)4 * WIDE_MIN_NQ && dim % 4 == 0 && x->opt_probe) {
         const int pq = WIDE_MIN_NQ, pk = std::min(10, max_k);
         hipLaunchKernelGGL(gather_rows_kernel, dim3(pq), dim3(192), 0, 0, x->corpus, x->qdev, (long long)(n / pq), dim, pq);
         CR_TRY(hipGetLastError());
@@ -1395,7 +1400,7 @@ static int search_common(icd_index *x, const float *queries, int64_t nq, int32_t
     const float *dq = queries;
     if (!q_on_device) {
         const size_t qbytes = (size_t)nq * x->dim * sizeof(float);
-        if (nq == 1 && (g_host_one & 1) && qbytes <= sizeof(StreamInlineQuery) && !x->capturing) {
+        if (nq == 1 && (x->opt_host_one & 1) && qbytes <= sizeof(StreamInlineQuery) && !x->capturing) {
             x->host_q = queries;   // ONE query: search_device puts it into the single-launch kernel's arguments (or copies it after all)
         } else if (qbytes <= PIN_Q_BYTES) {
             memcpy(x->h_pin, queries, qbytes);
@@ -1652,22 +1657,7 @@ int icd_index_stats(icd_index *idx, icd_stats *out) {
     return ICD_OK;
 }
 
-int icd_debug_set_permute(int32_t enabled) {
-    g_permute = enabled != 0;
-    return ICD_OK;
-}
-
-int icd_debug_set_create_probe(int32_t enabled) {
-    g_probe = enabled != 0;
-    return ICD_OK;
-}
-
-int icd_debug_set_center(int32_t enabled) {
-    g_center = enabled != 0;
-    return ICD_OK;
-}
-
-int icd_debug_unpack_query_slices(int32_t device, const void *gathered, int32_t world, int64_t nq, int32_t k, double *out_adj,
+int icd_unpack_query_slices(int32_t device, const void *gathered, int32_t world, int64_t nq, int32_t k, double *out_adj,
                                   float *out_raw, int64_t *out_ids, int32_t *out_levels, void *stream) {
     if (!gathered || !out_adj || !out_raw || !out_ids || !out_levels) return fail(ICD_ERR_INVALID, "pointer is NULL");
     if (world < 1 || nq < 0 || k <= 0) return fail(ICD_ERR_INVALID, "world=%d nq=%lld k=%d", world, (long long)nq, k);
@@ -1680,29 +1670,19 @@ int icd_debug_unpack_query_slices(int32_t device, const void *gathered, int32_t 
     return ICD_OK;
 }
 
-int icd_debug_set_pacing(int32_t shift, int32_t lead) {
-    g_pace_shift = shift > 12 ? 12 : shift;
-    g_pace_lead = lead < 1 ? 1 : lead;
-    return ICD_OK;
-}
-
-int icd_debug_set_exact_narrow(int32_t enabled) {
-    g_exact_narrow = enabled != 0;
-    return ICD_OK;
-}
-
-int icd_debug_set_host_one(int32_t bits) {
-    g_host_one = bits & 3;
-    return ICD_OK;
-}
-
-int icd_debug_set_stream_one(int32_t enabled) {
-    g_stream_one = enabled != 0;
-    return ICD_OK;
-}
-
-int icd_debug_set_family_order(int32_t enabled) {
-    g_family_order = (enabled & 1) != 0;
+int icd_index_set_option(icd_index *idx, int32_t option, int32_t value) {
+    if (!valid(idx)) return fail(ICD_ERR_STATE, "invalid handle");
+    std::lock_guard<std::mutex> guard(idx->mu);
+    icd_index *x = idx;
+    switch (option) {
+    case ICD_OPT_FAMILY_ORDER: x->opt_family_order = (value & 1) != 0; break;
+    case ICD_OPT_STREAM_ONE:   x->opt_stream_one = value != 0; break;
+    case ICD_OPT_HOST_ONE:     x->opt_host_one = value & 3; break;
+    case ICD_OPT_PACING_SHIFT: x->opt_pace_shift = value > 12 ? 12 : value; break;
+    case ICD_OPT_PACING_LEAD:  x->opt_pace_lead = value < 1 ? 1 : value; break;
+    case ICD_OPT_EXACT_NARROW: x->opt_exact_narrow = value != 0; break;
+    default: return fail(ICD_ERR_INVALID, "option %d: not one of ICD_OPT_*", option);
+    }
     return ICD_OK;
 }
 

@@ -262,7 +262,6 @@ int main(int argc, char **argv) {
         run_case("auto/37k-k5", make_data(37000, 1, 768, 0, 24), 5, ICD_MODE_AUTO);
     }
     }
-    if (getenv("ICD_STREAM_ONE")) icd_debug_set_stream_one(atoi(getenv("ICD_STREAM_ONE")));   // A/B: the single-launch kernel of one / two queries
     if (do_bench) {
         const int var = getenv("ICD_FLAT_VAR") ? atoi(getenv("ICD_FLAT_VAR")) : 0;
         bench(bn, bnq, 768, 10, iters, chunks, (var & (64 | 256 | 512 | 8192)) == 0, auto_only);   // (timing-only variants compute garbage)

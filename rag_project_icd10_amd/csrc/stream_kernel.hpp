@@ -329,7 +329,9 @@ __device__ __forceinline__ void stream_topk_body(const StreamArgs &a, const floa
                 *flag = (t % (u64)gridDim.x) == (u64)gridDim.x - 1ull ? 1 : 0;   // (written after the add has returned)
             }
             __syncthreads();
-            if (*flag == 0) return;   // (work-group-uniform; ONE = true runs a single pass: nq <= QB)
+            const int last_arriver = *flag;
+            __syncthreads();   // (every thread has read the flag: the last arriver's scratch below may overlap it - at small dims also in the 1-2 query branch)
+            if (last_arriver == 0) return;   // (work-group-uniform; ONE = true runs a single pass: nq <= QB)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: keeps the compiler from moving the sc1 loads up)
             if constexpr (QB > 2) {
                 // ---- the last arriver, 3-4 queries: every wave takes a whole query (wave w: query w), four rounds of 64
@@ -339,7 +341,6 @@ __device__ __forceinline__ void stream_topk_body(const StreamArgs &a, const floa
                 u64 *surv = reinterpret_cast<u64 *>(wbase);                       // [4 rounds][KP * KP]
                 u64 *sorted = surv + 4 * KP * KP;                                  // [128]
                 double *adjbuf = reinterpret_cast<double *>(sorted + 128);         // [128]
-                __syncthreads();   // (every thread has read the flag: the scratch below overlaps it)
                 for (int qi = wave; qi < nqp; qi += 4) {
                     const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(a.wg_keys + (size_t)(q0 + qi) * nl * KP, 0, nl * KP * 8, 0x00020000);
                     int tot = 0;

@@ -30,6 +30,7 @@ from typing import Any, Dict, List, Optional
 import numpy as np
 import torch
 
+from .. import graph_capture
 from ..dotenv_lite import load_dotenv
 
 load_dotenv()   # the reference does this at import (python-dotenv); existing environment variables win
@@ -402,7 +403,7 @@ class EmbeddingService:
         if dtype != torch.float32:
             self.model.bert.to(dtype)
         self._dim = int(bert.config.hidden_size)
-        self._graphs = {} if os.getenv("ICD_EMBEDDING_GRAPHS", "1") == "1" else None
+        self._graphs = graph_capture.Buckets() if os.getenv("ICD_EMBEDDING_GRAPHS", "1") == "1" else None
         # large batches: the encoder over packed tokens (ICD_EMBEDDING_PACKED=0: the padded HF forward everywhere)
         self._packed = (_PackedBert(self.model.bert) if os.getenv("ICD_EMBEDDING_PACKED", "1") == "1" and _PackedBert.supported(self.model.bert)
                         else None)
@@ -503,10 +504,14 @@ class EmbeddingService:
             try:
                 entry = self._capture(bb, wb)
             except Exception as exc:  # pragma: no cover - depends on the runtime
-                logger.warning("HIP graph capture failed (%s): encoder runs eagerly", exc)
-                self._graphs = None
-                return self.model(tok.to(self.device, non_blocking=True), mask.to(self.device, non_blocking=True))
-            self._graphs[(bb, wb)] = entry
+                gave_up = self._graphs.failed((bb, wb))   # (this call runs eagerly; the bucket is retried at its next use, a few times)
+                logger.warning("HIP graph capture of bucket %s failed (%s): this call runs eagerly%s", (bb, wb), exc,
+                               "; the bucket stays eager" if gave_up else "")
+                entry = False
+            else:
+                self._graphs.put((bb, wb), entry)
+        if entry is False:
+            return self.model(tok.to(self.device, non_blocking=True), mask.to(self.device, non_blocking=True))
         g, stok, smask, sout = entry
         pad = self._tokenizer.pad_token_id if self._tokenizer is not None else _CharTokenizer.pad_id
         stok.fill_(pad)
@@ -521,15 +526,9 @@ class EmbeddingService:
         dev = self.device
         stok = torch.zeros((bb, wb), dtype=torch.long, device=dev)
         smask = torch.ones((bb, wb), dtype=torch.long, device=dev)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                self.model(stok, smask)
-        torch.cuda.current_stream().wait_stream(side)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            sout = self.model(stok, smask)
+        # (thread-local capture mode under the process-wide capture lock: a worker thread's allocations or copies - the NER job of
+        #  the same request - cannot invalidate it, graph_capture.py)
+        g, sout = graph_capture.capture(torch, lambda: self.model(stok, smask))
         return g, stok, smask, sout
 
     # ---- reference API -------------------------------------------------------------------------------------

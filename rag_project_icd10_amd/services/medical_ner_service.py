@@ -29,6 +29,7 @@ from typing import Any, Dict, List, Sequence
 
 import numpy as np
 
+from .. import graph_capture
 from .diagnosis_entity_filter import DiagnosisEntityFilter
 
 logger = logging.getLogger(__name__)
@@ -193,7 +194,7 @@ class _TokenClassifier:
         b, w = ids.shape
         graphs = getattr(self, "_graphs", None)
         if graphs is None and not hasattr(self, "_graphs"):
-            graphs = self._graphs = {} if (str(self.device).startswith("cuda") and os.getenv("ICD_NER_GRAPHS", "1") == "1") else None
+            graphs = self._graphs = graph_capture.Buckets() if (str(self.device).startswith("cuda") and os.getenv("ICD_NER_GRAPHS", "1") == "1") else None
         if graphs is None or b > self._GRAPH_BATCHES[-1] or w > self._GRAPH_WIDTHS[-1]:
             logits = self.model(input_ids=torch.from_numpy(ids).to(self.device),
                                 attention_mask=torch.from_numpy(mask).to(self.device)).logits
@@ -205,10 +206,16 @@ class _TokenClassifier:
             try:
                 entry = self._capture(bb, wb)
             except Exception as exc:  # pragma: no cover - depends on the runtime
-                logger.warning("HIP graph capture failed (%s): the token classifier runs eagerly", exc)
-                self._graphs = None
-                return self._scores(ids, mask, pad)
-            graphs[(bb, wb)] = entry
+                gave_up = graphs.failed((bb, wb))   # (this call runs eagerly; the bucket is retried at its next use, a few times)
+                logger.warning("HIP graph capture of bucket %s failed (%s): this call runs eagerly%s", (bb, wb), exc,
+                               "; the bucket stays eager" if gave_up else "")
+                entry = False
+            else:
+                graphs.put((bb, wb), entry)
+        if entry is False:
+            logits = self.model(input_ids=torch.from_numpy(ids).to(self.device),
+                                attention_mask=torch.from_numpy(mask).to(self.device)).logits
+            return self._logits_to_scores(logits)
         g, sids, smask, sscore, slabel = entry
         sids.fill_(pad)
         smask.zero_()
@@ -222,15 +229,7 @@ class _TokenClassifier:
         torch = self.torch
         sids = torch.zeros((bb, wb), dtype=torch.long, device=self.device)
         smask = torch.ones((bb, wb), dtype=torch.long, device=self.device)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(2):
-                self._logits_to_scores(self.model(input_ids=sids, attention_mask=smask).logits)
-        torch.cuda.current_stream().wait_stream(side)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g), torch.no_grad():
-            sscore, slabel = self._logits_to_scores(self.model(input_ids=sids, attention_mask=smask).logits)
+        g, (sscore, slabel) = graph_capture.capture(torch, lambda: self._logits_to_scores(self.model(input_ids=sids, attention_mask=smask).logits))
         return g, sids, smask, sscore, slabel
 
     # -- forward: one padded batch per max_batch strings; softmax, best label and its probability per token on the device

@@ -171,15 +171,16 @@ class MultiDiagnosisService:
         import torch
         kk = min(top_k, order.shape[1])
         # (ONE copy: eight .tolist() calls were eight stream synchronisations, ~20 us each - a fifth of a one-diagnosis request.
-        #  Everything travels as float64: exact for the int32 / int64 row indices and the float32 scores alike)
+        #  Everything travels in 8-byte slots: float64 - exact for the int32 order and the float32 scores - except the int64 ids,
+        #  whose bit patterns ride in plane 0 (an id_base of a shard may exceed 2^53))
         if adj.is_cuda:
             from .. import _native
             packed = _native.pack_winners(order, ids, raw, adj, enh, vs, hb, boost, kk).cpu()   # (one launch: gathers, slices, stack)
         else:
             o = order[:, :kk].long().clamp(min=0)
-            packed = torch.stack([torch.gather(ids, 1, o).double(), torch.gather(raw, 1, o).double(), torch.gather(adj, 1, o).double()]
+            packed = torch.stack([torch.gather(ids, 1, o).long().contiguous().view(torch.float64), torch.gather(raw, 1, o).double(), torch.gather(adj, 1, o).double()]
                                  + [t[:, :kk].double() for t in (order, enh, vs, hb, boost)], 0)
-        h_ids, h_ord = packed[0].long().tolist(), packed[3].long().tolist()
+        h_ids, h_ord = packed[0].contiguous().view(torch.int64).tolist(), packed[3].long().tolist()
         h_raw, h_adj, h_enh, h_vs, h_hb, h_boost = (packed[i].tolist() for i in (1, 2, 4, 5, 6, 7))
         recs = self.milvus_service.client.records
         sc = 0.3 if hs.embedding_service else 0.5

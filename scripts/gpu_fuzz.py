@@ -163,9 +163,7 @@ def main():
         r = rng.random(n)
         levels = np.where(r < 0.1243, 1, np.where(r < 0.4234, 2, 3)).astype(np.int32)
         probe = bool(rng.random() < 0.75)                       # the corpus-shape probe of icd_index_create, mostly on
-        _native.load_library().icd_debug_set_create_probe(1 if probe else 0)
-        idx = IcdIndex(corpus, levels, max_nq=nq, max_k=k, id_base=id_base)
-        _native.load_library().icd_debug_set_create_probe(1)
+        idx = IcdIndex(corpus, levels, max_nq=nq, max_k=k, id_base=id_base, probe=probe)
         sp = int(rng.choice([1, 1, 1, 2, 0]))                   # adaptive (default) / second pass without the adaptive parts / off
         if sp != 1:
             idx.set_second_pass(sp != 0, adaptive=False)

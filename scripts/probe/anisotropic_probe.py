@@ -1,5 +1,5 @@
 """Probe: certification on anisotropic unit rows x = normalise(mu0 + s e / sqrt(dim)) (mean pairwise cosine 1 / (1 + s^2)),
-centred against uncentred fp16 image (icd_debug_set_center), several s / batch sizes."""
+centred against uncentred fp16 image (the per-index flag center), several s / batch sizes."""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,9 +22,7 @@ for s in (0.07, 0.2, 0.5, 1.0):
         levels = icd_levels(n, 32)
         dq = torch.from_numpy(queries).cuda()
         for center in (1, 0):
-            lib.icd_debug_set_center(center)
-            idx = IcdIndex(corpus, levels, max_nq=nq, max_k=20)
-            lib.icd_debug_set_center(1)
+            idx = IcdIndex(corpus, levels, max_nq=nq, max_k=20, center=bool(center))
             for k in (10,):
                 for _ in range(3):
                     out = idx.search_reweighted(dq, k, MODE_AUTO)

@@ -2,7 +2,7 @@
 """exact_by_k.py - `--mode exact` (the fp32-MFMA kernel, the parity anchor and the re-search of uncertified queries) by k, over the
 reference's k range (/query searches top_k * 2 with top_k <= 50: models/icd_models.py:138, services/multi_diagnosis_service.py:153),
 at the bench size (10 000 x 37 000 x 768) and for a short batch (512): certified NARROW lists (lists of 32 over row-strided chunks,
-icd_debug_set_exact_narrow, default on) against lists of KP >= k. Every line is checked against the oracle on a query sample.
+the per-index option exact_narrow, default on) against lists of KP >= k. Every line is checked against the oracle on a query sample.
 Format of profiles/r04_exact_mode_by_k.log; 'frac' = of the 157.3 TFLOP/s fp32 MFMA peak."""
 import os
 import sys
@@ -31,7 +31,7 @@ def main():
     dq = torch.from_numpy(queries).cuda()
     sample = np.arange(0, 10000, 40)
     for narrow in (1, 0):
-        lib.icd_debug_set_exact_narrow(narrow)
+        index.set_option("exact_narrow", narrow)
         for k in (10, 20, 33, 50, 64, 100):
             if narrow == 0 and k <= 32:
                 continue
@@ -59,7 +59,6 @@ def main():
                 frac = 2.0 * nq * n * dim / (ms * 1e-3) / 1e12 / 157.3
                 print(f"{'narrow' if narrow else 'kp>=k '} k {k} nq {nq} ms {ms:.3f} chunks {st['last_chunks']} exact {prof['ms_exact']:.5f} fin {prof['ms_exact_finalize']:.5f} "
                       f"re-searched {st['last_fallback']} frac {frac:.3f} ok {ok_i} {ok_s}", flush=True)
-    lib.icd_debug_set_exact_narrow(1)
 
 
 if __name__ == "__main__":

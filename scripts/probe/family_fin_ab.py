@@ -1,5 +1,5 @@
 """A/B of the wide-window finalize on the family corpus (300 x 124 rows, cosine 0.99, 10 000 queries, k = 10 / 20):
-icd_debug_set_family_order: 0 = batch order (round 3), 1 = family order (shipped)."""
+the per-index option family_order: 0 = batch order (round 3), 1 = family order (shipped)."""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,7 +17,7 @@ for k in (10, 20):
     idx = IcdIndex(corpus, levels, max_nq=10000, max_k=20)
     for rnd in range(2):
         for bits in (0, 1):
-            lib.icd_debug_set_family_order(bits)
+            idx.set_option("family_order", bits)
             for _ in range(3):
                 out = idx.search_reweighted(dq, k, MODE_AUTO)
             torch.cuda.synchronize()
@@ -32,5 +32,4 @@ for k in (10, 20):
                 ref = (k, out)
             same = all(torch.equal(a, b) for a, b in zip(out, ref[1]))
             print(f"k={k} bits={bits}: {dt:.3f} ms | coarse {p['ms_coarse']:.3f} finalize {p['ms_finalize']:.3f} | wide {st['wide_mode']} fallback {st['last_fallback']} same_as_first {same}", flush=True)
-    lib.icd_debug_set_family_order(1)
     idx.close()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """rowshard_pacing_probe.py - the coarse sweep over a 1.25 M-row shard (BASELINE configs[4] on one GPU: 16 384 queries per
 slice), with and without PACING of the work-groups that sweep the same corpus tiles (csrc/coarse_flat_kernel.hpp, VAR 67108864;
-icd_debug_set_pacing(shift, lead)).
+the per-index options pacing_shift / pacing_lead).
 
   python3 scripts/probe/rowshard_pacing_probe.py                      # interleaved A/B of several settings: ms per slice, results equal
   python3 scripts/probe/rowshard_pacing_probe.py --one SHIFT LEAD     # ONE setting, three searches: run under
@@ -40,7 +40,7 @@ def main():
     q = torch.randn((nq, dim), generator=g, device="cuda")
     q /= q.norm(dim=1, keepdim=True)
     if len(sys.argv) >= 4 and sys.argv[1] == "--one":
-        lib.icd_debug_set_pacing(int(sys.argv[2]), int(sys.argv[3]))
+        index.set_option("pacing_shift", int(sys.argv[2])); index.set_option("pacing_lead", int(sys.argv[3]))
         for _ in range(3):
             index.search_reweighted(q, k)
         torch.cuda.synchronize()
@@ -50,7 +50,7 @@ def main():
     times = {s: [] for s in settings}
     for rnd in range(3):
         for st in settings:
-            lib.icd_debug_set_pacing(*st)
+            index.set_option("pacing_shift", st[0]); index.set_option("pacing_lead", st[1])
             index.search_reweighted(q, k)          # warm
             torch.cuda.synchronize()
             index.set_profiling(True)
@@ -77,7 +77,7 @@ def main():
         print(f"{name:46s}: coarse launch median {cs[1]:7.3f} ms (min {cs[0]:7.3f}) = {flop / (cs[1] * 1e-3) / 1e12 / 2500:.3f} of 2.5 PFLOP/s; "
               f"search {ws[1]:7.3f} ms per slice of {nq}; fallback {index.stats()['last_fallback']}")
     print("results bit-identical across all settings")
-    lib.icd_debug_set_pacing(3, 2)
+    index.set_option("pacing_shift", 3); index.set_option("pacing_lead", 2)
 
 
 if __name__ == "__main__":

@@ -2,7 +2,7 @@
 """single_query_probe.py - the reference's own call shape: ONE query per MilvusService.search call
 (services/milvus_service.py:280-285, data=[query_vector.tolist()]), k = 5 and 10, 40 474 rows.
 
-For each k, with the single-launch streaming kernel on (default) and off (icd_debug_set_stream_one(0): memset + stream_topk +
+For each k, with the single-launch streaming kernel on (default) and off (the per-index option stream_one = 0: memset + stream_topk +
 reduce_lists + finalize), three ways of calling:
   device   IcdIndex.search_reweighted on a device-resident query, 400 calls enqueued back to back between two events (what the
            GPU needs per call; bytes / time against 8 TB/s is the HBM-roofline fraction of the call);
@@ -40,7 +40,7 @@ def main():
     ref = {}
     for k in (5, 10):
         for one in (1, 0):
-            lib.icd_debug_set_stream_one(one)
+            index.set_option("stream_one", one)
             outs = [index.search_reweighted(dq[i:i + 1], k) for i in range(64)]
             torch.cuda.synchronize()
             got = tuple(torch.cat([o[j] for o in outs]).cpu().numpy().tobytes() for j in range(4))
@@ -62,7 +62,7 @@ def main():
             wall_us = (time.perf_counter() - t0) / 400 * 1e6
             dev_us = e0.elapsed_time(e1) / 400 * 1e3
             # host: numpy in, numpy out, one call at a time; with the single-launch kernel also the four forms of handing the
-            # vector over and of waiting (icd_debug_set_host_one: 0 = copy + stream synchronisation, 1 = vector in the kernel
+            # vector over and of waiting (the per-index option host_one: 0 = copy + stream synchronisation, 1 = vector in the kernel
             # arguments, 2 = polled completion word, 3 = both, the default), interleaved
             forms = (0, 1, 2, 3) if one else (3,)
             lat_by = {b: [] for b in forms}
@@ -70,11 +70,11 @@ def main():
                 index.search_reweighted(queries[:1], k)
             for i in range(200):
                 for b in forms:
-                    lib.icd_debug_set_host_one(b)
+                    index.set_option("host_one", b)
                     t0 = time.perf_counter()
                     index.search_reweighted(queries[i & 63:(i & 63) + 1], k)
                     lat_by[b].append((time.perf_counter() - t0) * 1e6)
-            lib.icd_debug_set_host_one(3)
+            index.set_option("host_one", 3)
             for b in forms:
                 lat_by[b].sort()
             if one:
@@ -83,11 +83,11 @@ def main():
             print(f"k={k:2d} single-launch kernel {'on ' if one else 'off'}: device {dev_us:6.1f} us per call (host enqueue {wall_us:5.1f} us; "
                   f"{bytes_per_call / dev_us / 1e6:5.2f} TB/s = {bytes_per_call / dev_us / 1e6 / 8.0:.3f} of 8 TB/s) | "
                   f"host call median {lat[100]:6.1f} us, p10 {lat[20]:6.1f}, p90 {lat[180]:6.1f}")
-    lib.icd_debug_set_stream_one(1)
+    index.set_option("stream_one", 1)
     # 3 ... 8 queries per call (a /query request's diagnoses in one search_batch): GPU time by the library's own events
     for nq in (1, 2, 3, 4, 8, 16):
         for one in (1, 0):
-            lib.icd_debug_set_stream_one(one)
+            index.set_option("stream_one", one)
             for _ in range(20):
                 index.search_reweighted(dq[:nq], 10)
             torch.cuda.synchronize()
@@ -99,7 +99,7 @@ def main():
             prof = index.profile_summary()
             index.set_profiling(False)
             print(f"nq={nq:2d} k=10 single-launch kernel {'on ' if one else 'off'}: GPU {prof['ms_total'] * 1e3:6.1f} us per call (library events, {prof['count']} calls)")
-    lib.icd_debug_set_stream_one(1)
+    index.set_option("stream_one", 1)
     index.close()
     # the service: the reference's search(), numpy vector in, hit dicts out
     tmp = tempfile.mkdtemp()
@@ -115,7 +115,7 @@ def main():
         svc.insert_records(recs[b:b + 4096], [corpus[i] for i in range(b, min(n, b + 4096))])
     for k in (5, 10):
         for one in (1, 0):
-            lib.icd_debug_set_stream_one(one)
+            index.set_option("stream_one", one)
             for i in range(20):
                 svc.search(queries[i], k)
             lat = []
@@ -126,7 +126,7 @@ def main():
             assert len(hits) == k
             lat.sort()
             print(f"k={k:2d} single-launch kernel {'on ' if one else 'off'}: MilvusService.search median {lat[100]:6.1f} us, p10 {lat[20]:6.1f}, p90 {lat[180]:6.1f}")
-    lib.icd_debug_set_stream_one(1)
+    index.set_option("stream_one", 1)
 
 
 if __name__ == "__main__":

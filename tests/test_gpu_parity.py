@@ -239,13 +239,9 @@ def test_corpus_in_code_order_stays_on_the_fast_path(oracle):
     idx.close()
     assert st["last_mode"] == MODE_AUTO and st["last_fallback"] <= 256 // 8
     from rag_project_icd10_amd import _native
-    _native.load_library().icd_debug_set_permute(0)   # test switch: fp16 copy in row order
-    try:
-        idx = IcdIndex(corpus, levels, max_nq=256, max_k=10)
-        st2 = _check(oracle, idx, corpus, levels, queries, 10, MODE_AUTO)
-        idx.close()
-    finally:
-        _native.load_library().icd_debug_set_permute(1)
+    idx = IcdIndex(corpus, levels, max_nq=256, max_k=10, permute=False)   # per-index option: fp16 copy in row order
+    st2 = _check(oracle, idx, corpus, levels, queries, 10, MODE_AUTO)
+    idx.close()
     assert st2["last_fallback"] >= st["last_fallback"]
 
 
@@ -557,11 +553,38 @@ def test_query_sharded_search_single_rank_nccl_and_config3_share(oracle):
 
 
 def test_config4_per_gpu_share_at_full_size():
-    """BASELINE configs[4] at its stated per-GPU size, through the bench's own leg: a 1 250 000 x 768 shard generated on the
-    device, the 100 000-query batch in slices of 16 384 through ShardedSearch(ROW) -> icd_group_search (local top-k, the
-    all-gather step, merge + reweight), one pass; the 64-query sample is checked against the oracle over the whole shard
-    (ids, raw and adjusted scores bit for bit), every slice's output is sorted, and nearly everything stays certified."""
-    import argparse
+    """BASELINE configs[4] at its stated per-GPU size, END TO END through the driver's command: `python bench.py --gpus 1
+    --workload rowshard` in a process of its own with ICD_SHARDED_ENGINE=native - a 1 250 000 x 768 shard generated on the
+    device, the 100 000-query batch in slices of 16 384 through ShardedSearch(ROW) -> icd_group_search (the C-ABI group: local
+    top-k, the all-gather step, merge + reweight), one pass; the 56-query sample is checked against the oracle over the whole
+    shard (ids, raw and adjusted scores bit for bit), every slice's output is sorted, nearly everything stays certified, and the
+    line names the engine that produced it."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["ICD_SHARDED_ENGINE"] = "native"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "rowshard", "--steps", "1", "--rowshard-steps", "1"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["engine"] == "icd_group (C ABI)" and line["config"]["collective_ranks"] == 1 and line["n_gpus"] == 1
+    assert line["config"]["queries"] == 100_000 and line["config"]["rows_per_gpu"] == 1_250_000 and "configs[4]" in line["config"]["workload"]
+    assert line["ids_exact_on_sample"] and line["raw_scores_exact_on_sample"] and line["adjusted_scores_exact_on_sample"] and line["adjusted_sorted"]
+    assert line["sample_queries"] == 56 and line["sample_slices"] == 7 and "oracle" in line["sample_checked_against"]   # 8 of every slice, the 1 696-query last one included
+    assert line["fallback_queries_last_slice"] <= 20 and line["value"] > 1e5
+    # the paced coarse sweep of a 1.25 M-row shard: 0.46-0.47 of the fp16 MFMA peak on a quiet box (profiles/r05_bench_rowshard_n1.json);
+    # a fraction below 0.35 is a regression of the kernel, not box noise
+    assert 0.35 < line["roofline"]["frac"] < 1.0, line["roofline"]
+
+
+def test_config0_composed_one_string_per_call():
+    """BASELINE configs[0] as ONE workload, through the bench's own leg (bench.config0_extra): 100 golden diagnosis strings, per
+    string encode_query (one string per call) -> MilvusService.search(top_k=5) (one query per call) over the 40 474-row
+    database DatabaseBuilder builds in the same run (reference: services/multi_diagnosis_service.py:152-153,
+    services/milvus_service.py:280-285, tools/build_database.py:217-222). Every hit of every string equals the oracle over the
+    stored corpus bit for bit, and a stored row IS encode_query of its text."""
     import sys
     from conftest import ROOT
     sys.path.insert(0, ROOT)
@@ -569,13 +592,11 @@ def test_config4_per_gpu_share_at_full_size():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         os.environ.pop(k, None)
     ctx = bench.Ctx()
-    assert ctx.world == 1
-    args = argparse.Namespace(steps=1, warmup=1, k=10, rows_per_gpu=1_250_000, rowshard_queries=100_000, rowshard_slice=16384, rowshard_steps=1)
-    line = bench.run_rowshard(ctx, args)
-    assert line["config"]["queries"] == 100_000 and line["config"]["rows_per_gpu"] == 1_250_000 and "configs[4]" in line["config"]["workload"]
-    assert line["ids_exact_on_sample"] and line["raw_scores_exact_on_sample"] and line["adjusted_scores_exact_on_sample"] and line["adjusted_sorted"]
-    assert line["sample_queries"] == 56 and line["sample_slices"] == 7 and "oracle" in line["sample_checked_against"]   # 8 of every slice, the 1 696-query last one included
-    assert line["fallback_queries_last_slice"] <= 20 and line["value"] > 1e5 and 0.2 < line["roofline"]["frac"] < 1.0
+    obj, es = bench.config0_extra(ctx)
+    assert "error" not in obj, obj
+    assert obj["strings"] == 100 and obj["top_k"] == 5 and obj["corpus_rows"] == 40474 and obj["parity_checked_strings"] == 100
+    assert obj["hits_exact"] and obj["stored_row_equals_encode_query_of_its_text"] and obj["batch_arithmetic"] == "canonical"
+    assert es is not None and obj["strings_per_sec"] > 200          # (measured ~1 900 strings/s; the CPU composition runs at ~5)
 
 
 def test_config2_shape_batched_equals_one_at_a_time(tmp_path, monkeypatch):
@@ -690,11 +711,7 @@ def test_family_corpus_is_certified_within_the_call(oracle, k, no_gc):
     perf_records.record(f"family_k{k}_fresh_index_batches_ms", each)
     idx_a.close()
     # (b) the same without the probe: the second coarse pass inside the call
-    _native.load_library().icd_debug_set_create_probe(0)
-    try:
-        idx = IcdIndex(corpus, levels, max_nq=10000, max_k=20)
-    finally:
-        _native.load_library().icd_debug_set_create_probe(1)
+    idx = IcdIndex(corpus, levels, max_nq=10000, max_k=20, probe=False)
     assert idx.stats()["wide_mode"] == 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -748,11 +765,7 @@ def test_second_pass_switch_and_gaussian_batches_skip_it(oracle):
     fc, fq = _tight_family_corpus(100, 124, 768, 0.10, 6000, 11)           # 6 000 queries x 97 tiles: 6-7 lists of 16 per query
     fl = icd_levels(len(fc), 12)
     from rag_project_icd10_amd import _native
-    _native.load_library().icd_debug_set_create_probe(0)                   # (the probe would start this corpus on the wide plan)
-    try:
-        idx = IcdIndex(fc, fl, max_nq=6000, max_k=10)
-    finally:
-        _native.load_library().icd_debug_set_create_probe(1)
+    idx = IcdIndex(fc, fl, max_nq=6000, max_k=10, probe=False)             # (the probe would start this corpus on the wide plan)
     a1 = [t.cpu().numpy() for t in idx.search_reweighted(torch.from_numpy(fq).cuda(), 10)]
     st1 = idx.stats()
     idx.set_second_pass(False)
@@ -1022,11 +1035,7 @@ def test_anisotropic_embeddings_are_certified_on_a_centred_image(oracle, k):
     lib = _native.load_library()
     fall = {}
     for center in (1, 0):
-        lib.icd_debug_set_center(center)
-        try:
-            idx = IcdIndex(corpus, levels, max_nq=nq, max_k=k)
-        finally:
-            lib.icd_debug_set_center(1)
+        idx = IcdIndex(corpus, levels, max_nq=nq, max_k=k, center=bool(center))
         st = idx.stats()
         assert st["centered"] == center and st["mean_share"] > 0.5 and abs(st["rmax"] - 1.0) < 1e-3
         for _ in range(2):
@@ -1089,7 +1098,7 @@ def test_short_flagged_lists_take_the_chunked_exact_research(oracle, flagged, k)
 def test_query_sharded_unpack_kernel_matches_the_host_concatenation(world):
     """icd_group_search, query-sharded with gather: ONE kernel scatters the all-gathered padded slices to the [nq][k] outputs
     (it replaced four hipMemcpyAsync per rank). Its index arithmetic restates shard_bounds; checked here for any world size on
-    one GPU through icd_debug_unpack_query_slices against sharded.py's host-side concatenation rule (nq % world != 0 and
+    one GPU through icd_unpack_query_slices against sharded.py's host-side concatenation rule (nq % world != 0 and
     nq < world included). No reference counterpart: the reference is a single process (main.py:753-758)."""
     import ctypes
 
@@ -1118,7 +1127,7 @@ def test_query_sharded_unpack_kernel_matches_the_host_concatenation(world):
         o_ids = torch.empty((nq, k), dtype=torch.int64, device="cuda")
         o_lv = torch.empty((nq, k), dtype=torch.int32, device="cuda")
         vp = ctypes.c_void_p
-        rc = lib.icd_debug_unpack_query_slices(0, vp(gathered.data_ptr()), world, nq, k, vp(o_adj.data_ptr()), vp(o_raw.data_ptr()),
+        rc = lib.icd_unpack_query_slices(0, vp(gathered.data_ptr()), world, nq, k, vp(o_adj.data_ptr()), vp(o_raw.data_ptr()),
                                                vp(o_ids.data_ptr()), vp(o_lv.data_ptr()), vp(torch.cuda.current_stream().cuda_stream))
         assert rc == 0, lib.icd_last_error()
         torch.cuda.synchronize()
@@ -1131,7 +1140,7 @@ def test_one_and_two_queries_take_the_single_launch_kernel_and_match_the_oracle(
     """The reference's call shape - ONE query per MilvusService.search call (services/milvus_service.py:280-285) - and up to eight
     (a /query request batches the searches of its D diagnoses, services/multi_diagnosis_service.py:98-103,153; up to four take this kernel):
     stream_topk_kernel<ONE> folds the list reduction and finalize into the streaming launch (last-arriver ticket). Bit-equal
-    to the oracle and to the general four-operation path (icd_debug_set_stream_one(0)), over corpus sizes from one
+    to the oracle and to the general four-operation path (set_option("stream_one", 0)), over corpus sizes from one
     work-group to multi-step sweeps, k = 1 ... 16, exact ties (duplicate rows) included; repeated calls (the ticket only
     ever counts up)."""
     dim = 768
@@ -1148,7 +1157,7 @@ def test_one_and_two_queries_take_the_single_launch_kernel_and_match_the_oracle(
                 q = queries[lo:hi]
                 os_, oi = oracle.flat_ip_topk(corpus, q, k)
                 want = oracle.reweight(os_, oi, levels)
-                lib.icd_debug_set_stream_one(1)
+                idx.set_option("stream_one", 1)
                 for rep in range(2):
                     s, i = idx.search(q, k)
                     got = idx.search_reweighted(q, k)
@@ -1156,11 +1165,10 @@ def test_one_and_two_queries_take_the_single_launch_kernel_and_match_the_oracle(
                     assert np.array_equal(got[2], want[2]) and _bits(got[0]) == _bits(want[0]) and _bits(got[1]) == _bits(want[1])
                     assert np.array_equal(got[3], want[3])
                 assert idx.stats()["last_mode"] == MODE_EXACT and idx.stats()["last_fallback"] == 0
-                lib.icd_debug_set_stream_one(0)
+                idx.set_option("stream_one", 0)
                 old = idx.search_reweighted(q, k)
                 assert all(_bits(a) == _bits(b) for a, b in zip(old, got))
     finally:
-        lib.icd_debug_set_stream_one(1)
         idx.close()
 
 
@@ -1168,7 +1176,7 @@ def test_one_and_two_queries_take_the_single_launch_kernel_and_match_the_oracle(
 def test_a_host_callers_one_query_in_the_kernel_arguments_and_the_polled_completion(oracle, dim):
     """ONE query per call from HOST memory (MilvusClient.search(data=[query_vector.tolist()]), services/milvus_service.py:280-285):
     the vector travels in the single-launch kernel's arguments and the call returns on a polled completion word
-    (icd_debug_set_host_one bits 1 and 2). All four settings are bit-equal to the oracle, call after call (the word is a
+    (the per-index option host_one, bits 1 and 2). All four settings are bit-equal to the oracle, call after call (the word is a
     sequence number), also interleaved with batch calls, calls of two queries and device-resident calls on the same handle;
     1024-d vectors do not fit the arguments and take the copy; k > 16 leaves the single-launch kernel (the copy is enqueued
     after all)."""
@@ -1187,7 +1195,7 @@ def test_a_host_callers_one_query_in_the_kernel_arguments_and_the_polled_complet
     dq = torch.from_numpy(queries).cuda()
     try:
         for bits in (3, 0, 1, 2, 3):
-            lib.icd_debug_set_host_one(bits)
+            idx.set_option("host_one", bits)
             for k in (10, 1, 16, 20):
                 os_, oi, rw = want[k]
                 for j in range(12):
@@ -1204,7 +1212,6 @@ def test_a_host_callers_one_query_in_the_kernel_arguments_and_the_polled_complet
                         torch.cuda.synchronize()
                         assert np.array_equal(i4.cpu().numpy(), oi[j:j + 1]) and _bits(s4.cpu().numpy()) == _bits(os_[j:j + 1])
     finally:
-        lib.icd_debug_set_host_one(3)
         idx.close()
 
 
@@ -1262,7 +1269,7 @@ def test_exact_mode_above_k32_runs_certified_narrow_lists_and_stays_exact(oracle
     """ICD_MODE_EXACT at k > 32 (the k range /query can ask for: top_k * 2 with top_k <= 50, models/icd_models.py:138,
     services/multi_diagnosis_service.py:153): lists of 32 over row-strided chunks + the certificate of finalize.hpp
     (narrow_check), re-search of what it cannot clear. Bit-equal to the oracle and to the KP >= k lists
-    (icd_debug_set_exact_narrow(0)) on Gaussian rows, on families of near-identical NEIGHBOURING rows, on hundreds of exact
+    (set_option("exact_narrow", 0)) on Gaussian rows, on families of near-identical NEIGHBOURING rows, on hundreds of exact
     duplicates of one row, and on a corpus built so that ONE list holds more than 32 members of a query's top-k (the
     certificate must flag it: last_fallback > 0)."""
     import torch
@@ -1287,7 +1294,7 @@ def test_exact_mode_above_k32_runs_certified_narrow_lists_and_stays_exact(oracle
             os_, oi = oracle.flat_ip_topk(corpus, queries, k)
             want = oracle.reweight(os_, oi, levels)
             for narrow in (1, 0):
-                lib.icd_debug_set_exact_narrow(narrow)
+                idx.set_option("exact_narrow", narrow)
                 s, i = idx.search(queries, k, MODE_EXACT)
                 got = idx.search_reweighted(queries, k, MODE_EXACT)
                 assert np.array_equal(i, oi) and _bits(s) == _bits(os_), (name, narrow)
@@ -1298,7 +1305,6 @@ def test_exact_mode_above_k32_runs_certified_narrow_lists_and_stays_exact(oracle
                     assert st["last_mode"] == MODE_EXACT and st["last_fallback"] == 0, (name, st)   # rows that spread: nothing to re-search
             idx.close()
         # the adversarial corpus: 45 copies of query 7 at rows 3, 3 + P, 3 + 2 P, ... = ONE strided chunk holds 45 members of its top-k
-        lib.icd_debug_set_exact_narrow(1)
         adv = gauss.copy()
         adv[3 + pn * np.arange(45)] = queries[7]
         levels = icd_levels(n, 9)
@@ -1310,7 +1316,7 @@ def test_exact_mode_above_k32_runs_certified_narrow_lists_and_stays_exact(oracle
         assert np.array_equal(i, oi) and _bits(s) == _bits(os_)
         idx.close()
     finally:
-        lib.icd_debug_set_exact_narrow(1)
+        pass
 
 
 def test_device_resident_searches_can_be_captured_into_a_hip_graph(oracle):
@@ -1358,3 +1364,31 @@ def test_device_resident_searches_can_be_captured_into_a_hip_graph(oracle):
     g2.replay()
     torch.cuda.synchronize()
     idx.close()
+
+
+def test_pack_winners_carries_int64_ids_as_bit_patterns():
+    """icd_pack_winners (row N2: the winners of a rescored batch for the host in one array; reference
+    services/multi_diagnosis_service.py:147-176 builds Candidate objects from them): plane 0 holds the int64 ids' BIT PATTERNS,
+    so ids beyond 2^53 - a shard's id_base is an arbitrary int64 in the C ABI - come back exact (a double would round them:
+    ADVICE r5); the other planes equal plain torch gathers / slices."""
+    import torch
+    from rag_project_icd10_amd import _native
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    nq, k, kk = 257, 20, 7
+    base = (1 << 60) + 12345
+    ids = torch.randint(0, 40474, (nq, k), generator=g, device="cuda", dtype=torch.int64) + base
+    raw = torch.rand((nq, k), generator=g, device="cuda", dtype=torch.float32)
+    adj, enh, vs, hb, boost = (torch.rand((nq, k), generator=g, device="cuda", dtype=torch.float64) for _ in range(5))
+    order = torch.argsort(torch.rand((nq, k), generator=g, device="cuda"), dim=1).to(torch.int32)
+    order[5, 3:] = -1                                                    # a query with three hits only
+    out = _native.pack_winners(order, ids, raw, adj, enh, vs, hb, boost, kk).cpu()
+    o = order[:, :kk].long().clamp(min=0)
+    assert out.shape == (8, nq, kk)
+    got_ids = out[0].contiguous().view(torch.int64)
+    assert torch.equal(got_ids, torch.gather(ids, 1, o).cpu()) and int(got_ids.min()) >= base
+    assert float((got_ids.double() - got_ids.double().round()).abs().max()) == 0.0 and not torch.equal(got_ids.double().long(), got_ids)   # (a double could not have held them)
+    assert torch.equal(out[1], torch.gather(raw, 1, o).double().cpu()) and torch.equal(out[2], torch.gather(adj, 1, o).cpu())
+    assert torch.equal(out[3], order[:, :kk].double().cpu())
+    for plane, t in zip((4, 5, 6, 7), (enh, vs, hb, boost)):
+        assert torch.equal(out[plane], t[:, :kk].cpu())

@@ -24,6 +24,13 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_native.EXPORTED_SYMBOLS)
+    # round 6: no process-wide A/B switch in the product ABI - the former icd_debug_set_* globals are options of ONE index
+    # (icd_index_create flags, icd_index_set_option); the library exports none of them, declared or not
+    assert not [n for n in names if n.startswith("icd_debug")]
+    import subprocess
+    dyn = subprocess.run(["nm", "-D", "--defined-only", _native.LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted({ln.split()[-1] for ln in dyn.splitlines() if " T " in ln and ln.split()[-1].startswith("icd_")})
+    assert exported == names, sorted(set(exported) ^ set(names))
     assert lib.icd_abi_version() == _native.ABI_VERSION == 6
 
 
@@ -54,6 +61,8 @@ def test_argument_validation_needs_no_gpu():
     assert b"multiple of 32" in lib.icd_last_error()
     assert lib.icd_index_create(buf.ctypes.data, 2, 64, None, 0, 0, 1, 500, 0, ctypes.byref(out)) == -1  # max_k
     assert lib.icd_index_destroy(None) == -5 and lib.icd_index_stats(None, None) == -5
+    assert lib.icd_index_set_option(None, 1, 0) == -5
+    assert lib.icd_index_create(buf.ctypes.data, 2, 64, None, 0, 0, 1, 1, 1 << 20, ctypes.byref(out)) == -1 and b"unknown bits" in lib.icd_last_error()
     assert lib.icd_merge_topk(0, None, None, None, 1, 1, 1, None, None, None, None, None) == -1
 
 
