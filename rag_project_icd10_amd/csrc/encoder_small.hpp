@@ -42,11 +42,20 @@ namespace icd {
 
 constexpr int ENC_TMAX = 512;   // packed tokens per call (any ONE sequence a BERT-style encoder takes fits: max_position_embeddings 512)
 constexpr int ENC_BMAX = 64;    // sequences per call
+// the batch form of the same forward (encoder_big.hpp: the GEMMs in large tiles, everything else these kernels): tokens / sequences per pass
+constexpr int ENC_BIG_TMAX = 8192;
+constexpr int ENC_BIG_BMAX = 2048;
 // descriptor (int32 words): [0] T, [1] B, then per token (TMAX each): id, position, first row of its sequence, length of its
 // sequence (0 past the call's tokens), then BMAX + 1 sequence starts (starts[b] = T for b >= B)
-constexpr int ENC_META_IDS = 2, ENC_META_POS = 2 + ENC_TMAX, ENC_META_TOK_R0 = 2 + 2 * ENC_TMAX, ENC_META_TOK_LEN = 2 + 3 * ENC_TMAX;
-constexpr int ENC_META_STARTS = 2 + 4 * ENC_TMAX;
-constexpr int ENC_META_WORDS = ENC_META_STARTS + ENC_BMAX + 1;
+template <int TMAX, int BMAX>
+struct EncMeta {
+    static constexpr int IDS = 2, POS = 2 + TMAX, TOK_R0 = 2 + 2 * TMAX, TOK_LEN = 2 + 3 * TMAX, STARTS = 2 + 4 * TMAX;
+    static constexpr int WORDS = STARTS + BMAX + 1;
+    static constexpr int T_MAX = TMAX, B_MAX = BMAX;
+};
+using EncMetaSmall = EncMeta<ENC_TMAX, ENC_BMAX>;
+using EncMetaBig = EncMeta<ENC_BIG_TMAX, ENC_BIG_BMAX>;
+constexpr int ENC_META_WORDS = EncMetaSmall::WORDS;
 
 typedef float enc_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -105,6 +114,58 @@ __device__ __forceinline__ float enc_wave_sum(float v) {
     return v;
 }
 
+// ---- the arithmetic BOTH forms of a GEMM share (enc_linear_kernel below; enc_linear_big_kernel, encoder_big.hpp) ----------------
+// One embedding arithmetic whatever the call shape: the batch form must give every token the BITS the
+// small-input form gives it. The products and sums of the MFMAs are fixed by the instruction order both kernels spell out;
+// everything around them lives in these functions, with contraction OFF (every rounding is the one written here, whatever
+// code surrounds the inlined body) and the two explicit fmaf where a fused step is meant.
+// statistics of ONE wave's slice of a row (KW = 16 ITER columns): lane (r16, kq) holds ITER float4 of row r16; returns the
+// slice's mean and centred sum of squares in every lane of the row
+template <int ITER>
+__device__ __forceinline__ void enc_piece_stats(const float4 (&areg)[ITER], float &mw, float &qw) {
+#pragma clang fp contract(off)
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) sm += (areg[i].x + areg[i].y) + (areg[i].z + areg[i].w);
+    sm += __shfl_xor(sm, 16);
+    sm += __shfl_xor(sm, 32);
+    mw = sm * (1.0f / (16 * ITER));
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+        const float dx = areg[i].x - mw, dy = areg[i].y - mw, dz = areg[i].z - mw, dw = areg[i].w - mw;
+        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+    q += __shfl_xor(q, 16);
+    q += __shfl_xor(q, 32);
+    qw = q;
+}
+// the slices of a row combined (equal counts: mean = the average of the slices' means, M2 = sum of their M2 + KW sum (mean_w - mean)^2);
+// mw / qw: the nw slices' numbers, `stride` floats apart
+__device__ __forceinline__ void enc_combine_stats(const float *mw, const float *qw, int stride, int nw, int kw_cols, int K, float eps, float &mean, float &rstd) {
+#pragma clang fp contract(off)
+    float m = 0.f;
+    for (int w = 0; w < nw; ++w) m += mw[(size_t)w * stride];
+    m /= (float)nw;
+    float m2 = 0.f;
+    for (int w = 0; w < nw; ++w) { const float dm = mw[(size_t)w * stride] - m; m2 += qw[(size_t)w * stride] + (float)kw_cols * dm * dm; }
+    mean = m;
+    rstd = 1.0f / sqrtf(m2 / (float)K + eps);
+}
+// what becomes of a K slice's sum `s`: LNPRO rstd (s - mean c1); in the FIRST slice (slab 0) + bias (+ the LayerNorm-ed residual,
+// EPI == 2); erf-GELU (EPI == 1)
+template <int EPI, bool LNPRO>
+__device__ __forceinline__ float enc_epilogue(float s, bool first_slice, float mean, float rstd, float c1, float bias, float rsrc, float rmean, float rrstd, float rg, float rb) {
+#pragma clang fp contract(off)
+    if constexpr (LNPRO) s = rstd * (s - mean * c1);
+    if (first_slice) {
+        s += bias;
+        if constexpr (EPI == 2) s += (rsrc - rmean) * rrstd * rg + rb;
+    }
+    if constexpr (EPI == 1) s = 0.5f * s * (1.0f + erff(s * 0.70710678118654752440f));
+    return s;
+}
+
 struct EncEmbedArgs {
     const int *meta;
     const float *word, *pos, *type0;   // embeddings [vocab][H], [max_pos][H], token type 0 [H]
@@ -112,11 +173,11 @@ struct EncEmbedArgs {
     float *y;   // [TMAX][H] pre-norm, operand order
 };
 // y[t] = (word[id] + type0) + pos[p] (BertEmbeddings in front of its LayerNorm): one wave per token
-template <int NV>
+template <int NV, typename M = EncMetaSmall>
 __global__ __launch_bounds__(256) void enc_embed_kernel(EncEmbedArgs a) {
     const int lane = threadIdx.x & 63, t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= a.meta[0]) return;   // wave-uniform
-    const size_t id = (size_t)a.meta[ENC_META_IDS + t], p = (size_t)a.meta[ENC_META_POS + t];
+    const size_t id = (size_t)a.meta[M::IDS + t], p = (size_t)a.meta[M::POS + t];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int c = 4 * (lane + 64 * j);
@@ -254,26 +315,12 @@ __global__ __launch_bounds__(MAXW * 64) void enc_linear_kernel(EncLinearArgs a) 
             c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i + 1].w, wreg[i + 1].w, c1, 0, 0, 0);
         }
         float mw = 0.f, qw = 0.f;
-        if constexpr (LNPRO) {
-            // LayerNorm without touching the operand: the MFMAs above ran on the RAW rows against W diag(g); what is left is
-            // rstd (acc - mean c1) + c2 per output (epilogue). The statistics: the work-group's waves hold rows t0 .. t0 + 15
-            // whole between them (lane (r16, kq) of wave w: 48 values of row r16); every wave reduces ITS 192 columns of a row
-            // to (mean, centred sum of squares) - two passes over registers, VALU work that runs beside the MFMAs - and the
-            // pairs are combined behind the barrier the partial sums need anyway.
-            float sm = 0.f;
-#pragma unroll
-            for (int i = 0; i < ITER; ++i) sm += (areg[i].x + areg[i].y) + (areg[i].z + areg[i].w);
-            sm += __shfl_xor(sm, 16);
-            sm += __shfl_xor(sm, 32);
-            mw = sm * (1.0f / (16 * ITER));
-#pragma unroll
-            for (int i = 0; i < ITER; ++i) {
-                const float dx = areg[i].x - mw, dy = areg[i].y - mw, dz = areg[i].z - mw, dw = areg[i].w - mw;
-                qw += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-            }
-            qw += __shfl_xor(qw, 16);
-            qw += __shfl_xor(qw, 32);
-        }
+        // LayerNorm without touching the operand: the MFMAs above ran on the RAW rows against W diag(g); what is left is
+        // rstd (acc - mean c1) + c2 per output (epilogue). The statistics: the work-group's waves hold rows t0 .. t0 + 15
+        // whole between them (lane (r16, kq) of wave w: 48 values of row r16); every wave reduces ITS 192 columns of a row
+        // to (mean, centred sum of squares) - two passes over registers, VALU work that runs beside the MFMAs - and the
+        // pairs are combined behind the barrier the partial sums need anyway.
+        if constexpr (LNPRO) enc_piece_stats<ITER>(areg, mw, qw);
         ENC_STAMP(3);    // MFMAs issued, statistics done
         // C[token 4 (lane >> 4) + j][column lane & 15] in register j
 #pragma unroll
@@ -287,25 +334,15 @@ __global__ __launch_bounds__(MAXW * 64) void enc_linear_kernel(EncLinearArgs a) 
         if (ecol) {
             float s = 0.f;
             for (int w = 0; w < nw; ++w) s += red[w][tid];
+            float mean = 0.f, rstd = 0.f;
             if constexpr (LNPRO) {
-                // equal counts: mean = the average of the waves' means, M2 = sum of their M2 + 192 sum (mean_w - mean)^2
-                float mean = 0.f;
-                for (int w = 0; w < nw; ++w) mean += lnred[0][w][et];
-                mean /= (float)nw;
-                float m2 = 0.f;
-                for (int w = 0; w < nw; ++w) { const float dm = lnred[0][w][et] - mean; m2 += lnred[1][w][et] + (float)(16 * ITER) * dm * dm; }
-                const float rstd = 1.0f / sqrtf(m2 / (float)a.K + a.ln_eps);
-                s = rstd * (s - mean * c1_v);
+                enc_combine_stats(&lnred[0][0][et], &lnred[1][0][et], 16, nw, 16 * ITER, a.K, a.ln_eps, mean, rstd);
                 if (blockIdx.x == 0 && en == 0 && t0 + et < T) {
                     a.stats_out[2 * (t0 + et)] = mean;
                     a.stats_out[2 * (t0 + et) + 1] = rstd;
                 }
             }
-            if (ks == 0) {   // (work-group-uniform) bias and residual once, in slab 0
-                s += bias_v;
-                if constexpr (EPI == 2) s += (rsrc - rmean) * rrstd * rg + rb;
-            }
-            if constexpr (EPI == 1) s = 0.5f * s * (1.0f + erff(s * 0.70710678118654752440f));
+            s = enc_epilogue<EPI, LNPRO>(s, ks == 0, mean, rstd, c1_v, bias_v, rsrc, rmean, rrstd, rg, rb);   // (ks: work-group-uniform - bias and residual once, in slab 0)
             if (t0 + et < T) {
                 float *yo = a.y + (size_t)ks * a.slab;
                 if constexpr (OUT_PA) yo[enc_pa(t0 + et, n0 + en, a.N, KW)] = s;
@@ -330,13 +367,13 @@ struct EncAttnArgs {
 // SINGLE: the call is ONE sequence (the reference's call shape): its keys are rows 0, 1, ... whatever the length, so the
 // first chunk's loads are issued without waiting for the descriptor (one dependent memory round trip less: ~2 us of a 6-us
 // kernel); rows past the length hold finite stale values and are masked.
-template <bool SINGLE>
+template <bool SINGLE, typename M = EncMetaSmall>
 __global__ __launch_bounds__(256) void enc_attention_kernel(EncAttnArgs a) {
     constexpr int CH = 32;
     const int lane = threadIdx.x & 63;
     const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int t = task / a.heads, h = task - t * a.heads;
-    if (t >= ENC_TMAX) return;
+    if (t >= M::T_MAX) return;
     const size_t ld = 3 * (size_t)a.H;
     int r0 = 0, L;
     float kreg[CH], vreg[CH];
@@ -347,8 +384,8 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(EncAttnArgs a) {
         L = a.meta[0];
         if (t >= L) return;
     } else {
-        r0 = a.meta[ENC_META_TOK_R0 + t];
-        L = a.meta[ENC_META_TOK_LEN + t];   // (0 past the call's tokens)
+        r0 = a.meta[M::TOK_R0 + t];
+        L = a.meta[M::TOK_LEN + t];   // (0 past the call's tokens)
         if (L <= 0) return;   // wave-uniform, no barriers below
     }
     const float q = a.qkv[(size_t)t * ld + (size_t)h * ATT_HEAD_DIM + lane] * a.scale;
@@ -401,12 +438,12 @@ struct EncPoolArgs {
 // dependent memory round trip, so the rows are dealt over as many waves as a work-group has), keeps their sum, and the
 // sums meet in LDS. Column 4 (lane + 64 j) + c sits in element c of chunk j of lane `lane`.
 constexpr int ENC_POOL_WAVES = 16;
-template <int NV, int NSLAB>
+template <int NV, int NSLAB, typename M = EncMetaSmall>
 __global__ __launch_bounds__(ENC_POOL_WAVES * 64) void enc_pool_kernel(EncPoolArgs a) {
     __shared__ float4 part[ENC_POOL_WAVES][NV][64];
     const int b = blockIdx.x;
     if (b >= a.meta[1]) return;
-    const int r0 = a.meta[ENC_META_STARTS + b], r1 = a.meta[ENC_META_STARTS + b + 1];
+    const int r0 = a.meta[M::STARTS + b], r1 = a.meta[M::STARTS + b + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 gg[NV], bb[NV], acc[NV];
 #pragma unroll

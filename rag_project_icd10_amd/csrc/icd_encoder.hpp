@@ -10,6 +10,7 @@
 #pragma once
 #include "attention_kernel.hpp"
 #include "encoder_small.hpp"
+#include "encoder_big.hpp"
 
 struct icd_encoder {
     uint64_t magic = 0;
@@ -36,6 +37,15 @@ struct icd_encoder {
     int *h_ring[RING] = {};
     hipEvent_t ev_ring[RING] = {};      // recorded behind the H2D copy of the slot: the slot may be refilled once it has run
     bool ring_pending[RING] = {};
+    // the batch form's workspace (encoder_big.hpp): allocated at the first icd_encoder_encode_many of more than one small call
+    struct Big {
+        float *y[3] = {nullptr, nullptr, nullptr}, *x = nullptr, *qkv = nullptr, *ctx = nullptr, *mid = nullptr, *pooled = nullptr, *sA = nullptr, *sB = nullptr;
+        int *d_meta = nullptr;
+        int *h_meta[2] = {nullptr, nullptr};          // pinned descriptors of consecutive passes
+        hipEvent_t ev[2] = {nullptr, nullptr};        // behind the H2D copy of each
+        bool pending[2] = {false, false};
+        bool ready = false;
+    } big;
     unsigned long long *stamps = nullptr;   // diagnostic builds (ICD_ABLATE, env ICD_ENC_STAMPS=1): [4 GEMMs of layer 0][16] clock stamps
     std::mutex mu;
 };
@@ -145,21 +155,123 @@ inline int enc_graph(icd_encoder *e, int bi, int pooling, int normalize, bool si
     return ICD_OK;
 }
 
-// the descriptor of one call (encoder_small.hpp, layout at ENC_META_*): sequences [b0, b0 + nb) of `lengths`, their ids at ids + t0
+// the descriptor of one call (encoder_small.hpp, EncMeta): `nb` sequences of `lengths`, their ids back to back at `ids`
+template <typename M>
 inline void enc_fill_meta(int *m, const icd_encoder_desc &d, const int32_t *ids, const int32_t *lengths, int nb, int T) {
     m[0] = T; m[1] = nb;
     int t = 0;
     for (int b = 0; b < nb; ++b) {
-        m[ENC_META_STARTS + b] = t;
+        m[M::STARTS + b] = t;
         const int first = t;
-        for (int i = 0; i < lengths[b]; ++i, ++t) { m[ENC_META_IDS + t] = ids[t]; m[ENC_META_POS + t] = d.pos_offset + i; m[ENC_META_TOK_R0 + t] = first; m[ENC_META_TOK_LEN + t] = lengths[b]; }
+        for (int i = 0; i < lengths[b]; ++i, ++t) { m[M::IDS + t] = ids[t]; m[M::POS + t] = d.pos_offset + i; m[M::TOK_R0 + t] = first; m[M::TOK_LEN + t] = lengths[b]; }
     }
-    for (int b = nb; b <= ENC_BMAX; ++b) m[ENC_META_STARTS + b] = T;
-    for (int u = T; u < ENC_TMAX; ++u) { m[ENC_META_TOK_R0 + u] = 0; m[ENC_META_TOK_LEN + u] = 0; }
+    for (int b = nb; b <= M::B_MAX; ++b) m[M::STARTS + b] = T;
+    for (int u = T; u < M::T_MAX; ++u) { m[M::TOK_R0 + u] = 0; m[M::TOK_LEN + u] = 0; }
+}
+
+// ---- the batch form: one pass over T <= ENC_BIG_TMAX tokens / nb <= ENC_BIG_BMAX sequences whose descriptor is in big.d_meta ----
+template <int ITER, int NV, int TM>
+inline int enc_big_enqueue_t(icd_encoder *e, int T, int nb, int pooling, int normalize, hipStream_t s) {
+    constexpr int KW = 16 * ITER;
+    using M = EncMetaBig;
+    const icd_encoder_desc &d = e->d;
+    icd_encoder::Big &g = e->big;
+    const int H = d.hidden, I = d.inter;
+    const int tiles = (T + 15) / 16;
+    const unsigned gy = (unsigned)((tiles + 4 * TM - 1) / (4 * TM));
+    {
+        EncEmbedArgs a{};
+        a.meta = g.d_meta; a.word = d.word_emb; a.pos = d.pos_emb; a.type0 = d.type_emb0; a.H = H; a.KW = KW; a.y = g.y[0];
+        hipLaunchKernelGGL((enc_embed_kernel<NV, M>), dim3((T + 3) / 4), dim3(256), 0, s, a);
+    }
+    int cur = 0;
+    const float *pg = d.emb_ln_g, *pb = d.emb_ln_b;
+    auto stats = [&](const float *x, float *out) {
+        EncStatsArgs a{};
+        a.x = x; a.stats = out; a.T = T; a.K = H; a.eps = d.ln_eps;
+        hipLaunchKernelGGL((enc_ln_stats_kernel<ITER>), dim3((tiles + 3) / 4), dim3(256), 0, s, a);
+    };
+    for (int l = 0; l < d.layers; ++l) {
+        float *y0 = g.y[cur], *y1 = g.y[(cur + 1) % 3], *y2 = g.y[(cur + 2) % 3];
+        stats(y0, g.sA);
+        {   // Q | K | V = LayerNorm(y0) Wqkv^T + b
+            EncBigLinearArgs a{};
+            a.x = y0; a.stats = g.sA; a.c1 = e->c1_qkv[l]; a.w = e->w_qkv[l]; a.NT = 16; a.bias = e->c2_qkv[l]; a.y = g.qkv;
+            a.T = T; a.K = H; a.N = 3 * H; a.pps = H / KW;
+            hipLaunchKernelGGL((enc_linear_big_kernel<ITER, TM, 4, 0, true, false, 1>), dim3(3 * H / 64, gy), dim3(256), 0, s, a);
+        }
+        {
+            EncAttnArgs a{};
+            a.meta = g.d_meta; a.qkv = g.qkv; a.out = g.ctx; a.H = H; a.heads = d.heads; a.KW = KW; a.scale = 0.125f;
+            hipLaunchKernelGGL((enc_attention_kernel<false, M>), dim3((unsigned)(((size_t)T * d.heads + 3) / 4)), dim3(256), 0, s, a);
+        }
+        {   // y1 = ctx Wo^T + b + LayerNorm(y0)
+            EncBigLinearArgs a{};
+            a.x = g.ctx; a.w = e->w_ao[l]; a.NT = 8; a.bias = e->b_ao[l];
+            a.res_src = y0; a.res_stats = g.sA; a.res_g = pg; a.res_b = pb; a.y = y1; a.T = T; a.K = H; a.N = H; a.pps = H / KW;
+            hipLaunchKernelGGL((enc_linear_big_kernel<ITER, TM, 2, 2, false, true, 1>), dim3(H / 32, gy), dim3(256), 0, s, a);
+        }
+        stats(y1, g.sB);
+        {   // mid = GELU(LayerNorm1(y1) Wup^T + b)
+            EncBigLinearArgs a{};
+            a.x = y1; a.stats = g.sB; a.c1 = e->c1_up[l]; a.w = e->w_up[l]; a.NT = 16; a.bias = e->c2_up[l]; a.y = g.mid;
+            a.T = T; a.K = H; a.N = I; a.pps = H / KW;
+            hipLaunchKernelGGL((enc_linear_big_kernel<ITER, TM, 4, 1, true, true, 1>), dim3(I / 64, gy), dim3(256), 0, s, a);
+        }
+        {   // y2 = mid Wdown^T + b + LayerNorm1(y1): the small form's ENC_SLABS K slices, added in slab order
+            EncBigLinearArgs a{};
+            a.x = g.mid; a.w = e->w_down[l]; a.NT = 16; a.bias = e->b_down[l];
+            a.res_src = y1; a.res_stats = g.sB; a.res_g = e->ln1_g[l]; a.res_b = e->ln1_b[l]; a.y = y2; a.T = T; a.K = I; a.N = H; a.pps = I / KW / ENC_SLABS;
+            hipLaunchKernelGGL((enc_linear_big_kernel<ITER, TM, 2, 2, false, true, ENC_SLABS>), dim3(H / 32, gy), dim3(256), 0, s, a);
+        }
+        cur = (cur + 2) % 3;
+        pg = e->ln2_g[l]; pb = e->ln2_b[l];
+    }
+    {
+        EncPoolArgs a{};
+        a.meta = g.d_meta; a.y = g.y[cur]; a.g = pg; a.b = pb; a.eps = d.ln_eps; a.H = H; a.KW = KW; a.pooling = pooling; a.normalize = normalize;
+        a.out = g.pooled; a.hidden = g.x; a.slab = 0;
+        hipLaunchKernelGGL((enc_pool_kernel<NV, 1, M>), dim3(nb), dim3(ENC_POOL_WAVES * 64), 0, s, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return ICD_OK;
+}
+
+inline int enc_big_enqueue(icd_encoder *e, int T, int nb, int pooling, int normalize, hipStream_t s) {
+    // two tiles of tokens per wave where there are enough tokens to fill the chip with them (128 tokens per work-group)
+    const bool wide = T >= 2048;
+    if (e->d.hidden == 1024) return wide ? enc_big_enqueue_t<16, 4, 2>(e, T, nb, pooling, normalize, s) : enc_big_enqueue_t<16, 4, 1>(e, T, nb, pooling, normalize, s);
+    return wide ? enc_big_enqueue_t<12, 3, 2>(e, T, nb, pooling, normalize, s) : enc_big_enqueue_t<12, 3, 1>(e, T, nb, pooling, normalize, s);
+}
+
+// the batch form's buffers: activations of ENC_BIG_TMAX tokens (+ the rows a last partial work-group reads), ~0.5 GB at hidden 768
+inline int enc_big_alloc(icd_encoder *e) {
+    icd_encoder::Big &g = e->big;
+    if (g.ready) return ICD_OK;
+    const size_t H = (size_t)e->d.hidden, I = (size_t)e->d.inter, T = (size_t)ENC_BIG_TMAX + 128;
+    struct { float **p; size_t n; } bufs[] = {{&g.y[0], T * H}, {&g.y[1], T * H}, {&g.y[2], T * H}, {&g.x, T * H}, {&g.qkv, T * 3 * H}, {&g.ctx, T * H},
+                                              {&g.mid, T * I}, {&g.pooled, (size_t)ENC_BIG_BMAX * H}, {&g.sA, 2 * T}, {&g.sB, 2 * T}};
+    for (auto &b : bufs) {
+        if (*b.p) continue;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(b.p), b.n * sizeof(float)));
+        HIP_TRY(hipMemset(*b.p, 0, b.n * sizeof(float)));   // (rows past a pass's tokens are read by its last tiles: finite, never stored)
+    }
+    if (!g.d_meta) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_meta), EncMetaBig::WORDS * sizeof(int)));
+    for (int r = 0; r < 2; ++r) {
+        if (!g.h_meta[r]) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g.h_meta[r]), EncMetaBig::WORDS * sizeof(int), hipHostMallocDefault));
+        if (!g.ev[r]) HIP_TRY(hipEventCreateWithFlags(&g.ev[r], hipEventDisableTiming));
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    g.ready = true;
+    return ICD_OK;
 }
 
 inline void enc_free(icd_encoder *e) {
     for (auto &b : e->exec) for (auto &p : b) for (auto &n : p) for (auto &o : n) for (auto &g : o) if (g) hipGraphExecDestroy(g);
+    for (float *p : {e->big.y[0], e->big.y[1], e->big.y[2], e->big.x, e->big.qkv, e->big.ctx, e->big.mid, e->big.pooled, e->big.sA, e->big.sB}) if (p) hipFree(p);
+    if (e->big.d_meta) hipFree(e->big.d_meta);
+    for (int *p : e->big.h_meta) if (p) hipHostFree(p);
+    for (hipEvent_t ev : e->big.ev) if (ev) hipEventDestroy(ev);
     for (int *p : e->h_ring) if (p) hipHostFree(p);
     for (hipEvent_t ev : e->ev_ring) if (ev) hipEventDestroy(ev);
     for (float *p : {e->yb[0], e->yb[1], e->yb[2], e->x, e->qkv, e->ctx, e->mid, e->pooled, e->sA, e->sB}) if (p) hipFree(p);
@@ -321,7 +433,7 @@ int icd_encoder_encode(icd_encoder *e, const int32_t *ids, const int32_t *length
     if (capturing) return fail(ICD_ERR_UNSUPPORTED, "icd_encoder_encode reads its token ids from host memory at call time: it cannot be captured into a graph");
     // the previous launch's copy node may not have read h_meta yet (device outputs: the call did not wait)
     if (e->ev_pending) { HIP_TRY(hipEventSynchronize(e->ev_done)); e->ev_pending = false; }
-    enc_fill_meta(e->h_meta, d, ids, lengths, nseq, T);
+    enc_fill_meta<EncMetaSmall>(e->h_meta, d, ids, lengths, nseq, T);
     hipGraphExec_t gx = nullptr;
     { const int rc = enc_graph(e, enc_bucket(T), pooling, normalize, nseq == 1, true, &gx); if (rc) return rc; }
     HIP_TRY(hipGraphLaunch(gx, s));
@@ -365,13 +477,36 @@ int icd_encoder_encode_many(icd_encoder *e, const int32_t *ids, const int32_t *l
     //  protects d_meta; h_meta is not touched here)
     const size_t H = (size_t)d.hidden;
     int64_t b0 = 0, t0 = 0;
+    if (total > ENC_TMAX || nseq > ENC_BMAX) {
+        // more than one small call: the batch form (encoder_big.hpp) - the same arithmetic per token in large tiles, passes of
+        // at most ENC_BIG_TMAX tokens / ENC_BIG_BMAX sequences cut greedily in the given order; the host fills pass i + 1's
+        // descriptor while pass i runs
+        { const int rc = enc_big_alloc(e); if (rc) return rc; }
+        icd_encoder::Big &g = e->big;
+        int slot = 0;
+        while (b0 < nseq) {
+            int nb = 0, T = 0;
+            while (b0 + nb < nseq && nb < ENC_BIG_BMAX && T + lengths[b0 + nb] <= ENC_BIG_TMAX) { T += lengths[b0 + nb]; ++nb; }
+            if (g.pending[slot]) { HIP_TRY(hipEventSynchronize(g.ev[slot])); g.pending[slot] = false; }
+            enc_fill_meta<EncMetaBig>(g.h_meta[slot], d, ids + t0, lengths + b0, nb, T);
+            HIP_TRY(hipMemcpyAsync(g.d_meta, g.h_meta[slot], EncMetaBig::WORDS * sizeof(int), hipMemcpyHostToDevice, s));
+            HIP_TRY(hipEventRecord(g.ev[slot], s));
+            g.pending[slot] = true;
+            { const int rc = enc_big_enqueue(e, T, nb, pooling, normalize, s); if (rc) return rc; }
+            HIP_TRY(hipMemcpyAsync(out + (size_t)b0 * H, g.pooled, (size_t)nb * H * sizeof(float), out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+            b0 += nb; t0 += T;
+            slot ^= 1;
+        }
+        if (!out_on_device) HIP_TRY(hipStreamSynchronize(s));
+        return ICD_OK;
+    }
     int slot = 0;
     while (b0 < nseq) {
         // greedy, in the given order: as many sequences as fit the largest bucket
         int nb = 0, T = 0;
         while (b0 + nb < nseq && nb < ENC_BMAX && T + lengths[b0 + nb] <= ENC_TMAX) { T += lengths[b0 + nb]; ++nb; }
         if (e->ring_pending[slot]) { HIP_TRY(hipEventSynchronize(e->ev_ring[slot])); e->ring_pending[slot] = false; }
-        enc_fill_meta(e->h_ring[slot], d, ids + t0, lengths + b0, nb, T);
+        enc_fill_meta<EncMetaSmall>(e->h_ring[slot], d, ids + t0, lengths + b0, nb, T);
         hipGraphExec_t gx = nullptr;
         { const int rc = enc_graph(e, enc_bucket(T), pooling, normalize, nb == 1, false, &gx); if (rc) return rc; }
         HIP_TRY(hipMemcpyAsync(e->d_meta, e->h_ring[slot], ENC_META_WORDS * sizeof(int), hipMemcpyHostToDevice, s));
