@@ -76,11 +76,14 @@ struct EncBigLinearArgs {
 // ITER: 16-column k-steps per K piece (12: hidden 768 / inter 3 072; 16: hidden 1 024 / inter 4 096); TM x TN: tiles of 16 tokens x
 // 16 columns per wave; EPI / LNPRO / OUT_PA: as enc_linear_kernel; SLICES: K slices of `pps` pieces each whose sums the small
 // form keeps in slabs (1, or ENC_SLABS = 4: the FFN-down GEMM)
-template <int ITER, int TM, int TN, int EPI, bool LNPRO, bool OUT_PA, int SLICES>
+// PF: pairs of k-steps in flight ahead of the MFMAs (1: a double buffer, 2: three buffers - where ITER / 2 is a multiple of three)
+template <int ITER, int TM, int TN, int EPI, bool LNPRO, bool OUT_PA, int SLICES, int PF = 1>
 __global__ __launch_bounds__(256) void enc_linear_big_kernel(EncBigLinearArgs a) {
+    extern __shared__ char enc_big_occupancy_pin[];   // (never touched: the launch asks for more than half a CU's LDS so that a CU holds ONE work-group - see icd_encoder.hpp)
     constexpr int KW = 16 * ITER;
     constexpr int STEPS = ITER / 2;           // an iteration: two k-steps (one MFMA group of each chain)
-    static_assert(STEPS % 2 == 0, "the register double buffer returns to buffer 0 at every piece");
+    constexpr int NBUF = PF + 1;
+    static_assert(STEPS % NBUF == 0, "the register ring returns to buffer 0 at every piece");
     const int NPIECE = a.pps * SLICES;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void enc_linear_big_kernel(EncBigLinearArgs a)
     }
     const size_t a_step = 256, a_piece = (size_t)ITER * 256;                        // floats between k-steps / pieces of an A tile
     const size_t b_step = (size_t)4 * a.NT * 4, b_piece = (size_t)ITER * b_step;    // ... of a W row tile
-    float4 abuf[2][2][TM], bbuf[2][2][TN];   // [buffer][k-step of the pair][tile]
+    float4 abuf[NBUF][2][TM], bbuf[NBUF][2][TN];   // [buffer][k-step of the pair][tile]
     auto load_pair = [&](const int buf, int piece, int st) {   // (buf is a constant at every call site: the buffers stay in registers)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -122,6 +125,7 @@ __global__ __launch_bounds__(256) void enc_linear_big_kernel(EncBigLinearArgs a)
         rb[n] = EPI == 2 ? a.res_b[col] : 0.f;
     }
     load_pair(0, 0, 0);
+    if constexpr (PF == 2) load_pair(1, 0, 1);
 #pragma unroll 1
     for (int sl = 0; sl < SLICES; ++sl) {
         enc_f32x4 s[TM][TN];
@@ -140,23 +144,22 @@ __global__ __launch_bounds__(256) void enc_linear_big_kernel(EncBigLinearArgs a)
 #pragma unroll
             for (int st = 0; st < STEPS; ++st) {
                 // the next pair's loads (the next piece's first pair behind this piece's last) under this pair's MFMAs
-                const bool last = st == STEPS - 1;
-                if (!(last && piece == NPIECE - 1)) load_pair((st & 1) ^ 1, last ? piece + 1 : piece, last ? 0 : st + 1);
+                // the loads of the pair PF steps ahead (into the next pieces' first pairs behind this piece's last) under this pair's MFMAs
+                {
+                    const int ahead = st + PF;                       // (STEPS >= NBUF: at most one piece ahead)
+                    const int pz = ahead >= STEPS ? piece + 1 : piece, sz = ahead >= STEPS ? ahead - STEPS : ahead;
+                    if (pz < NPIECE) load_pair((st + PF) % NBUF, pz, sz);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int m = 0; m < TM; ++m)
-#pragma unroll
-                    for (int n = 0; n < TN; ++n) {
-                        const float4 a0 = abuf[st & 1][0][m], a1 = abuf[st & 1][1][m], b0 = bbuf[st & 1][0][n], b1 = bbuf[st & 1][1][n];
-                        c0[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, c0[m][n], 0, 0, 0);
-                        c1[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, c1[m][n], 0, 0, 0);
-                        c0[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, c0[m][n], 0, 0, 0);
-                        c1[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, c1[m][n], 0, 0, 0);
-                        c0[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, c0[m][n], 0, 0, 0);
-                        c1[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, c1[m][n], 0, 0, 0);
-                        c0[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, c0[m][n], 0, 0, 0);
-                        c1[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, c1[m][n], 0, 0, 0);
+                // (component by component over ALL tiles: consecutive MFMAs never touch the same accumulator)
+#define ENC_BIG_MFMA(C)                                                                                                   \
+                _Pragma("unroll") for (int m = 0; m < TM; ++m)                                                            \
+                    _Pragma("unroll") for (int n = 0; n < TN; ++n) {                                                      \
+                        c0[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[st % NBUF][0][m].C, bbuf[st % NBUF][0][n].C, c0[m][n], 0, 0, 0); \
+                        c1[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[st % NBUF][1][m].C, bbuf[st % NBUF][1][n].C, c1[m][n], 0, 0, 0); \
                     }
+                ENC_BIG_MFMA(x) ENC_BIG_MFMA(y) ENC_BIG_MFMA(z) ENC_BIG_MFMA(w)
+#undef ENC_BIG_MFMA
                 __builtin_amdgcn_sched_barrier(0);
             }
             // the piece's sum joins the slice's: s += (c0 + c1), in piece order (the small form: s = 0; for w: s += red[w])

@@ -354,6 +354,41 @@ __global__ __launch_bounds__(MAXW * 64) void enc_linear_kernel(EncLinearArgs a) 
     }
 }
 
+// one chunk of at most CH keys of the flash recurrence of ONE (token, head): q = the lane's scaled query component, kreg / vreg =
+// the lane's component of the chunk's keys / values; the first Lc are live (contraction off: the roundings are the ones written here)
+template <int CH>
+__device__ __forceinline__ void enc_attn_chunk(float q, const float (&kreg)[CH], const float (&vreg)[CH], int Lc, float &m_run, float &l_run, float &o_run) {
+#pragma clang fp contract(off)
+    // (keys in groups of eight behind wave-uniform branches: a 18-token sequence pays for 24 keys, not for the chunk's 32 - the
+    //  sums are VALU work, ~7 DPP steps per key and token, and the batch form is bound by it)
+    float sc[CH];
+    float m = m_run;
+#pragma unroll
+    for (int jb = 0; jb < CH; jb += 8) {
+        if (jb < Lc) {
+#pragma unroll
+            for (int j = jb; j < jb + 8; ++j) {
+                sc[j] = j < Lc ? att_wave_sum(q * kreg[j]) : -INFINITY;   // (wave-uniform)
+                m = fmaxf(m, sc[j]);
+            }
+        }
+    }
+    const float carry = expf(m_run - m);      // (first chunk: exp(-inf) = 0)
+    float l = l_run * carry, o = o_run * carry;
+#pragma unroll
+    for (int jb = 0; jb < CH; jb += 8) {
+        if (jb < Lc) {
+#pragma unroll
+            for (int j = jb; j < jb + 8; ++j) {
+                const float e = j < Lc ? expf(sc[j] - m) : 0.f;
+                l += e;
+                o = fmaf(e, vreg[j], o);
+            }
+        }
+    }
+    m_run = m; l_run = l; o_run = o;
+}
+
 struct EncAttnArgs {
     const int *meta;
     const float *qkv;   // [TMAX][3 H] row-major: Q | K | V of a token side by side
@@ -402,22 +437,7 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(EncAttnArgs a) {
                 vreg[j] = vb[row];
             }
         }
-        float sc[CH];
-        float m = m_run;
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            sc[j] = j < Lc ? att_wave_sum(q * kreg[j]) : -INFINITY;   // (wave-uniform)
-            m = fmaxf(m, sc[j]);
-        }
-        const float carry = expf(m_run - m);      // (first chunk: exp(-inf) = 0)
-        float l = l_run * carry, o = o_run * carry;
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const float e = j < Lc ? expf(sc[j] - m) : 0.f;
-            l += e;
-            o = fmaf(e, vreg[j], o);
-        }
-        m_run = m; l_run = l; o_run = o;
+        enc_attn_chunk<CH>(q, kreg, vreg, Lc, m_run, l_run, o_run);
     }
     a.out[enc_pa(t, h * ATT_HEAD_DIM + lane, a.H, a.KW)] = o_run / l_run;
 }

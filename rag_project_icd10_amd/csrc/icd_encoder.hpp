@@ -170,7 +170,15 @@ inline void enc_fill_meta(int *m, const icd_encoder_desc &d, const int32_t *ids,
 }
 
 // ---- the batch form: one pass over T <= ENC_BIG_TMAX tokens / nb <= ENC_BIG_BMAX sequences whose descriptor is in big.d_meta ----
-template <int ITER, int NV, int TM>
+// ONE work-group per CU for the GEMMs: the four waves of a work-group share their W fragments through the CU's L1 (32 KB); a second
+// work-group's fragments evict them (measured, per layer and 8 192 tokens: QKV 333 -> 254 us, FFN up 457 -> 365, FFN down 447 -> 354,
+// attention output 141 -> 104, profiles/r06_encoder_big_kernel_stats.log). The kernels use no LDS: asking for more than half of a
+// CU's 160 KB as dynamic LDS is what keeps the second work-group away.
+constexpr size_t ENC_BIG_LDS_PIN = 84 * 1024;
+// TM: 16-token tiles per wave; TNQ / TNU / TNO: 16-column tiles per wave of the QKV, FFN-up and the two hidden-sized-output GEMMs (the
+// column groups per GEMM a multiple of the 8 XCDs: the hardware deals work-groups round-robin over them, so a column group's W
+// tiles stay in ONE XCD's L2); PF: pairs of k-steps in flight
+template <int ITER, int NV, int TM, int TNQ, int TNU, int TNO, int PF>
 inline int enc_big_enqueue_t(icd_encoder *e, int T, int nb, int pooling, int normalize, hipStream_t s) {
     constexpr int KW = 16 * ITER;
     using M = EncMetaBig;
@@ -179,6 +187,19 @@ inline int enc_big_enqueue_t(icd_encoder *e, int T, int nb, int pooling, int nor
     const int H = d.hidden, I = d.inter;
     const int tiles = (T + 15) / 16;
     const unsigned gy = (unsigned)((tiles + 4 * TM - 1) / (4 * TM));
+    size_t lds_pin = ENC_BIG_LDS_PIN;
+#ifdef ICD_ABLATE
+    if (const char *v = getenv("ICD_ENCBIG_LDS")) lds_pin = (size_t)atoi(v);   // A/B: 0 = as many work-groups per CU as the registers allow
+#endif
+    auto k_qkv = enc_linear_big_kernel<ITER, TM, TNQ, 0, true, false, 1, PF>;
+    auto k_ao = enc_linear_big_kernel<ITER, TM, TNO, 2, false, true, 1, PF>;
+    auto k_up = enc_linear_big_kernel<ITER, TM, TNU, 1, true, true, 1, PF>;
+    auto k_down = enc_linear_big_kernel<ITER, TM, TNO, 2, false, true, ENC_SLABS, PF>;
+    {
+        static int c0[MAX_DEVICES] = {}, c1[MAX_DEVICES] = {}, c2[MAX_DEVICES] = {}, c3[MAX_DEVICES] = {};   // (per instantiation and device; calls on a handle are serialised)
+        HIP_TRY(ensure_dynamic_lds(k_qkv, e->device, lds_pin, c0)); HIP_TRY(ensure_dynamic_lds(k_ao, e->device, lds_pin, c1));
+        HIP_TRY(ensure_dynamic_lds(k_up, e->device, lds_pin, c2)); HIP_TRY(ensure_dynamic_lds(k_down, e->device, lds_pin, c3));
+    }
     {
         EncEmbedArgs a{};
         a.meta = g.d_meta; a.word = d.word_emb; a.pos = d.pos_emb; a.type0 = d.type_emb0; a.H = H; a.KW = KW; a.y = g.y[0];
@@ -198,9 +219,12 @@ inline int enc_big_enqueue_t(icd_encoder *e, int T, int nb, int pooling, int nor
             EncBigLinearArgs a{};
             a.x = y0; a.stats = g.sA; a.c1 = e->c1_qkv[l]; a.w = e->w_qkv[l]; a.NT = 16; a.bias = e->c2_qkv[l]; a.y = g.qkv;
             a.T = T; a.K = H; a.N = 3 * H; a.pps = H / KW;
-            hipLaunchKernelGGL((enc_linear_big_kernel<ITER, TM, 4, 0, true, false, 1>), dim3(3 * H / 64, gy), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(k_qkv, dim3(3 * H / (16 * TNQ), gy), dim3(256), lds_pin, s, a);
         }
         {
+            // (one wave per (token, head): the attention is VALU work - a wave-wide sum per key and token - and 100 000 short waves
+            //  balance over the SIMDs where 5 000 long ones, one per (sequence, head) with the keys kept in registers, do not:
+            //  205 against 495 us per layer and 8 192 tokens, profiles/r06_encoder_big_kernel_stats.log)
             EncAttnArgs a{};
             a.meta = g.d_meta; a.qkv = g.qkv; a.out = g.ctx; a.H = H; a.heads = d.heads; a.KW = KW; a.scale = 0.125f;
             hipLaunchKernelGGL((enc_attention_kernel<false, M>), dim3((unsigned)(((size_t)T * d.heads + 3) / 4)), dim3(256), 0, s, a);
@@ -209,20 +233,20 @@ inline int enc_big_enqueue_t(icd_encoder *e, int T, int nb, int pooling, int nor
             EncBigLinearArgs a{};
             a.x = g.ctx; a.w = e->w_ao[l]; a.NT = 8; a.bias = e->b_ao[l];
             a.res_src = y0; a.res_stats = g.sA; a.res_g = pg; a.res_b = pb; a.y = y1; a.T = T; a.K = H; a.N = H; a.pps = H / KW;
-            hipLaunchKernelGGL((enc_linear_big_kernel<ITER, TM, 2, 2, false, true, 1>), dim3(H / 32, gy), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(k_ao, dim3(H / (16 * TNO), gy), dim3(256), lds_pin, s, a);
         }
         stats(y1, g.sB);
         {   // mid = GELU(LayerNorm1(y1) Wup^T + b)
             EncBigLinearArgs a{};
             a.x = y1; a.stats = g.sB; a.c1 = e->c1_up[l]; a.w = e->w_up[l]; a.NT = 16; a.bias = e->c2_up[l]; a.y = g.mid;
             a.T = T; a.K = H; a.N = I; a.pps = H / KW;
-            hipLaunchKernelGGL((enc_linear_big_kernel<ITER, TM, 4, 1, true, true, 1>), dim3(I / 64, gy), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(k_up, dim3(I / (16 * TNU), gy), dim3(256), lds_pin, s, a);
         }
         {   // y2 = mid Wdown^T + b + LayerNorm1(y1): the small form's ENC_SLABS K slices, added in slab order
             EncBigLinearArgs a{};
             a.x = g.mid; a.w = e->w_down[l]; a.NT = 16; a.bias = e->b_down[l];
             a.res_src = y1; a.res_stats = g.sB; a.res_g = e->ln1_g[l]; a.res_b = e->ln1_b[l]; a.y = y2; a.T = T; a.K = I; a.N = H; a.pps = I / KW / ENC_SLABS;
-            hipLaunchKernelGGL((enc_linear_big_kernel<ITER, TM, 2, 2, false, true, ENC_SLABS>), dim3(H / 32, gy), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(k_down, dim3(H / (16 * TNO), gy), dim3(256), lds_pin, s, a);
         }
         cur = (cur + 2) % 3;
         pg = e->ln2_g[l]; pb = e->ln2_b[l];
@@ -238,10 +262,32 @@ inline int enc_big_enqueue_t(icd_encoder *e, int T, int nb, int pooling, int nor
 }
 
 inline int enc_big_enqueue(icd_encoder *e, int T, int nb, int pooling, int normalize, hipStream_t s) {
-    // two tiles of tokens per wave where there are enough tokens to fill the chip with them (128 tokens per work-group)
-    const bool wide = T >= 2048;
-    if (e->d.hidden == 1024) return wide ? enc_big_enqueue_t<16, 4, 2>(e, T, nb, pooling, normalize, s) : enc_big_enqueue_t<16, 4, 1>(e, T, nb, pooling, normalize, s);
-    return wide ? enc_big_enqueue_t<12, 3, 2>(e, T, nb, pooling, normalize, s) : enc_big_enqueue_t<12, 3, 1>(e, T, nb, pooling, normalize, s);
+    // tiles of 16 tokens per wave: as many as still leave every CU a work-group of the narrowest GEMM (16 column groups x T / (64 TM) rows)
+    const int tm = T >= 4096 ? 4 : (T >= 2048 ? 2 : 1);
+#ifdef ICD_ABLATE
+    if (const char *v = getenv("ICD_ENCBIG_VAR")) {   // A/B: tile shapes and prefetch depth of the batch form's GEMMs (profiles/r06_encoder_big_sweep.log)
+        switch (atoi(v)) {
+        case 0: return enc_big_enqueue_t<12, 3, 2, 3, 4, 2, 1>(e, T, nb, pooling, normalize, s);
+        case 1: return enc_big_enqueue_t<12, 3, 2, 3, 4, 3, 1>(e, T, nb, pooling, normalize, s);
+        case 2: return enc_big_enqueue_t<12, 3, 4, 3, 4, 3, 1>(e, T, nb, pooling, normalize, s);
+        case 3: return enc_big_enqueue_t<12, 3, 4, 3, 4, 2, 1>(e, T, nb, pooling, normalize, s);
+        case 4: return enc_big_enqueue_t<12, 3, 2, 3, 4, 2, 2>(e, T, nb, pooling, normalize, s);
+        case 5: return enc_big_enqueue_t<12, 3, 4, 3, 3, 3, 2>(e, T, nb, pooling, normalize, s);
+        case 6: return enc_big_enqueue_t<12, 3, 2, 3, 4, 3, 2>(e, T, nb, pooling, normalize, s);
+        default: break;
+        }
+    }
+#endif
+    // Tile shapes (profiles/r06_encoder_big_sweep.log: seven shapes and prefetch depths within 5 % of each other once a CU holds one
+    // work-group - the GEMMs run at 0.65-0.75 of the 157 TFLOP/s fp32 MFMA peak, which is what the fp32-MFMA search kernel reaches too)
+    if (e->d.hidden == 1024) {
+        if (tm == 4) return enc_big_enqueue_t<16, 4, 4, 3, 4, 2, 1>(e, T, nb, pooling, normalize, s);
+        if (tm == 2) return enc_big_enqueue_t<16, 4, 2, 3, 4, 2, 1>(e, T, nb, pooling, normalize, s);
+        return enc_big_enqueue_t<16, 4, 1, 3, 4, 2, 1>(e, T, nb, pooling, normalize, s);
+    }
+    if (tm == 4) return enc_big_enqueue_t<12, 3, 4, 3, 4, 3, 1>(e, T, nb, pooling, normalize, s);
+    if (tm == 2) return enc_big_enqueue_t<12, 3, 2, 3, 4, 3, 1>(e, T, nb, pooling, normalize, s);
+    return enc_big_enqueue_t<12, 3, 1, 3, 4, 3, 1>(e, T, nb, pooling, normalize, s);
 }
 
 // the batch form's buffers: activations of ENC_BIG_TMAX tokens (+ the rows a last partial work-group reads), ~0.5 GB at hidden 768

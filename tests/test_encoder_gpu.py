@@ -484,6 +484,13 @@ def test_small_input_encoder_at_hidden_1024(family):
             assert got.shape == (len(ids), 1024)
             assert np.max(np.abs(got - want)) <= TOL, (family, lengths)
             assert np.max(np.abs(rows.cpu().numpy() - want_rows)) <= 5e-5, (family, lengths)
+        # the batch form at hidden 1024 (csrc/encoder_big.hpp, 256-column K pieces): 90 sequences = 2 000+ tokens in one list, every
+        # row bit for bit what the sequence gets alone
+        lengths = [int(x) for x in rng.integers(1, 60, 88)] + [300, 1]
+        ids = [[int(v) for v in rng.integers(5, 3000, size=n)] for n in lengths]
+        many = enc.encode_many(ids)
+        for i in (0, 1, 17, 45, 87, 88, 89):
+            assert np.array_equal(many[i], enc.encode([ids[i]])[0]), (family, i, lengths[i])
     finally:
         enc.close()
 
