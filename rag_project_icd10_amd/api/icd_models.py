@@ -111,6 +111,74 @@ def trusted_candidates(recs, ids, scores, originals, factors) -> List["Candidate
     return out
 
 
+def trusted_matches_ready() -> bool:
+    """True once trusted_candidate has checked, on a real object, that this pydantic lays its models out the way the unchecked
+    constructors assume"""
+    return _trusted_ok is True
+
+
+_SHARED_CAND_FIELDS = set(_CAND_FIELDS)   # ONE set for every bulk-made Candidate: all eight fields are in it, so pydantic's own
+                                          # `fields_set.add(name)` on assignment never changes it; model_copy() copies it
+
+
+def bulk_candidates(codes, titles, factors_cls, ids, scores, originals, vs, hb, sc: float, cr: float) -> List["Candidate"]:
+    """The Candidate objects of ONE query's winners with their SimilarityFactors, in one loop without a call per object (row N2:
+    the batched request path makes 10 000 of each per 1 000 strings - this loop is most of what that path costs the host).
+    codes / titles: the corpus' columns by row; ids / scores / originals / vs / hb: the winners' parallel sequences (live hits:
+    level 1, parent "", no entity match, no category alignment - SURVEY F8). The caller has checked trusted_matches_ready().
+    A negative or NaN score raises the validated constructor's ValidationError (reference models/icd_models.py:71)."""
+    out = []
+    new, onew, setattr_, shared = Candidate.__new__, object.__new__, object.__setattr__, _SHARED_CAND_FIELDS
+    for j in range(len(ids)):
+        s = scores[j]
+        if not s >= 0.0:
+            Candidate(code="", title="", score=s)   # raises
+        f = onew(factors_cls)
+        f.__dict__ = {"vector_similarity": vs[j], "hierarchy_boost": hb[j], "entity_match_score": 0.0, "semantic_coherence": sc,
+                      "category_alignment": 0.0, "context_relevance": cr}
+        i = ids[j]
+        c = new(Candidate)
+        setattr_(c, "__dict__", {"code": codes[i], "title": titles[i], "score": s, "level": 1, "parent_code": "",
+                                 "enhanced_score": s, "original_score": originals[j], "similarity_factors": f})
+        setattr_(c, "__pydantic_fields_set__", shared)
+        setattr_(c, "__pydantic_extra__", None)
+        setattr_(c, "__pydantic_private__", None)
+        out.append(c)
+    return out
+
+
+_trusted_match_ok: Optional[bool] = None
+_setattr = object.__setattr__
+
+
+def _new_match(cls):
+    return cls.__new__(cls)
+
+
+def trusted_match(diagnosis_text: str, candidates: List["Candidate"], match_confidence: float, confidence_factors=None) -> "DiagnosisMatch":
+    """DiagnosisMatch(diagnosis_text=, candidates=, match_confidence=, confidence_factors=) from values that are already what its
+    validator would produce (a str, a list of Candidate objects, a float in [0, 1]); checked once against the validated
+    constructor, like trusted_candidate"""
+    global _trusted_match_ok
+    if _trusted_match_ok and 0.0 <= match_confidence <= 1.0:
+        m = _new_match(DiagnosisMatch)
+        _setattr(m, "__dict__", {"diagnosis_text": diagnosis_text, "candidates": candidates, "match_confidence": match_confidence,
+                                 "confidence_metrics": None, "confidence_factors": confidence_factors, "confidence_level": None})
+        _setattr(m, "__pydantic_fields_set__", {"diagnosis_text", "candidates", "match_confidence", "confidence_factors"})
+        _setattr(m, "__pydantic_extra__", None)
+        _setattr(m, "__pydantic_private__", None)
+        return m
+    b = DiagnosisMatch(diagnosis_text=diagnosis_text, candidates=candidates, match_confidence=match_confidence, confidence_factors=confidence_factors)   # (raises outside [0, 1])
+    if _trusted_match_ok is None:
+        try:
+            _trusted_match_ok = True
+            a = trusted_match(diagnosis_text, candidates, match_confidence, confidence_factors)
+            _trusted_match_ok = bool(a == b and a.model_dump() == b.model_dump() and a.model_fields_set == b.model_fields_set)
+        except Exception:
+            _trusted_match_ok = False
+    return b
+
+
 class DiagnosisMatch(BaseModel):
     model_config = ConfigDict(arbitrary_types_allowed=True)
     diagnosis_text: str = Field(..., description="提取的诊断文本")

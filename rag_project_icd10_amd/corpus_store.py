@@ -216,6 +216,16 @@ class CorpusStore:
             self._matrix = np.zeros((0, self.dim), dtype=np.float32)
         return self._matrix
 
+    def code_title_columns(self):
+        """(codes, titles): the two payload fields a Candidate is made of, as plain lists by row - rebuilt when rows were added
+        (the batched request path builds 10 000 Candidates per 1 000 strings: list indexing, not two dict lookups per object)"""
+        cached = getattr(self, "_code_title", None)
+        if cached is None or cached[0] != len(self.records):
+            codes = [r.get("code", "") for r in self.records]
+            titles = [r.get("preferred_zh", "") for r in self.records]
+            self._code_title = cached = (len(self.records), codes, titles)
+        return cached[1], cached[2]
+
     def levels(self) -> np.ndarray:
         """levels of the rows, from the metadata (levels.i32 is the same column as a flat file for external readers;
         `_load()` checks that the two agree)"""

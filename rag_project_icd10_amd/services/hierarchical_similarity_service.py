@@ -320,11 +320,18 @@ class HierarchicalSimilarityService:
             from .uncertainty_diagnosis_service import _MARKER_GROUPS
             cls._kw_any = re.compile("|".join(re.escape(k) for _n, kws, _w in _CHAPTERS.values() for k in kws))
             cls._marker_any = re.compile("|".join(re.escape(m.lower()) for _t, _w, _d, ms in _MARKER_GROUPS for m in ms))
-        if cls._marker_any.search(query_text.lower()):
+            cls._NO_CATS = [0.0] * len(self.CHAPTER_ORDER)
+        lowered_q = query_text.lower()
+        if cls._marker_any.search(lowered_q):
             found = self.uncertainty_service.detect_uncertainty(query_text)
             clean, weight = found["clean_text"], float(found["uncertainty_weight"])
         else:
             clean, weight = query_text, 0.0
+            if not cls._kw_any.search(lowered_q):
+                # the common case, in closed form: no marker, no chapter keyword. Against the empty title of a live hit
+                # _calculate_context_relevance is max((1 - len / max(len, 1)) * 0.3 + 0 * 0.7, 0) = 0.0 for any non-empty text
+                # (0.3 for the empty one), the exact-match flag is set by an all-blank query only, every chapter boost is 0
+                return [0.0, 0.0 if clean else 0.3, 1.0 if not clean.strip() else 0.0] + cls._NO_CATS
         cr = self._calculate_context_relevance(clean, {})
         exact = 1.0 if "" == clean.strip() else 0.0
         lowered = clean.lower()

@@ -199,6 +199,14 @@ class MultiDiagnosisService:
         return out
 
     def _build_matches(self, out, diagnoses, kk, h_ord, h_enh, h_adj, h_raw, h_boost, h_ids, h_vs, h_hb, recs, sc, qps, conf, trusted_factors_row):
+        from ..api.icd_models import bulk_candidates, trusted_match, trusted_matches_ready
+        from .hierarchical_similarity_service import SimilarityFactors
+        # the corpus' code / title columns (plain lists by row) where the store offers them, and the one-loop constructor once
+        # trusted_candidate has checked this pydantic's object layout on a real hit (the first call of a process does)
+        cols = getattr(getattr(self.milvus_service, "client", None), "code_title_columns", None)
+        codes = titles = None
+        if cols is not None and recs is getattr(self.milvus_service.client, "records", None):
+            codes, titles = cols()
         for q, diagnosis in enumerate(diagnoses):
             try:
                 # how many winners exist (order < 0 from there on); live hits carry level / parent_code under "metadata": the
@@ -207,17 +215,23 @@ class MultiDiagnosisService:
                 # raises and degrades the whole match to an empty one, like the reference's
                 n = kk
                 row_ord = h_ord[q]
-                for j in range(kk):
-                    if row_ord[j] < 0:
-                        n = j
-                        break
+                if row_ord[kk - 1] < 0:   # (the winners come first: most queries have all kk)
+                    for j in range(kk):
+                        if row_ord[j] < 0:
+                            n = j
+                            break
                 enh_q, adj_q, raw_q, boost_q = h_enh[q], h_adj[q], h_raw[q], h_boost[q]
-                originals = [adj_q[j] if boost_q[j] > 0 else raw_q[j] for j in range(n)]
-                cands = trusted_candidates(recs, h_ids[q][:n], enh_q[:n], originals,
-                                           trusted_factors_row(h_vs[q][:n], h_hb[q][:n], sc, qps[q][1]))
-                out.append(DiagnosisMatch(diagnosis_text=diagnosis, candidates=cands,
-                                          match_confidence=self._calculate_match_confidence(cands),
-                                          confidence_factors=conf[q] if conf is not None else None))
+                if max(boost_q) > 0:      # (an uncertainty marker in the query: the boosted hits report their reweighted score)
+                    originals = [adj_q[j] if boost_q[j] > 0 else raw_q[j] for j in range(n)]
+                else:
+                    originals = raw_q
+                if codes is not None and trusted_matches_ready():
+                    ids_q = h_ids[q] if n == kk else h_ids[q][:n]
+                    cands = bulk_candidates(codes, titles, SimilarityFactors, ids_q, enh_q, originals, h_vs[q], h_hb[q], sc, qps[q][1])
+                else:
+                    cands = trusted_candidates(recs, h_ids[q][:n], enh_q[:n], originals[:n],
+                                               trusted_factors_row(h_vs[q][:n], h_hb[q][:n], sc, qps[q][1]))
+                out.append(trusted_match(diagnosis, cands, self._match_confidence_of_scores(enh_q if n == kk else enh_q[:n]), conf[q] if conf is not None else None))
             except Exception as exc:
                 logger.error("match failed for %s: %s", diagnosis, exc)
                 out.append(DiagnosisMatch(diagnosis_text=diagnosis, candidates=[], match_confidence=0.0))
@@ -244,7 +258,13 @@ class MultiDiagnosisService:
     def _calculate_match_confidence(self, candidates: List[Candidate]) -> float:
         if not candidates:
             return 0.0
-        scores = [c.score for c in candidates]
+        return self._match_confidence_of_scores([c.score for c in candidates])
+
+    @staticmethod
+    def _match_confidence_of_scores(scores) -> float:
+        """the reference's _calculate_match_confidence (services/multi_diagnosis_service.py:276-304) on the candidates' scores"""
+        if not scores:
+            return 0.0
         best = max(scores)
         if best > 0.9:
             conf = min(best, 0.95)

@@ -150,3 +150,25 @@ def test_device_rescoring_host_inputs_equal_the_per_candidate_methods():
     assert H.row_tag("A01.003+G01*") == 0 and H.row_tag("M800000/0") == 15
     w = hs.device_weights()
     assert w == [0.20, 0.15, 0.08, 0.04, 0.03, 0.3, 0.15 * 0.3] and H().device_weights()[5] == 0.5
+
+
+def test_query_params_closed_form_fast_path_equals_the_general_path():
+    """HierarchicalSimilarityService.query_params decides the common case (no uncertainty marker, no chapter keyword) in closed
+    form: the same twelve numbers as the general path (the per-candidate methods of the reference,
+    services/hierarchical_similarity_service.py:293-328,448-473, against a live-shaped hit) on the 1 000 golden strings and the
+    edge cases"""
+    import re
+    from rag_project_icd10_amd.services.hierarchical_similarity_service import HierarchicalSimilarityService
+    hs = HierarchicalSimilarityService()
+    strings = [l.strip() for l in open(os.path.join(GOLDEN, "diagnosis_strings.txt"), encoding="utf-8") if l.strip()]
+    strings += ["", " ", "  \t", "x", "待查", "？", " 疑似 ", "肺炎待查", "高血压 糖尿病 肿瘤 感染", "Possible 肺炎?", "ABC def"]
+    fast = [hs.query_params(q) for q in strings]
+    cls = type(hs)
+    saved = cls._kw_any
+    cls._kw_any = re.compile("")          # matches everything: no string takes the closed form
+    try:
+        general = [hs.query_params(q) for q in strings]
+    finally:
+        cls._kw_any = saved
+    assert fast == general
+    assert sum(1 for p in fast if p[0] == 0.0 and not any(p[3:])) > 300   # (the closed form is a common case: half of the golden strings carry a marker)
