@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = (
 )
 # include/icd_search.h: icd_index_create flags and icd_index_set_option ids (A/B and test options of ONE index)
 CREATE_CORPUS_ON_DEVICE, CREATE_ROW_ORDER, CREATE_NO_PROBE, CREATE_NO_CENTER = 1, 2, 4, 8
-OPTIONS = {"family_order": 1, "stream_one": 2, "host_one": 3, "pacing_shift": 4, "pacing_lead": 5, "exact_narrow": 6}
+OPTIONS = {"family_order": 1, "stream_one": 2, "host_one": 3, "pacing_shift": 4, "pacing_lead": 5, "exact_narrow": 6, "wide_from": 7}
 GROUP_ROW_SHARD = 0
 GROUP_QUERY_SHARD = 1
 GROUP_ID_BYTES = 128

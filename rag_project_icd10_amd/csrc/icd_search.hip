@@ -156,6 +156,8 @@ struct icd_index {
     int opt_host_one = 3;           // ICD_OPT_HOST_ONE: a host caller's ONE query 1 = travels in the kernel arguments, 2 = completion by a polled word
     bool opt_stream_one = true;     // ICD_OPT_STREAM_ONE: one or two queries per call take the single-launch streaming kernel
     bool opt_family_order = true;   // ICD_OPT_FAMILY_ORDER: the wide-window finalize visits the queries in family order
+    int opt_wide_from = 32;         // ICD_OPT_WIDE_FROM: k above this keeps 24 candidates per coarse list instead of 16 (>= ICD_MAX_K: never). 32 since round 6:
+                                    // at k = 40 ... 64 lists of 16 left 1-5 of 10 000 queries to the exact re-search, 0.18-0.20 ms per batch (profiles/r06_k100_lists.log)
     int64_t n = 0, id_base = 0;
     int n_pad = 0;
     int dim = 0;
@@ -813,7 +815,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     const FlatPlan plan = plan_flat_tiles(mtc, ctiles_min, x->n_pad / 128 - ctiles_min, x->num_cu);
     const int ctiles = plan.ctiles;
     int pc = 0;
-    const bool wide_lists = k > 64 && x->dim == 768;
+    const bool wide_lists = k > x->opt_wide_from && x->dim == 768;
     // ---- adaptive list count of large batches -------------------------------------------------------------------------
     // The counters of the previous search sit in pinned host memory once its copy event has completed (hipEventQuery: no
     // wait). If that search was a large batch on the narrow plan and its second coarse pass had to take in a quarter of
@@ -1681,6 +1683,7 @@ int icd_index_set_option(icd_index *idx, int32_t option, int32_t value) {
     case ICD_OPT_PACING_SHIFT: x->opt_pace_shift = value > 12 ? 12 : value; break;
     case ICD_OPT_PACING_LEAD:  x->opt_pace_lead = value < 1 ? 1 : value; break;
     case ICD_OPT_EXACT_NARROW: x->opt_exact_narrow = value != 0; break;
+    case ICD_OPT_WIDE_FROM:    x->opt_wide_from = value < 0 ? 0 : value; break;
     default: return fail(ICD_ERR_INVALID, "option %d: not one of ICD_OPT_*", option);
     }
     return ICD_OK;
