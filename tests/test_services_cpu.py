@@ -336,3 +336,40 @@ def test_trusted_candidate_equals_the_validated_constructor():
     assert got[1].score == 1.1 and got[0].model_fields_set == want[0].model_fields_set
     with pytest.raises(ValidationError):
         trusted_candidates(recs, [0, 1], [0.5, -1e-9], [0.1, 0.1], fr[:2])
+
+
+def test_bulk_candidates_c_loop_equals_python_loop_equals_validated_constructor():
+    """the Candidate / SimilarityFactors objects of the batched request path (row N2; reference models/icd_models.py:56-87,
+    services/multi_diagnosis_service.py:161-175): csrc/fastobj.c builds them in one C loop - the same objects as the Python loop
+    and as the validated constructors, field for field, in model_dump() and in model_fields_set; a negative score raises the
+    validator's error either way"""
+    import random
+    import pydantic
+    from rag_project_icd10_amd.api import icd_models as M
+    from rag_project_icd10_amd.services.hierarchical_similarity_service import SimilarityFactors
+    assert M._fastobj is not None, "rag_project_icd10_amd/_fastobj.so is not built (make -C rag_project_icd10_amd/csrc)"
+    M.trusted_candidate("A00", "霍乱", 0.5, 0.5, 0.4, None)            # (the one-time layout check the bulk path relies on)
+    assert M.trusted_matches_ready()
+    rnd = random.Random(4)
+    n = 500
+    codes, titles = [f"A{i % 100:02d}.{i % 10}" for i in range(n)], [f"疾病{i}" for i in range(n)]
+    for kk in (0, 1, 10, 50):
+        ids = [rnd.randrange(n) for _ in range(kk)]
+        sc, og, vs, hb = ([rnd.random() for _ in range(kk + 3)] for _ in range(4))   # (longer than ids: only the first kk count)
+        got = M.bulk_candidates(codes, titles, SimilarityFactors, ids, sc, og, vs, hb, 0.3, 0.25)
+        saved, M._fastobj = M._fastobj, None
+        try:
+            py = M.bulk_candidates(codes, titles, SimilarityFactors, ids, sc, og, vs, hb, 0.3, 0.25)
+        finally:
+            M._fastobj = saved
+        want = [M.Candidate(code=codes[i], title=titles[i], score=sc[j], level=1, parent_code="", enhanced_score=sc[j], original_score=og[j],
+                            similarity_factors=SimilarityFactors(vs[j], hb[j], 0.0, 0.3, 0.0, 0.25)) for j, i in enumerate(ids)]
+        assert got == py == want and len(got) == kk
+        assert [c.model_dump() for c in got] == [c.model_dump() for c in want]
+        assert all(c.model_fields_set == w.model_fields_set and type(c.similarity_factors) is SimilarityFactors for c, w in zip(got, want))
+    with pytest.raises(pydantic.ValidationError):
+        M.bulk_candidates(codes, titles, SimilarityFactors, [1, 2], [0.5, -0.1], [0.5, 0.5], [0.1, 0.1], [0.1, 0.1], 0.3, 0.25)
+    with pytest.raises(pydantic.ValidationError):
+        M.bulk_candidates(codes, titles, SimilarityFactors, [1], [float("nan")], [0.5], [0.1], [0.1], 0.3, 0.25)
+    m = M.trusted_match("诊断", got, 0.5, None)
+    assert m == M.DiagnosisMatch(diagnosis_text="诊断", candidates=got, match_confidence=0.5, confidence_factors=None)
