@@ -51,9 +51,11 @@ def rows(rng, n, dim, kind):
 
 def fuzz_encoder(args):
     """--focus encoder: the small-input sentence encoder (csrc/encoder_small.hpp through icd_encoder_encode) against
-    transformers' padded fp32 forward of the same seeded BERT-base weights on the GPU: random numbers of sequences (1 ... 32) and
-    lengths (1 ... 256 packed tokens: every token bucket, sequences that straddle the 16-token tiles), mean and [CLS] pooling,
-    normalised or not, pooled rows and the last hidden state of every token; tolerance 1e-5 on unit rows."""
+    transformers' padded fp32 forward of the same seeded BERT-base weights on the GPU: random numbers of sequences (1 ... 64) and
+    lengths (1 ... 512 packed tokens: every token bucket, sequences that straddle the 16-token tiles), mean and [CLS] pooling,
+    normalised or not, pooled rows and the last hidden state of every token; tolerance 1e-5 on unit rows. Every fourth case also
+    runs a LIST of a few thousand tokens through icd_encoder_encode_many (the batch form, csrc/encoder_big.hpp) with the case's
+    sequences scattered in it: their rows must be bit for bit what the small-input form gave them."""
     import torch
     os.environ.setdefault("EMBEDDING_MODEL_NAME", "shibing624/text2vec-base-chinese")
     from rag_project_icd10_amd.services.embedding_service import EmbeddingService
@@ -64,8 +66,8 @@ def fuzz_encoder(args):
     vocab = es.model.bert.config.vocab_size
     bad, t0 = 0, time.time()
     for case in range(args.cases):
-        nseq = int(rng.choice([1, 1, 1, 2, 3, 5, 8, 13, 32]))
-        budget = int(rng.choice([16, 17, 32, 33, 64, 100, 128, 129, 200, 256]))
+        nseq = int(rng.choice([1, 1, 1, 2, 3, 5, 8, 13, 32, 47, 64]))
+        budget = int(rng.choice([16, 17, 32, 33, 64, 100, 128, 129, 200, 256, 257, 400, 512]))
         budget = max(budget, nseq)
         cuts = np.sort(rng.choice(np.arange(1, budget), size=nseq - 1, replace=False)) if nseq > 1 else np.array([], dtype=np.int64)
         lengths = np.diff(np.concatenate([[0], cuts, [budget]])).astype(int).tolist()
@@ -88,6 +90,21 @@ def fuzz_encoder(args):
         d1, d2 = float(np.max(np.abs(got - want))), float(np.max(np.abs(rows_.cpu().numpy() - want_rows)))
         again = enc.encode(ids, pooling=pooling, normalize=True)
         ok = d1 <= 1e-5 and d2 <= 5e-5 and np.array_equal(again, got)
+        if case % 4 == 0:   # the batch form: the case's sequences scattered among fillers, 1 000 ... 20 000 tokens in all
+            nfill = int(rng.choice([40, 300, 1200]))
+            fill = [[int(v) for v in rng.integers(1000, vocab, size=int(n))] for n in rng.integers(1, 40, nfill)]
+            where = np.sort(rng.choice(np.arange(nfill + nseq), size=nseq, replace=False))
+            mixed, it, k_ = [], iter(fill), 0
+            for pos in range(nfill + nseq):
+                if k_ < nseq and pos == where[k_]:
+                    mixed.append(ids[k_]); k_ += 1
+                else:
+                    mixed.append(next(it))
+            many = enc.encode_many(mixed, pooling=pooling, normalize=True)
+            same = np.array_equal(many[where], got)
+            if not same:
+                print(f"FAIL case {case}: the batch form differs from the small-input form (lengths {lengths}, {nfill} fillers)", flush=True)
+            ok = ok and same
         if not ok:
             bad += 1
             print(f"FAIL case {case}: lengths {lengths} pooling {pooling}: max |d pooled| {d1:.2e}, max |d hidden| {d2:.2e}, replay equal {np.array_equal(again, got)}", flush=True)

@@ -365,6 +365,16 @@ def test_batch_rows_equal_one_string_per_call_bit_for_bit(services):
     many = enc.encode_many(ids, pooling="mean", normalize=True)
     for i in range(len(ids)):
         assert np.array_equal(many[i], enc.encode([ids[i]])[0]), (i, lengths[i])
+    # passes cut by the SEQUENCE limit (2 048 per pass) and a list that ends exactly on a pass's token limit
+    tiny_lengths = [int(x) for x in rng.integers(1, 5, 4500)]
+    tiny = [[int(v) for v in rng.integers(1000, vocab, size=n)] for n in tiny_lengths]
+    tiny_out = enc.encode_many(tiny)
+    for i in (0, 1, 2047, 2048, 2049, 4095, 4096, 4499):
+        assert np.array_equal(tiny_out[i], enc.encode([tiny[i]])[0]), (i, tiny_lengths[i])
+    full = [[int(v) for v in rng.integers(1000, vocab, size=128)] for _ in range(64 + 3)]          # 64 x 128 = 8 192 tokens, then 3 more
+    full_out = enc.encode_many(full)
+    for i in (0, 63, 64, 66):
+        assert np.array_equal(full_out[i], enc.encode([full[i]])[0]), i
     many_cls = enc.encode_many(ids[:40], pooling="cls", normalize=False)
     assert np.array_equal(many_cls, np.concatenate([enc.encode([x], pooling="cls", normalize=False) for x in ids[:40]]))
     from rag_project_icd10_amd import _native
