@@ -9,9 +9,16 @@ starts with "query:" / "passage:".
 The arithmetic the reference delegates to sentence-transformers (un-vendored; `>=4.1.0`,
 requirements.txt:7) is restated on PyTorch-ROCm: BERT encoder forward -> mean pooling over the
 attention mask -> L2 normalisation -> float32 (the published SentenceTransformer.encode contract with
-normalize_embeddings=True). Differences by design: texts are really batched and length-bucketed, and
-batches can stay on the GPU (`encode_query_batch(..., to_device=True)`) so the search kernel reads
-them without a host round trip.
+normalize_embeddings=True). Differences by design: texts are really batched, and batches can stay on the
+GPU (`encode_query_batch(..., to_device=True)`) so the search kernel reads them without a host round trip.
+
+ONE arithmetic whatever the call shape (round 6): the reference embeds corpus rows and queries through the same one-string
+call (tools/build_database.py:217-222 is a loop of encode_query) - identical text, identical vector. Here one string per call
+runs the hand-written fp32 forward of csrc/encoder_small.hpp, and any batch the SAME arithmetic in large tiles
+(csrc/encoder_big.hpp, icd_encoder_encode_many): row i of a batch is bit for bit encode_query of string i. The packed
+split-bf16 forward on PyTorch (_PackedBert: 2.4 x the throughput, vectors ~1.2e-6 off, near-tied hits may swap) is opt-in:
+ICD_EMBEDDING_BATCH=fast or fast=True; models the hand-written encoder is not instantiated for keep the framework's forward
+(get_model_info()["batch_arithmetic"] says which).
 
 Weights: `EMBEDDING_MODEL_NAME` is resolved locally only (no network in this deployment). If it
 cannot be resolved the constructor raises, exactly like the reference does on a failed model load

@@ -5,8 +5,10 @@ Drop-in for the reference's tools/build_database.py (same class, methods and CLI
 semantics follow :62-126 (load_csv_data), :128-154 (_parse_hierarchy), :156-171 (_build_semantic_text),
 :183-192 (batch-size rule) and are pinned by tests/golden/csv_records.json and csv_full_digest.json
 (outputs of the reference itself). Difference by design: the reference runs one
-batch-1 forward per record; here each insert batch is encoded in ONE bucketed forward on the GPU
-(`encode_query_batch`) - same text ("query: " + semantic_text, :220-221), same rows, same order.
+batch-1 forward per record; here 2 048 records at a time go through `encode_query_batch` - same text ("query: " +
+semantic_text, :220-221), same rows, same order, and (round 6) the SAME VECTORS: the batch form of the encoder runs the
+one-string call's arithmetic in large tiles (csrc/encoder_big.hpp), so a stored row is bit for bit encode_query of its text,
+as in the reference, whose build IS a loop of encode_query (:217-222).
 
     python -m rag_project_icd10_amd.tools.build_database --input data/ICD_10v601.csv [--rebuild] [--verify-only]
 """
