@@ -627,7 +627,7 @@ def two_streams_extra(ctx, args, index_factory, corpus, levels, queries, k, step
     them, so that one step's finalize (gather- and latency-bound, no MFMA) and its gated launches run under the next step's coarse
     sweep. What a server with back-to-back batches can do with the C ABI as it is (one stream per handle); never the headline:
     `value` times the steps one after the other on one stream. VERDICT r5 asked for this overlap INSIDE one step (two half
-    batches): measured slower (profiles/r06_two_streams_overlap.log: +3 % on one stream, +6 % on two - a 5 000-query sweep
+    batches): measured slower (profiles/r06_two_streams_overlap.log: +8 % on one stream and on two - a 5 000-query sweep
     reloads its queries twice as often, and finalize cannot share a CU with the coarse kernel's 452 registers per lane)."""
     from rag_project_icd10_amd._native import MODE_AUTO
     torch = ctx.torch
@@ -923,6 +923,8 @@ def native_group_trial(ctx, index, queries, sl, k, ref_outs, limit_s, steps=1):
 
     def body():
         try:
+            if not ctx.cpu_only:
+                torch.cuda.set_device(ctx.dev)   # (a new thread starts on device 0: the barrier and the reductions of ctx.timed below must run on this rank's device)
             sh = ShardedSearch.from_index(index, ROW_SHARD, native=True)
             if sh.native_group is None:
                 res["status"] = "not opened: the ranks agreed on the torch.distributed engine (see the warning on stderr)"
