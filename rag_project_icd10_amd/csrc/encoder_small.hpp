@@ -406,10 +406,9 @@ template <bool SINGLE, typename M = EncMetaSmall>
 __global__ __launch_bounds__(256) void enc_attention_kernel(EncAttnArgs a) {
     constexpr int CH = 32;
     const int lane = threadIdx.x & 63;
-    // (the wave's task, its sequence's first row and length are wave-UNIFORM: said so explicitly - readfirstlane - every row
-    //  offset below is scalar arithmetic and the key / value loads take a scalar base; left to the compiler they were 64-bit
-    //  vector multiplies, ~60 of a key's ~200 cycles in the batch form, where this kernel is bound by its VALU work)
-    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    // (measured and NOT kept, round 6: task / first row / length forced wave-uniform with readfirstlane, so that the row offsets
+    //  become scalar arithmetic instead of 64-bit vector multiplies - the batch form's launch went 203 -> 245 us per layer)
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int t = task / a.heads, h = task - t * a.heads;
     if (t >= M::T_MAX) return;
     const size_t ld = 3 * (size_t)a.H;
@@ -419,11 +418,11 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(EncAttnArgs a) {
         const float *kb0 = a.qkv + a.H + (size_t)h * ATT_HEAD_DIM + lane;
 #pragma unroll
         for (int j = 0; j < CH; ++j) { kreg[j] = kb0[(size_t)j * ld]; vreg[j] = kb0[(size_t)j * ld + a.H]; }
-        L = __builtin_amdgcn_readfirstlane(a.meta[0]);
+        L = a.meta[0];
         if (t >= L) return;
     } else {
-        r0 = __builtin_amdgcn_readfirstlane(a.meta[M::TOK_R0 + t]);
-        L = __builtin_amdgcn_readfirstlane(a.meta[M::TOK_LEN + t]);   // (0 past the call's tokens)
+        r0 = a.meta[M::TOK_R0 + t];
+        L = a.meta[M::TOK_LEN + t];   // (0 past the call's tokens)
         if (L <= 0) return;   // wave-uniform, no barriers below
     }
     const float q = a.qkv[(size_t)t * ld + (size_t)h * ATT_HEAD_DIM + lane] * a.scale;
