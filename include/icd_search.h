@@ -320,7 +320,7 @@ int icd_index_set_second_pass(icd_index *idx, int32_t enabled);
  *                             work-group per CU) instead of certified lists of 32 over row-strided chunks with a re-search of
  *                             the queries the certificate cannot clear (k range: /query searches top_k * 2 with top_k <= 50,
  *                             models/icd_models.py:138, services/multi_diagnosis_service.py:153).
- *   ICD_OPT_WIDE_FROM   [32]  searches with k above this keep 24 candidates per coarse list (about k / 6 lists per query) instead of
+ *   ICD_OPT_WIDE_FROM   [48]  searches with k above this keep 24 candidates per coarse list (about k / 6 lists per query) instead of
  *                             16 (about k / 4 lists): a slower sweep, but no query whose top-k crowd one list is left for the
  *                             exact re-search (profiles/r06_k100_lists.log). >= ICD_MAX_K: lists of 16 at every k.
  * No reference counterpart (the reference delegates the search to Milvus Lite). */

@@ -156,8 +156,10 @@ struct icd_index {
     int opt_host_one = 3;           // ICD_OPT_HOST_ONE: a host caller's ONE query 1 = travels in the kernel arguments, 2 = completion by a polled word
     bool opt_stream_one = true;     // ICD_OPT_STREAM_ONE: one or two queries per call take the single-launch streaming kernel
     bool opt_family_order = true;   // ICD_OPT_FAMILY_ORDER: the wide-window finalize visits the queries in family order
-    int opt_wide_from = 32;         // ICD_OPT_WIDE_FROM: k above this keeps 24 candidates per coarse list instead of 16 (>= ICD_MAX_K: never). 32 since round 6:
-                                    // at k = 40 ... 64 lists of 16 left 1-5 of 10 000 queries to the exact re-search, 0.18-0.20 ms per batch (profiles/r06_k100_lists.log)
+    int opt_wide_from = 48;         // ICD_OPT_WIDE_FROM: k above this keeps 24 candidates per coarse list instead of 16 (>= ICD_MAX_K: never). 64 until round 5.
+                                    // Lists of 16 leave 1-5 of 10 000 queries to the exact re-search at k = 40 ... 64: 0.18-0.20 ms per batch while the streaming
+                                    // re-search started its lists at -inf, 0.06-0.07 since it takes finalize's threshold (round 6). With that the two list
+                                    // widths meet at k = 50 ... 64 and 16 wins below (profiles/r06_k100_lists.log)
     int64_t n = 0, id_base = 0;
     int n_pad = 0;
     int dim = 0;
@@ -419,7 +421,7 @@ inline bool stream_fits(int kp, int qb, int dim) {
 
 template <int KP, int E, int QB>
 int launch_stream(icd_index *x, const float *dq, const int *qlist, const int *nq_ptr, int nq, int max_active,
-                  int p_out, int *p_used, hipStream_t s) {
+                  int p_out, int *p_used, hipStream_t s, const float *thr0 = nullptr) {
     const int n = (int)x->n;
     const int per_max = FIN_MAX_CAND / KP;                       // lists one reduce wave can merge
     const int p_cap = FIN_MAX_CAND / KP;                         // lists finalize<false> can merge
@@ -434,7 +436,7 @@ int launch_stream(icd_index *x, const float *dq, const int *qlist, const int *nq
     StreamArgs a{};
     a.corpus = x->corpus; a.queries = dq; a.qlist = qlist; a.nq_ptr = nq_ptr; a.nq = std::min(nq, max_active);
     a.max_active = max_active; a.n = n; a.dim = x->dim; a.rows_per_wg = rows_per_wg; a.nwg = nwg;
-    a.list_scores = x->lists_s; a.list_rows = x->lists_r;
+    a.list_scores = x->lists_s; a.list_rows = x->lists_r; a.thr0 = thr0;
     // wave-private LDS ring: as many 8-KB stages per wave as fit next to the queries and candidate buffers
     int stages = 4;
     while (stages > 2 && stream_lds_bytes<KP, E, QB>(x->dim, stages) > (size_t)LDS_LIMIT) --stages;
@@ -616,15 +618,15 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
     // (the first reduction level leaves at most 512 lists per slot in the second workspace)
     const int sparse_max = (int)std::min<size_t>(std::min<size_t>(ST_FALLBACK_MAX_ACTIVE, x->lists_cap / ((size_t)1024 * kpx)),
                                                  kpx == 16 ? (size_t)ST_FALLBACK_MAX_ACTIVE : x->partx_cap / ((size_t)512 * kpx));
-    auto run_stream = [&](const int *qlist, const int *nq_ptr, int nqs, int p_out, int *p_used) -> int {
+    auto run_stream = [&](const int *qlist, const int *nq_ptr, int nqs, int p_out, int *p_used, const float *thr0 = nullptr) -> int {
         int qb = nq_ptr ? 8 : (nqs <= 1 ? 1 : (nqs <= 2 ? 2 : (nqs <= 4 ? 4 : 8)));
         const int max_act = nq_ptr ? sparse_max : std::max(sparse_max, nqs);   // (a direct call - up to ST_MAX_ACTIVE queries - is not gated)
         while (qb > 1 && !stream_fits(kpx, qb, x->dim)) qb >>= 1;
 #define ICD_ST(KPV, EV) \
-        (qb == 1 ? launch_stream<KPV, EV, 1>(x, dq, qlist, nq_ptr, nqs, max_act, p_out, p_used, s) : \
-         qb == 2 ? launch_stream<KPV, EV, 2>(x, dq, qlist, nq_ptr, nqs, max_act, p_out, p_used, s) : \
-         qb == 4 ? launch_stream<KPV, EV, 4>(x, dq, qlist, nq_ptr, nqs, max_act, p_out, p_used, s) : \
-                   launch_stream<KPV, EV, 8>(x, dq, qlist, nq_ptr, nqs, max_act, p_out, p_used, s))
+        (qb == 1 ? launch_stream<KPV, EV, 1>(x, dq, qlist, nq_ptr, nqs, max_act, p_out, p_used, s, thr0) : \
+         qb == 2 ? launch_stream<KPV, EV, 2>(x, dq, qlist, nq_ptr, nqs, max_act, p_out, p_used, s, thr0) : \
+         qb == 4 ? launch_stream<KPV, EV, 4>(x, dq, qlist, nq_ptr, nqs, max_act, p_out, p_used, s, thr0) : \
+                   launch_stream<KPV, EV, 8>(x, dq, qlist, nq_ptr, nqs, max_act, p_out, p_used, s, thr0))
         if (kpx == 16) return ICD_ST(16, 2);
         if (kpx == 32) return ICD_ST(32, 2);
         if (kpx == 64) return ICD_ST(64, 3);
@@ -641,7 +643,7 @@ int search_device(icd_index *x, const float *dq, int nq, int k, int mode, const 
         int rc = ICD_OK;
         if (stream && stream_launch) {
             int used = px;
-            rc = run_stream(qlist, nq_ptr, nq, mfma ? px : 0, &used);   // alone: fewest output lists
+            rc = run_stream(qlist, nq_ptr, nq, mfma ? px : 0, &used, thr0);   // alone: fewest output lists
             if (rc) return rc;
             px = used;
             if (!nq_ptr) x->last_chunks = px;

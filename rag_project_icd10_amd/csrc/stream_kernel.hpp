@@ -56,6 +56,10 @@ struct StreamArgs {
     int ring_stages;      // 2..4 wave-private LDS stages
     float *list_scores;   // [slot][4 * nwg][KP]
     int *list_rows;
+    const float *thr0;    // nullable: [query] a score that k distinct rows are known to reach (finalize.hpp: an uncertified query's k best
+                          // coarse candidates, rescored) - the query's lists start there instead of at -inf (ties pass). Without it a
+                          // re-search at k > 32 kept EVERY row (a wave sees 64 rows per step, its list holds KP >= 64) and the list
+                          // reduction ranked the whole corpus per query: 0.15-0.25 ms for one to five queries (profiles/r06_k100_lists.log)
     // ONE = true only
     int rows_per_step;    // rows a wave takes per step (multiple of 8, <= 64); rows_per_wg is a multiple of 4 * rows_per_step
     u64 *wg_keys;         // [slot][nwg][KP] one merged best-first list per work-group (keys, 0 = empty)
@@ -190,7 +194,14 @@ __device__ __forceinline__ void stream_topk_body(const StreamArgs &a, const floa
         uint32_t thr_row[QB];
         int cnt[QB];
 #pragma unroll
-        for (int qi = 0; qi < QB; ++qi) { thr[qi] = -INFINITY; thr_row[qi] = 0u; cnt[qi] = 0; }
+        for (int qi = 0; qi < QB; ++qi) {
+            thr[qi] = -INFINITY; thr_row[qi] = 0u; cnt[qi] = 0;
+            if (a.thr0) {
+                const int slot = q0 + min(qi, nqp - 1);
+                const float t0 = a.thr0[a.qlist ? a.qlist[slot] : slot];
+                if (t0 > -INFINITY) { thr[qi] = t0; thr_row[qi] = 0xFFFFFFFFu; }   // (rows that tie with it pass)
+            }
+        }
 
         // stage cursor of the DMA stream: (step, slice) -> ring slot; runs D - 1 stages ahead of the reader.
         // Past the last stage it re-reads the last step (valid memory, never consumed).
