@@ -978,7 +978,7 @@ def exact_merge_torch(torch, scores, ids, k):
     return torch.gather(s, 1, o2)[:, :k].to(torch.float32), torch.gather(i, 1, o2)[:, :k]
 
 
-def run_rowshard(ctx, args, index_factory=hip_index_factory, sharded_factory=None):
+def run_rowshard(ctx, args, index_factory=hip_index_factory, sharded_factory=None, native_trial=None):
     """BASELINE configs[4]: the corpus row-sharded over the ranks (1.25 M rows per GPU), the query batch replicated"""
     from rag_project_icd10_amd.sharded import ROW_SHARD, ShardedSearch
     torch, dist = ctx.torch, ctx.dist
@@ -1056,12 +1056,16 @@ def run_rowshard(ctx, args, index_factory=hip_index_factory, sharded_factory=Non
         adj_ok = adj_ok and bool(np.array_equal(l0[mine], levels_host[i0[mine]]))
     stats = index.stats() if hasattr(index, "stats") else {}
     trial = None
-    if ctx.world > 1 and sharded_factory is None and getattr(sharded, "native_group", None) is None and not args.no_native_trial:
+    if ctx.world > 1 and native_trial is not None and not args.no_native_trial:   # (the CPU test engine's stand-in: the adoption logic below on gloo ranks)
+        trial = native_trial(ctx, index, queries, sl, k, outs, args.native_trial_limit, steps)
+    elif ctx.world > 1 and sharded_factory is None and getattr(sharded, "native_group", None) is None and not args.no_native_trial:
         trial = native_group_trial(ctx, index, queries, sl, k, outs, args.native_trial_limit, steps)
     # the C-ABI group becomes the leg's engine when its trial passed on EVERY rank: opened, every slice bit-identical to the torch
     # engine's, the timed passes finished (the ranks agree over the CPU side channel: a rank-0-only decision would be a lie)
     trial_ok = bool(trial) and trial.get("status") == "ok" and bool(trial.get("equals_torch_engine"))
     native_default = ctx.world > 1 and trial is not None and not ctx.any_rank(not trial_ok)
+    if trial is not None:
+        trial["adopted_as_the_legs_engine"] = bool(native_default)   # (false with status ok here: another rank's trial did not pass)
     line = None
     if ctx.rank == 0:
         flops_gpu = 2.0 * nq * n * dim
@@ -1119,7 +1123,7 @@ def test_engine():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     out = {"index_factory": mod.index_factory, "sharded_factory": mod.sharded_factory}
-    for hook in ("on_start", "on_exit"):
+    for hook in ("on_start", "on_exit", "native_trial"):
         if hasattr(mod, hook):
             out[hook] = getattr(mod, hook)
     return out
@@ -1297,8 +1301,11 @@ def main(argv=None):
     on_exit = eng.pop("on_exit", None)
     if "on_start" in eng:   # (the CPU test engine's fault injection: a rank that dies / never returns; nothing of the kind lives here)
         eng.pop("on_start")(ctx)
+    rs_eng = dict(eng)
+    if "native_trial" in eng:
+        eng = {k: v for k, v in eng.items() if k != "native_trial"}
     if args.workload == "rowshard":
-        line = run_rowshard(ctx, args, **eng)
+        line = run_rowshard(ctx, args, **rs_eng)
     else:
         line = run_replicated(ctx, args, **({"index_factory": eng["index_factory"]} if eng else {}))
         if ctx.world > 1 and not args.no_config3:
@@ -1306,7 +1313,7 @@ def main(argv=None):
             if line is not None:
                 line["config3"] = c3
         if ctx.world > 1 and not args.no_rowshard:
-            rs = run_rowshard(ctx, args, **eng)
+            rs = run_rowshard(ctx, args, **rs_eng)
             if line is not None:
                 line["rowshard"] = rs
     if ctx.rank == 0:

@@ -99,3 +99,18 @@ def on_exit(ctx):
     import time
     if os.environ.get("ICD_BENCH_TEST_HANG_AT_EXIT_RANK") == str(ctx.rank):
         time.sleep(10 ** 6)
+
+
+def native_trial(ctx, index, queries, sl, k, ref_outs, limit_s, steps=1):
+    """stand-in for bench.native_group_trial on gloo ranks (ICD_BENCH_TEST_NATIVE_TRIAL): what the C-ABI group's trial would report,
+    so that run_rowshard's ADOPTION logic - every rank must have passed, agreed over the side channel - runs on the CPU.
+    "ok": every rank passes; "rank1_differs": rank 1's output differed from the torch engine's; unset: no trial (None)."""
+    mode = os.environ.get("ICD_BENCH_TEST_NATIVE_TRIAL")
+    if not mode:
+        return None
+    nq = int(queries.shape[0])
+    res = {"status": "ok", "equals_torch_engine": True, "slices_compared": len(ref_outs), "steps": int(steps), "ms_per_step": 2.0,
+           "value": nq * 1000.0 / 2.0, "ms_per_slice": 2.0 / max(1, len(ref_outs)), "slice": int(min(sl, nq))}
+    if mode == "rank1_differs" and ctx.rank == 1:
+        res["equals_torch_engine"] = False
+    return res

@@ -257,3 +257,22 @@ def test_visible_gpus_counts_without_touching_the_runtime(monkeypatch, tmp_path)
     monkeypatch.setattr(_os, "listdir", lambda p: real_listdir(str(base)) if p == "/sys/class/kfd/kfd/topology/nodes" else real_listdir(p))
     monkeypatch.setattr(builtins, "open", lambda p, *a, **k: real_open(str(p).replace("/sys/class/kfd/kfd/topology/nodes", str(base)), *a, **k))
     assert bench.visible_gpus() == 2
+
+
+def test_bench_adopts_the_c_abi_group_only_when_every_ranks_trial_passed():
+    """round 6: the row-sharded leg reports the C-ABI group's number (config.engine says so, the torch engine's stays next to it)
+    when the trial passed on EVERY rank - agreed over the CPU side channel; one rank whose output differed keeps all of them on
+    the torch.distributed number. The trial itself is the test engine's stand-in (tests/bench_cpu_engine.py native_trial)."""
+    p = _run_bench(["--gpus", "2", "--no-config3", "--rank-timeout", "200"], {"ICD_BENCH_TEST_NATIVE_TRIAL": "ok"}, timeout=400)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rs = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])["rowshard"]
+    assert rs["config"]["engine"] == "icd_group (C ABI)" and "icd_group_search" in rs["config"]["collective"]
+    assert rs["native_group_trial"]["status"] == "ok" and rs["native_group_trial"]["adopted_as_the_legs_engine"] is True
+    assert rs["value"] == rs["native_group_trial"]["value"] and rs["ms_per_step"] == 2.0
+    assert rs["torch_distributed_engine"]["value"] > 0 and rs["ids_exact_on_sample"]
+    p = _run_bench(["--gpus", "2", "--no-config3", "--rank-timeout", "200"], {"ICD_BENCH_TEST_NATIVE_TRIAL": "rank1_differs"}, timeout=400)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rs = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])["rowshard"]
+    assert rs["config"]["engine"] == "torch.distributed" and rs["torch_distributed_engine"] is None
+    assert rs["native_group_trial"]["status"] == "ok" and rs["native_group_trial"]["adopted_as_the_legs_engine"] is False   # (rank 0's own trial passed; rank 1's did not)
+    assert rs["value"] != rs["native_group_trial"]["value"] and rs["ids_exact_on_sample"]
