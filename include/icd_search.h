@@ -360,7 +360,12 @@ typedef struct {
     const float *const *w_up;   const float *const *b_up;     /* intermediate dense [inter][hidden] */
     const float *const *w_down; const float *const *b_down;   /* output dense [hidden][inter] */
     const float *const *ln2_g;  const float *const *ln2_b;
+    int32_t arithmetic;                     /* of the four Linear layers' GEMMs, in BOTH forms (one call / icd_encoder_encode_many) alike:
+                                               ICD_ENCODER_ARITH_FP32 (0) fp32-input MFMA, exact products; ICD_ENCODER_ARITH_BF16X3 (1) the
+                                               split-bf16 form - x = x_hi + x_lo, w = w_hi + w_lo in bf16, three bf16 MFMAs per 32 k-values
+                                               (hi hi, hi lo, lo hi) into fp32: 1 / 5 of the matrix time, ~1e-6 off the fp32 forward */
 } icd_encoder_desc;
+enum { ICD_ENCODER_ARITH_FP32 = 0, ICD_ENCODER_ARITH_BF16X3 = 1 };
 #define ICD_ENCODER_MAX_TOKENS 512   /* packed tokens per call: any ONE sequence a BERT-style encoder takes fits */
 #define ICD_ENCODER_MAX_SEQS 64      /* sequences per call */
 int icd_encoder_create(int32_t device, const icd_encoder_desc *desc, icd_encoder **out);

@@ -68,9 +68,10 @@ class _EncoderDesc(C.Structure):   # include/icd_search.h icd_encoder_desc
     _fields_ = ([("layers", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32), ("inter", C.c_int32), ("vocab", C.c_int32),
                  ("max_pos", C.c_int32), ("pos_offset", C.c_int32), ("ln_eps", C.c_float),
                  ("word_emb", C.c_void_p), ("pos_emb", C.c_void_p), ("type_emb0", C.c_void_p), ("emb_ln_g", C.c_void_p), ("emb_ln_b", C.c_void_p)]
-                + [(name, C.POINTER(C.c_void_p)) for name in _ENC_LAYER_FIELDS])
+                + [(name, C.POINTER(C.c_void_p)) for name in _ENC_LAYER_FIELDS] + [("arithmetic", C.c_int32)])
 
 
+ENCODER_ARITH = {"fp32": 0, "bf16x3": 1}   # include/icd_search.h ICD_ENCODER_ARITH_*
 ENCODER_MAX_TOKENS = 512   # include/icd_search.h ICD_ENCODER_MAX_TOKENS
 ENCODER_MAX_SEQS = 64      # ... ICD_ENCODER_MAX_SEQS
 
@@ -593,9 +594,14 @@ class SmallEncoder:
         except Exception:
             return False
 
-    def __init__(self, bert):
+    def __init__(self, bert, arithmetic: Optional[str] = None):
+        """arithmetic: "bf16x3" (the default; env ICD_ENCODER_ARITH) = the split-bf16 GEMMs, "fp32" = fp32-input MFMAs - of BOTH
+        forms (encode / encode_many) alike: whichever it is, a list's rows equal the one-string call's bit for bit"""
         import torch
         self._lib = load_library()
+        self.arithmetic = (arithmetic or os.environ.get("ICD_ENCODER_ARITH", "bf16x3")).strip().lower()
+        if self.arithmetic not in ENCODER_ARITH:
+            raise ValueError(f"encoder arithmetic {self.arithmetic!r}: one of {sorted(ENCODER_ARITH)}")
         cfg = bert.config
         emb = bert.embeddings
         self.hidden = int(cfg.hidden_size)
@@ -614,6 +620,7 @@ class SmallEncoder:
         d.vocab, d.max_pos = int(emb.word_embeddings.weight.shape[0]), int(emb.position_embeddings.weight.shape[0])
         d.pos_offset = int(emb.padding_idx) + 1 if type(bert).__name__ != "BertModel" else 0
         d.ln_eps = float(cfg.layer_norm_eps)
+        d.arithmetic = ENCODER_ARITH[self.arithmetic]
         d.word_emb, d.pos_emb = ptr(emb.word_embeddings.weight), ptr(emb.position_embeddings.weight)
         d.type_emb0 = ptr(emb.token_type_embeddings.weight[0])
         d.emb_ln_g, d.emb_ln_b = ptr(emb.LayerNorm.weight), ptr(emb.LayerNorm.bias)

@@ -77,7 +77,11 @@ struct EncBigLinearArgs {
 // 16 columns per wave; EPI / LNPRO / OUT_PA: as enc_linear_kernel; SLICES: K slices of `pps` pieces each whose sums the small
 // form keeps in slabs (1, or ENC_SLABS = 4: the FFN-down GEMM)
 // PF: pairs of k-steps in flight ahead of the MFMAs (1: a double buffer, 2: three buffers - where ITER / 2 is a multiple of three)
-template <int ITER, int TM, int TN, int EPI, bool LNPRO, bool OUT_PA, int SLICES, int PF = 1>
+// BF: the split-bf16 arithmetic (encoder_small.hpp: three bf16 MFMAs per 32-block = per pair of k-steps; w holds w_hi / w_lo)
+// (measured and NOT kept, round 6: the W fragments of a pair through LDS - each wave loads a quarter, all four read all of them
+//  back, one barrier per pair: 394 against 228 us for the FFN-down GEMM; the four waves share their W fragments through the L1
+//  well enough, and the barrier puts the LDS round trip on every pair's critical path: profiles/r06_encoder_big_bf_sweep.log)
+template <int ITER, int TM, int TN, int EPI, bool LNPRO, bool OUT_PA, int SLICES, int PF = 1, bool BF = false>
 __global__ __launch_bounds__(256) void enc_linear_big_kernel(EncBigLinearArgs a) {
     extern __shared__ char enc_big_occupancy_pin[];   // (never touched: the launch asks for more than half a CU's LDS so that a CU holds ONE work-group - see icd_encoder.hpp)
     constexpr int KW = 16 * ITER;
@@ -151,6 +155,21 @@ __global__ __launch_bounds__(256) void enc_linear_big_kernel(EncBigLinearArgs a)
                     if (pz < NPIECE) load_pair((st + PF) % NBUF, pz, sz);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (BF) {
+                    // this pair of k-steps IS a 32-block (block st of the piece: even ones into c0, odd ones into c1, as in the small
+                    // form); its A fragments are split once and meet every column tile; term by term over ALL tiles
+                    enc_bf16x8 ah[TM], al[TM];
+#pragma unroll
+                    for (int m = 0; m < TM; ++m) enc_split8(abuf[st % NBUF][0][m], abuf[st % NBUF][1][m], ah[m], al[m]);
+#define ENC_BIG_BF(AOP, BSLOT)                                                                                             \
+                    _Pragma("unroll") for (int m = 0; m < TM; ++m)                                                         \
+                        _Pragma("unroll") for (int n = 0; n < TN; ++n) {                                                   \
+                            if ((st & 1) == 0) c0[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AOP[m], enc_as_bf16x8(bbuf[st % NBUF][BSLOT][n]), c0[m][n], 0, 0, 0); \
+                            else c1[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AOP[m], enc_as_bf16x8(bbuf[st % NBUF][BSLOT][n]), c1[m][n], 0, 0, 0); \
+                        }
+                    ENC_BIG_BF(ah, 0) ENC_BIG_BF(ah, 1) ENC_BIG_BF(al, 0)
+#undef ENC_BIG_BF
+                } else {
                 // (component by component over ALL tiles: consecutive MFMAs never touch the same accumulator)
 #define ENC_BIG_MFMA(C)                                                                                                   \
                 _Pragma("unroll") for (int m = 0; m < TM; ++m)                                                            \
@@ -160,6 +179,7 @@ __global__ __launch_bounds__(256) void enc_linear_big_kernel(EncBigLinearArgs a)
                     }
                 ENC_BIG_MFMA(x) ENC_BIG_MFMA(y) ENC_BIG_MFMA(z) ENC_BIG_MFMA(w)
 #undef ENC_BIG_MFMA
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             // the piece's sum joins the slice's: s += (c0 + c1), in piece order (the small form: s = 0; for w: s += red[w])

@@ -92,6 +92,45 @@ __global__ __launch_bounds__(256) void enc_permute_w_kernel(const float *src, co
     }
     *reinterpret_cast<float4 *>(dst + enc_pw(n, k, K, NT, KW)) = v;
 }
+// ---- the split-bf16 arithmetic (ENC_ARITH_BF16X3) ------------------------------------------------------------------------------
+// The fp32-input MFMA runs at 1 / 16 of the bf16 rate. With x = x_hi + x_lo and w = w_hi + w_lo in bf16 (x_lo = bf16(x - x_hi): 16
+// mantissa bits each way) a block of 32 k-values is THREE v_mfma_f32_16x16x32_bf16 into one fp32 accumulator, in this order:
+//   x_hi w_hi, x_hi w_lo, x_lo w_hi          (the dropped x_lo w_lo is 2^-18 relative; products exact in fp32, fp32 accumulation)
+// - 48 cycles of the matrix pipe where eight fp32 MFMAs take 256. Weights are split ONCE (enc_permute_w_bf16_kernel), activations
+// in registers on their way into the MFMA (enc_split8: the same function in both forms of the GEMM - same bits). The operand
+// ORDER is the fp32 form's: the lane's two 16-byte slots of a 32-block hold k = 32 b + 4 kq + c and 32 b + 16 + 4 kq + c (c = 0 .. 3);
+// the MFMA's eight slots per lane take them in that order for A and B alike (which k sits in which slot does not matter to a dot
+// product as long as both operands agree). For W the two slots hold the block's eight w_hi and its eight w_lo.
+typedef __bf16 enc_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void enc_split8(const float4 &p, const float4 &q, enc_bf16x8 &hi, enc_bf16x8 &lo) {
+#pragma clang fp contract(off)
+    const float v[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h = (__bf16)v[e];            // round to nearest even
+        hi[e] = h;
+        lo[e] = (__bf16)(v[e] - (float)h);
+    }
+}
+__device__ __forceinline__ enc_bf16x8 enc_as_bf16x8(const float4 &v) { return __builtin_bit_cast(enc_bf16x8, v); }
+// one-time: a Linear weight [N][K] row-major (columns optionally scaled: W' = W diag(g)) -> per (row, 32-block, kq) the eight w_hi
+// in the slot of k-step 2 b and the eight w_lo in the slot of k-step 2 b + 1 of the NT-row-tile order; one thread per (n, b, kq)
+__global__ __launch_bounds__(256) void enc_permute_w_bf16_kernel(const float *src, const float *colscale, float *dst, int N, int K, int NT, int KW) {
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= (size_t)N * K / 8) return;
+    const int n = (int)(g / (K / 8)), r = (int)(g % (K / 8)), b = r >> 2, kq = r & 3;
+    const int k0 = 32 * b + 4 * kq;
+    float4 p = *reinterpret_cast<const float4 *>(src + (size_t)n * K + k0), q = *reinterpret_cast<const float4 *>(src + (size_t)n * K + k0 + 16);
+    if (colscale) {
+        const float4 s0 = *reinterpret_cast<const float4 *>(colscale + k0), s1 = *reinterpret_cast<const float4 *>(colscale + k0 + 16);
+        p.x *= s0.x; p.y *= s0.y; p.z *= s0.z; p.w *= s0.w; q.x *= s1.x; q.y *= s1.y; q.z *= s1.z; q.w *= s1.w;
+    }
+    enc_bf16x8 hi, lo;
+    enc_split8(p, q, hi, lo);
+    *reinterpret_cast<enc_bf16x8 *>(dst + enc_pw(n, k0, K, NT, KW)) = hi;
+    *reinterpret_cast<enc_bf16x8 *>(dst + enc_pw(n, k0 + 16, K, NT, KW)) = lo;
+}
+
 // one-time, for a Linear that reads a LayerNorm's output, LN(x) W^T + bias = rstd (x (W diag g)^T - mean c1) + c2 with
 //   c1[n] = sum_k g[k] W[n][k]        c2[n] = sum_k b[k] W[n][k] + bias[n]          (sums in double); one wave per n
 __global__ __launch_bounds__(256) void enc_fold_ln_kernel(const float *w, const float *g, const float *b, const float *bias, float *c1, float *c2, int N, int K) {
@@ -226,7 +265,8 @@ __device__ unsigned long long g_enc_first[8];   // diagnostic: clocks at the fir
 // 768, 16: hidden 1 024), the block has at most MAXW waves;
 // EPI: 0 bias, 1 bias + erf-GELU (BertIntermediate), 2 bias + LayerNorm-ed residual; OUT_PA: y in operand order
 // NSLAB: the A operand is the sum of this many slabs
-template <int ITER, int NT, int EPI, bool LNPRO, bool OUT_PA, int MAXW, int NSLAB>
+// BF: the split-bf16 arithmetic (three bf16 MFMAs per 32-block; w holds w_hi / w_lo) instead of eight fp32 MFMAs
+template <int ITER, int NT, int EPI, bool LNPRO, bool OUT_PA, int MAXW, int NSLAB, bool BF = false>
 __global__ __launch_bounds__(MAXW * 64) void enc_linear_kernel(EncLinearArgs a) {
     static_assert(NT == 16 || NT == 8 || NT == 4, "columns per work-group");
     constexpr int KW = 16 * ITER;   // this wave's columns of K
@@ -303,6 +343,23 @@ __global__ __launch_bounds__(MAXW * 64) void enc_linear_kernel(EncLinearArgs a) 
     if (t0 >= T) return;   // (work-group-uniform, before any barrier: a token tile past the call's tokens; its loads were harmless)
     {
         enc_f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};   // (two chains: a dependent MFMA waits out the one before it)
+        if constexpr (BF) {
+            // 32-blocks b = 0, 1, ...: even ones into c0, odd ones into c1, each block hi hi, hi lo, lo hi (two blocks interleaved)
+            static_assert(ITER % 4 == 0, "pairs of 32-blocks");
+#pragma unroll
+            for (int i = 0; i < ITER; i += 4) {
+                enc_bf16x8 ah0, al0, ah1, al1;
+                enc_split8(areg[i], areg[i + 1], ah0, al0);
+                enc_split8(areg[i + 2], areg[i + 3], ah1, al1);
+                const enc_bf16x8 wh0 = enc_as_bf16x8(wreg[i]), wl0 = enc_as_bf16x8(wreg[i + 1]), wh1 = enc_as_bf16x8(wreg[i + 2]), wl1 = enc_as_bf16x8(wreg[i + 3]);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, wh0, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, wh1, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, wl0, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, wl1, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0, wh0, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al1, wh1, c1, 0, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < ITER; i += 2) {
             c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i].x, wreg[i].x, c0, 0, 0, 0);

@@ -57,7 +57,7 @@ inline bool enc_valid(const icd_encoder *e) { return e && e->magic == ENC_MAGIC;
 // the launches of one forward on stream s (inside a capture): the descriptor H2D in front, the pooled rows' D2H behind
 constexpr int ENC_SLABS = 4;   // K slices of the FFN-down GEMM = slabs of its output
 // ITER: 16-column k-steps per wave (12: hidden 768 / inter 3 072, 16: hidden 1 024 / inter 4 096); NV = hidden / 256
-template <int ITER, int NV>
+template <int ITER, int NV, bool BF>
 inline int enc_enqueue_t(icd_encoder *e, int bucket_tokens, int pooling, int normalize, bool single, bool copies, hipStream_t s) {
     constexpr int KW = 16 * ITER;
     const icd_encoder_desc &d = e->d;
@@ -80,8 +80,8 @@ inline int enc_enqueue_t(icd_encoder *e, int bucket_tokens, int pooling, int nor
             a.meta = e->d_meta; a.x = y0; a.ln_eps = d.ln_eps; a.stats_out = e->sA;
             a.w = e->w_qkv[l]; a.c1 = e->c1_qkv[l]; a.bias = e->c2_qkv[l]; a.y = e->qkv; a.K = H; a.N = 3 * H; a.stamps = (e->stamps && l == d.layers - 1) ? e->stamps : nullptr;
             a.nwk = H / KW; a.slab = slab; a.res_nslab = 1;
-            if (l == 0) hipLaunchKernelGGL((enc_linear_kernel<ITER, 16, 0, true, false, 4, 1>), dim3(3 * H / 16, tiles), dim3(64 * (H / KW)), 0, s, a);   // (the embedding sum: one slab)
-            else hipLaunchKernelGGL((enc_linear_kernel<ITER, 16, 0, true, false, 4, ENC_SLABS>), dim3(3 * H / 16, tiles), dim3(64 * (H / KW)), 0, s, a);
+            if (l == 0) hipLaunchKernelGGL((enc_linear_kernel<ITER, 16, 0, true, false, 4, 1, BF>), dim3(3 * H / 16, tiles), dim3(64 * (H / KW)), 0, s, a);   // (the embedding sum: one slab)
+            else hipLaunchKernelGGL((enc_linear_kernel<ITER, 16, 0, true, false, 4, ENC_SLABS, BF>), dim3(3 * H / 16, tiles), dim3(64 * (H / KW)), 0, s, a);
         }
         {
             EncAttnArgs a{};
@@ -94,14 +94,14 @@ inline int enc_enqueue_t(icd_encoder *e, int bucket_tokens, int pooling, int nor
             a.meta = e->d_meta; a.x = e->ctx; a.w = e->w_ao[l]; a.bias = e->b_ao[l];
             a.res_src = y0; a.res_stats = e->sA; a.res_g = pg; a.res_b = pb; a.y = y1; a.K = H; a.N = H; a.stamps = (e->stamps && l == d.layers - 1) ? e->stamps + 16 : nullptr;
             a.nwk = H / KW; a.slab = slab; a.res_nslab = l == 0 ? 1 : ENC_SLABS;
-            hipLaunchKernelGGL((enc_linear_kernel<ITER, 8, 2, false, true, 4, 1>), dim3(H / 8, tiles), dim3(64 * (H / KW)), 0, s, a);
+            hipLaunchKernelGGL((enc_linear_kernel<ITER, 8, 2, false, true, 4, 1, BF>), dim3(H / 8, tiles), dim3(64 * (H / KW)), 0, s, a);
         }
         {   // mid = GELU(LayerNorm1(y1) Wup^T + b); statistics of LayerNorm1 in sB
             EncLinearArgs a{};
             a.meta = e->d_meta; a.x = y1; a.ln_eps = d.ln_eps; a.stats_out = e->sB;
             a.w = e->w_up[l]; a.c1 = e->c1_up[l]; a.bias = e->c2_up[l]; a.y = e->mid; a.K = H; a.N = I; a.stamps = (e->stamps && l == d.layers - 1) ? e->stamps + 32 : nullptr;
             a.nwk = H / KW; a.slab = slab; a.res_nslab = 1;
-            hipLaunchKernelGGL((enc_linear_kernel<ITER, 16, 1, true, true, 4, 1>), dim3(I / 16, tiles), dim3(64 * (H / KW)), 0, s, a);
+            hipLaunchKernelGGL((enc_linear_kernel<ITER, 16, 1, true, true, 4, 1, BF>), dim3(I / 16, tiles), dim3(64 * (H / KW)), 0, s, a);
         }
         {   // y2 = mid Wdown^T + b + LayerNorm1(y1)   (BertOutput in front of its LayerNorm)
             EncLinearArgs a{};
@@ -109,7 +109,7 @@ inline int enc_enqueue_t(icd_encoder *e, int bucket_tokens, int pooling, int nor
             a.res_src = y1; a.res_stats = e->sB; a.res_g = e->ln1_g[l]; a.res_b = e->ln1_b[l]; a.y = y2; a.K = I; a.N = H; a.stamps = (e->stamps && l == d.layers - 1) ? e->stamps + 48 : nullptr;
             // K = inter split over ENC_SLABS work-groups of (inter / 192 / ENC_SLABS) waves per 16 output columns: partial sums into the slabs of y2
             a.nwk = I / KW; a.slab = slab; a.res_nslab = 1;
-            hipLaunchKernelGGL((enc_linear_kernel<ITER, 16, 2, false, true, 4, 1>), dim3(H / 16 * ENC_SLABS, tiles), dim3(64 * (I / KW / ENC_SLABS)), 0, s, a);
+            hipLaunchKernelGGL((enc_linear_kernel<ITER, 16, 2, false, true, 4, 1, BF>), dim3(H / 16 * ENC_SLABS, tiles), dim3(64 * (I / KW / ENC_SLABS)), 0, s, a);
         }
         cur = (cur + 2) % 3;
         pg = e->ln2_g[l]; pb = e->ln2_b[l];
@@ -126,8 +126,11 @@ inline int enc_enqueue_t(icd_encoder *e, int bucket_tokens, int pooling, int nor
 }
 
 inline int enc_enqueue(icd_encoder *e, int bucket_tokens, int pooling, int normalize, bool single, bool copies, hipStream_t s) {
-    return e->d.hidden == 1024 ? enc_enqueue_t<16, 4>(e, bucket_tokens, pooling, normalize, single, copies, s)
-                               : enc_enqueue_t<12, 3>(e, bucket_tokens, pooling, normalize, single, copies, s);
+    if (e->d.arithmetic == ICD_ENCODER_ARITH_BF16X3)
+        return e->d.hidden == 1024 ? enc_enqueue_t<16, 4, true>(e, bucket_tokens, pooling, normalize, single, copies, s)
+                                   : enc_enqueue_t<12, 3, true>(e, bucket_tokens, pooling, normalize, single, copies, s);
+    return e->d.hidden == 1024 ? enc_enqueue_t<16, 4, false>(e, bucket_tokens, pooling, normalize, single, copies, s)
+                               : enc_enqueue_t<12, 3, false>(e, bucket_tokens, pooling, normalize, single, copies, s);
 }
 
 // the token bucket of a call (index into icd_encoder::exec; its launches cover 16 << index tokens)
@@ -178,7 +181,7 @@ constexpr size_t ENC_BIG_LDS_PIN = 84 * 1024;
 // TM: 16-token tiles per wave; TNQ / TNU / TNO: 16-column tiles per wave of the QKV, FFN-up and the two hidden-sized-output GEMMs (the
 // column groups per GEMM a multiple of the 8 XCDs: the hardware deals work-groups round-robin over them, so a column group's W
 // tiles stay in ONE XCD's L2); PF: pairs of k-steps in flight
-template <int ITER, int NV, int TM, int TNQ, int TNU, int TNO, int PF>
+template <int ITER, int NV, int TM, int TNQ, int TNU, int TNO, int PF, bool BF = false>
 inline int enc_big_enqueue_t(icd_encoder *e, int T, int nb, int pooling, int normalize, hipStream_t s) {
     constexpr int KW = 16 * ITER;
     using M = EncMetaBig;
@@ -191,10 +194,10 @@ inline int enc_big_enqueue_t(icd_encoder *e, int T, int nb, int pooling, int nor
 #ifdef ICD_ABLATE
     if (const char *v = getenv("ICD_ENCBIG_LDS")) lds_pin = (size_t)atoi(v);   // A/B: 0 = as many work-groups per CU as the registers allow
 #endif
-    auto k_qkv = enc_linear_big_kernel<ITER, TM, TNQ, 0, true, false, 1, PF>;
-    auto k_ao = enc_linear_big_kernel<ITER, TM, TNO, 2, false, true, 1, PF>;
-    auto k_up = enc_linear_big_kernel<ITER, TM, TNU, 1, true, true, 1, PF>;
-    auto k_down = enc_linear_big_kernel<ITER, TM, TNO, 2, false, true, ENC_SLABS, PF>;
+    auto k_qkv = enc_linear_big_kernel<ITER, TM, TNQ, 0, true, false, 1, PF, BF>;
+    auto k_ao = enc_linear_big_kernel<ITER, TM, TNO, 2, false, true, 1, PF, BF>;
+    auto k_up = enc_linear_big_kernel<ITER, TM, TNU, 1, true, true, 1, PF, BF>;
+    auto k_down = enc_linear_big_kernel<ITER, TM, TNO, 2, false, true, ENC_SLABS, PF, BF>;
     {
         static int c0[MAX_DEVICES] = {}, c1[MAX_DEVICES] = {}, c2[MAX_DEVICES] = {}, c3[MAX_DEVICES] = {};   // (per instantiation and device; calls on a handle are serialised)
         HIP_TRY(ensure_dynamic_lds(k_qkv, e->device, lds_pin, c0)); HIP_TRY(ensure_dynamic_lds(k_ao, e->device, lds_pin, c1));
@@ -278,6 +281,29 @@ inline int enc_big_enqueue(icd_encoder *e, int T, int nb, int pooling, int norma
         }
     }
 #endif
+    if (e->d.arithmetic == ICD_ENCODER_ARITH_BF16X3) {
+        // The split-bf16 arithmetic: the matrix time is a fifth of the fp32 form's, the operand supply per MFMA cycle five times -
+        // the GEMMs are bound by the L1 (every wave loads its A and W fragments itself). Shapes measured on the diagnostic build
+        // (profiles/r06_encoder_big_bf_sweep.log): two token tiles x SIX column tiles per wave (24 / 32 / 8 column groups per GEMM)
+        // 104.1 ms per 4 000 strings against 110.8 for the fp32 form's shapes (4 x 3 / 4 / 3); W through LDS: 146-174 (not kept).
+        if (e->d.hidden == 1024) {   // (inter 4 096 = 256 column tiles: no groups of six)
+            if (tm == 4) return enc_big_enqueue_t<16, 4, 4, 3, 4, 2, 1, true>(e, T, nb, pooling, normalize, s);
+            if (tm == 2) return enc_big_enqueue_t<16, 4, 2, 3, 4, 2, 1, true>(e, T, nb, pooling, normalize, s);
+            return enc_big_enqueue_t<16, 4, 1, 3, 4, 2, 1, true>(e, T, nb, pooling, normalize, s);
+        }
+#ifdef ICD_ABLATE
+        if (const char *v = getenv("ICD_ENCBIG_BF_VAR")) {   // A/B: tile shapes of the split-bf16 form (hidden 768)
+            switch (atoi(v)) {
+            case 1: return enc_big_enqueue_t<12, 3, 2, 3, 4, 3, 1, true>(e, T, nb, pooling, normalize, s);
+            case 2: return enc_big_enqueue_t<12, 3, 4, 3, 4, 3, 1, true>(e, T, nb, pooling, normalize, s);
+            case 3: return enc_big_enqueue_t<12, 3, 2, 6, 4, 3, 1, true>(e, T, nb, pooling, normalize, s);
+            default: break;
+            }
+        }
+#endif
+        if (tm >= 2) return enc_big_enqueue_t<12, 3, 2, 6, 6, 6, 1, true>(e, T, nb, pooling, normalize, s);
+        return enc_big_enqueue_t<12, 3, 1, 6, 6, 6, 1, true>(e, T, nb, pooling, normalize, s);
+    }
     // Tile shapes (profiles/r06_encoder_big_sweep.log: seven shapes and prefetch depths within 5 % of each other once a CU holds one
     // work-group - the GEMMs run at 0.65-0.75 of the 157 TFLOP/s fp32 MFMA peak, which is what the fp32-MFMA search kernel reaches too)
     if (e->d.hidden == 1024) {
@@ -294,7 +320,7 @@ inline int enc_big_enqueue(icd_encoder *e, int T, int nb, int pooling, int norma
 inline int enc_big_alloc(icd_encoder *e) {
     icd_encoder::Big &g = e->big;
     if (g.ready) return ICD_OK;
-    const size_t H = (size_t)e->d.hidden, I = (size_t)e->d.inter, T = (size_t)ENC_BIG_TMAX + 128;
+    const size_t H = (size_t)e->d.hidden, I = (size_t)e->d.inter, T = (size_t)ENC_BIG_TMAX + 128;   // (+ the rows a last partial work-group of 64 TM tokens reads)
     struct { float **p; size_t n; } bufs[] = {{&g.y[0], T * H}, {&g.y[1], T * H}, {&g.y[2], T * H}, {&g.x, T * H}, {&g.qkv, T * 3 * H}, {&g.ctx, T * H},
                                               {&g.mid, T * I}, {&g.pooled, (size_t)ENC_BIG_BMAX * H}, {&g.sA, 2 * T}, {&g.sB, 2 * T}};
     for (auto &b : bufs) {
@@ -349,6 +375,7 @@ int icd_encoder_create(int32_t device, const icd_encoder_desc *desc, icd_encoder
     if (d.inter < 4 * kw || d.inter % (4 * kw) != 0 || d.inter > 16 * kw) return fail(ICD_ERR_UNSUPPORTED, "inter=%d (a multiple of %d, at most %d: four K slices of at most four waves)", d.inter, 4 * kw, 16 * kw);
     if (d.vocab < 1 || d.max_pos < 1 || d.pos_offset < 0 || d.pos_offset >= d.max_pos) return fail(ICD_ERR_INVALID, "vocab=%d max_pos=%d pos_offset=%d", d.vocab, d.max_pos, d.pos_offset);
     if (!(d.ln_eps > 0.0f)) return fail(ICD_ERR_INVALID, "ln_eps=%g", (double)d.ln_eps);
+    if (d.arithmetic != ICD_ENCODER_ARITH_FP32 && d.arithmetic != ICD_ENCODER_ARITH_BF16X3) return fail(ICD_ERR_INVALID, "arithmetic=%d (ICD_ENCODER_ARITH_FP32 or _BF16X3)", d.arithmetic);
     if (!d.word_emb || !d.pos_emb || !d.type_emb0 || !d.emb_ln_g || !d.emb_ln_b) return fail(ICD_ERR_INVALID, "an embedding pointer is NULL");
     const float *const *arrs[12] = {d.w_qkv, d.b_qkv, d.w_ao, d.b_ao, d.ln1_g, d.ln1_b, d.w_up, d.b_up, d.w_down, d.b_down, d.ln2_g, d.ln2_b};
     for (auto a : arrs) {
@@ -384,6 +411,11 @@ int icd_encoder_create(int32_t device, const icd_encoder_desc *desc, icd_encoder
         auto permute = [&](const float *src, const float *colscale, float **dst, int N, int K, int NT) -> hipError_t {
             hipError_t er = hipMalloc(reinterpret_cast<void **>(dst), (size_t)N * K * sizeof(float));
             if (er != hipSuccess) return er;
+            if (d.arithmetic == ICD_ENCODER_ARITH_BF16X3) {   // w_hi / w_lo of every 32-block in the block's two 16-byte slots
+                const size_t groups = (size_t)N * K / 8;
+                hipLaunchKernelGGL(enc_permute_w_bf16_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, nullptr, src, colscale, *dst, N, K, NT, kw);
+                return hipGetLastError();
+            }
             const size_t groups = (size_t)N * K / 4;
             hipLaunchKernelGGL(enc_permute_w_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, nullptr, src, colscale, *dst, N, K, NT, kw);
             return hipGetLastError();
