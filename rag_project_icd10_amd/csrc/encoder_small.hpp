@@ -413,6 +413,13 @@ __global__ __launch_bounds__(MAXW * 64) void enc_linear_kernel(EncLinearArgs a) 
 
 // one chunk of at most CH keys of the flash recurrence of ONE (token, head): q = the lane's scaled query component, kreg / vreg =
 // the lane's component of the chunk's keys / values; the first Lc are live (contraction off: the roundings are the ones written here)
+// e^x of the softmax as ONE v_exp_f32 (2^(x log2 e): the product's rounding moves the exponent by |x| 2^-24 - a weight e^x is
+// off by ~1e-6 of ITSELF where it is ~e^-20 of the row's largest, by nothing where it matters; exp(-inf) = 0). ocml's expf is a
+// dozen instructions per key, a third of what this kernel costs in the batch form, where it is bound by its VALU work.
+__device__ __forceinline__ float enc_exp(float x) {
+#pragma clang fp contract(off)
+    return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+}
 template <int CH>
 __device__ __forceinline__ void enc_attn_chunk(float q, const float (&kreg)[CH], const float (&vreg)[CH], int Lc, float &m_run, float &l_run, float &o_run) {
 #pragma clang fp contract(off)
@@ -430,16 +437,16 @@ __device__ __forceinline__ void enc_attn_chunk(float q, const float (&kreg)[CH],
             }
         }
     }
-    const float carry = expf(m_run - m);      // (first chunk: exp(-inf) = 0)
+    const float carry = enc_exp(m_run - m);      // (first chunk: exp(-inf) = 0)
     float l = l_run * carry, o = o_run * carry;
 #pragma unroll
     for (int jb = 0; jb < CH; jb += 8) {
         if (jb < Lc) {
 #pragma unroll
             for (int j = jb; j < jb + 8; ++j) {
-                const float e = j < Lc ? expf(sc[j] - m) : 0.f;
+                const float e = j < Lc ? enc_exp(sc[j] - m) : 0.f;
                 l += e;
-                o = fmaf(e, vreg[j], o);
+                o = j < Lc ? fmaf(e, vreg[j], o) : o;   // (a masked key's value is never touched: whatever sits in a row past the sequence - stale, another call's, not even finite - cannot reach the output)
             }
         }
     }
@@ -491,6 +498,9 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(EncAttnArgs a) {
         if (!SINGLE || k0 > 0) {
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
+                // (measured and NOT kept, round 6: the rows k0 + j unclamped, masked like the SINGLE form's - no 64-bit multiply per
+                //  key, but 32 distinct rows per chunk whatever the length: 206 -> 481 us per layer in the batch form. The kernel
+                //  is bound by its loads, not by its VALU work: the clamped tail re-reads ONE row)
                 const size_t row = (size_t)(k0 + min(j, Lc - 1)) * ld;
                 kreg[j] = kb[row];
                 vreg[j] = vb[row];
@@ -499,6 +509,47 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(EncAttnArgs a) {
         enc_attn_chunk<CH>(q, kreg, vreg, Lc, m_run, l_run, o_run);
     }
     a.out[enc_pa(t, h * ATT_HEAD_DIM + lane, a.H, a.KW)] = o_run / l_run;
+}
+
+// The batch form's attention (encoder_big.hpp): ONE wave per (TPW consecutive tokens, head). The kernel above is bound by its loads - a
+// sequence's keys and values once per TOKEN; here a wave keeps the chunk of a sequence of at most 32 tokens in registers while its
+// tokens stay in that sequence (packed tokens: consecutive ones mostly do) and reloads only across a boundary. Every token gets the
+// arithmetic the kernel above gives it (enc_attn_chunk on the same operands): the same bits. (One wave per whole (sequence, head) was
+// measured too: 495 against 205 us per layer - 5 000 long waves do not balance over the SIMDs where 25 000 of four tokens do.)
+template <typename M, int TPW>
+__global__ __launch_bounds__(256) void enc_attention_group_kernel(EncAttnArgs a) {
+    constexpr int CH = 32;
+    const int lane = threadIdx.x & 63;
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int g = task / a.heads, h = task - g * a.heads;
+    const int T = a.meta[0];
+    const int t_first = g * TPW;
+    if (t_first >= T) return;   // wave-uniform, no barriers below
+    const size_t ld = 3 * (size_t)a.H;
+    float kreg[CH], vreg[CH];
+    int have_r0 = -1;           // first row of the sequence whose (single) chunk sits in kreg / vreg
+    for (int t = t_first; t < min(t_first + TPW, T); ++t) {
+        const int r0 = a.meta[M::TOK_R0 + t], L = a.meta[M::TOK_LEN + t];
+        if (L <= 0) continue;
+        const float q = a.qkv[(size_t)t * ld + (size_t)h * ATT_HEAD_DIM + lane] * a.scale;
+        const float *kb = a.qkv + (size_t)r0 * ld + a.H + (size_t)h * ATT_HEAD_DIM + lane;
+        const float *vb = kb + a.H;
+        float m_run = -INFINITY, l_run = 0.f, o_run = 0.f;
+        for (int k0 = 0; k0 < L; k0 += CH) {
+            const int Lc = min(CH, L - k0);
+            if (!(L <= CH && have_r0 == r0)) {   // (a one-chunk sequence whose chunk is in the registers already: nothing to load)
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const size_t row = (size_t)(k0 + min(j, Lc - 1)) * ld;
+                    kreg[j] = kb[row];
+                    vreg[j] = vb[row];
+                }
+                have_r0 = L <= CH ? r0 : -1;
+            }
+            enc_attn_chunk<CH>(q, kreg, vreg, Lc, m_run, l_run, o_run);
+        }
+        a.out[enc_pa(t, h * ATT_HEAD_DIM + lane, a.H, a.KW)] = o_run / l_run;
+    }
 }
 
 struct EncPoolArgs {

@@ -230,7 +230,15 @@ inline int enc_big_enqueue_t(icd_encoder *e, int T, int nb, int pooling, int nor
             //  205 against 495 us per layer and 8 192 tokens, profiles/r06_encoder_big_kernel_stats.log)
             EncAttnArgs a{};
             a.meta = g.d_meta; a.qkv = g.qkv; a.out = g.ctx; a.H = H; a.heads = d.heads; a.KW = KW; a.scale = 0.125f;
-            hipLaunchKernelGGL((enc_attention_kernel<false, M>), dim3((unsigned)(((size_t)T * d.heads + 3) / 4)), dim3(256), 0, s, a);
+            int tpw = 4;
+#ifdef ICD_ABLATE
+            if (const char *v = getenv("ICD_ENCBIG_TPW")) tpw = atoi(v);   // A/B: tokens per wave of the attention (1: the small form's kernel)
+#endif
+            const size_t groups = ((size_t)T + tpw - 1) / (size_t)std::max(1, tpw);
+            if (tpw == 4) hipLaunchKernelGGL((enc_attention_group_kernel<M, 4>), dim3((unsigned)((groups * d.heads + 3) / 4)), dim3(256), 0, s, a);
+            else if (tpw == 2) hipLaunchKernelGGL((enc_attention_group_kernel<M, 2>), dim3((unsigned)((groups * d.heads + 3) / 4)), dim3(256), 0, s, a);
+            else if (tpw == 8) hipLaunchKernelGGL((enc_attention_group_kernel<M, 8>), dim3((unsigned)((groups * d.heads + 3) / 4)), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((enc_attention_kernel<false, M>), dim3((unsigned)(((size_t)T * d.heads + 3) / 4)), dim3(256), 0, s, a);
         }
         {   // y1 = ctx Wo^T + b + LayerNorm(y0)
             EncBigLinearArgs a{};
@@ -399,7 +407,7 @@ int icd_encoder_create(int32_t device, const icd_encoder_desc *desc, icd_encoder
     e->d.w_qkv = e->d.b_qkv = e->d.w_ao = e->d.b_ao = e->d.ln1_g = e->d.ln1_b = e->d.w_up = e->d.b_up = e->d.w_down = e->d.b_down = e->d.ln2_g = e->d.ln2_b = nullptr;   // (the caller's arrays need not outlive this call)
 #define ENC_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { enc_free(e); return fail(e_ == hipErrorOutOfMemory ? ICD_ERR_NOMEM : ICD_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } } while (0)
     const size_t H = (size_t)d.hidden, I = (size_t)d.inter, T = ENC_TMAX;
-    struct { float **p; size_t n; } bufs[] = {{&e->yb[0], ENC_SLABS * T * H}, {&e->yb[1], ENC_SLABS * T * H}, {&e->yb[2], ENC_SLABS * T * H}, {&e->x, T * H}, {&e->qkv, T * 3 * H}, {&e->ctx, T * H},
+    struct { float **p; size_t n; } bufs[] = {{&e->yb[0], ENC_SLABS * T * H}, {&e->yb[1], ENC_SLABS * T * H}, {&e->yb[2], ENC_SLABS * T * H}, {&e->x, T * H}, {&e->qkv, (T + 32) * 3 * H} /* (+ a chunk of keys past the last sequence: loaded, masked) */, {&e->ctx, T * H},
                                               {&e->mid, T * I}, {&e->pooled, (size_t)ENC_BMAX * H}, {&e->sA, 2 * T}, {&e->sB, 2 * T}};
     for (auto &b : bufs) {
         ENC_TRY(hipMalloc(reinterpret_cast<void **>(b.p), b.n * sizeof(float)));
