@@ -35,8 +35,11 @@ bash scripts/gpu_encoder_small.sh $TAG > gpurun_out/encoder_small_$TAG.out 2>&1 
 # round 6: the batch form of the canonical encoder (kernel table, tile sweep on the diagnostic build), what it costs next to the fast path,
 # coarse lists of 24 / 16 at k = 40 ... 100, the single-query fp16 certificate priced, half batches / two handles on two streams
 bash scripts/gpu_encoder_big_profile.sh $TAG 4000 < /dev/null > gpurun_out/encoder_big_$TAG.out 2>&1
-if [ -f rag_project_icd10_amd/csrc/abe/libicdsearch.so ]; then bash scripts/gpu_encoder_big_sweep.sh ${TAG}s "0 1 2 3 4 5 6" < /dev/null > /dev/null 2>&1; fi
+# (the tile sweeps of the batch form - scripts/gpu_encoder_big_sweep.sh (fp32 arithmetic: ICD_ENCODER_ARITH=fp32), gpu_encoder_big_bf_sweep.sh - ran mid-round on
+#  the diagnostic build of their moment: profiles/r06_encoder_big_sweep.log, r06_encoder_big_bf_sweep.log)
 (timeout 300 python3 scripts/probe/encode_many_probe.py 2>&1 < /dev/null | grep -v "amdgpu.ids\|SYNTHETIC") > gpurun_out/${TAG}_encode_many_probe.log
+(timeout 300 python3 scripts/probe/encoder_arith_probe.py 2>&1 < /dev/null | grep -v "amdgpu.ids\|SYNTHETIC") > gpurun_out/${TAG}_encoder_arith.log
+(ICD_ENCODER_ARITH=fp32 timeout 600 python -m pytest tests/test_encoder_gpu.py tests/test_ner_gpu.py -q -m gpu 2>&1 < /dev/null | tail -2) > gpurun_out/${TAG}_pytest_encoder_fp32_arith.log
 (timeout 400 python3 scripts/probe/k100_lists.py 2>&1 < /dev/null | grep -v amdgpu.ids) > gpurun_out/${TAG}_k100_lists.log
 (timeout 300 python3 scripts/probe/single_query_fp16_sim.py 2>&1 < /dev/null | grep -v "amdgpu.ids\|SYNTHETIC") > gpurun_out/${TAG}_single_query_fp16_sim.log
 (timeout 200 python3 scripts/probe/two_streams.py 2>&1 < /dev/null | grep -v amdgpu.ids) > gpurun_out/${TAG}_two_streams_overlap.log
