@@ -15,11 +15,13 @@
 //                           global memory in operand order (enc_pa / enc_pw: 1 KB contiguous per wave instruction, the four
 //                           waves of a work-group share their W fragments through the L1), the next step's loads in flight
 //                           under this step's MFMAs: per step and wave (TM + TN) KB for 8 TM TN MFMAs - the small form's
-//                           2 KB for 8. fp32 MFMA (v_mfma_f32_16x16x4_f32: exact products) like the small form: 157 TFLOP/s
-//                           is this arithmetic's roofline.
+//                           2 KB for 8. The products in the handle's arithmetic, like the small form: fp32 MFMAs (157 TFLOP/s is
+//                           that arithmetic's roofline: the GEMMs reach 0.65-0.75 of it) or the split-bf16 form (BF: a fifth of
+//                           the matrix time - the GEMMs are then bound by the operand supply through the L1).
 //   enc_ln_stats_kernel     mean and 1 / std of every token's pre-norm row, by the lanes and in the order the small form's
 //                           LNPRO kernels compute them inside the GEMM (enc_piece_stats per 192-column slice, enc_combine_stats).
-//   embedding sum, attention, pooling: encoder_small.hpp's kernels themselves, instantiated for the larger descriptor.
+//   embedding sum, pooling: encoder_small.hpp's kernels themselves, instantiated for the larger descriptor; the attention one wave per
+//   (four consecutive tokens, head) instead of one per (token, head) - enc_attention_group_kernel, the same arithmetic per token.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "encoder_small.hpp"

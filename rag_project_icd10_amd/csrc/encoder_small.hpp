@@ -7,14 +7,17 @@
 // kernels of ~5 us: 1.1 ms replayed from a graph; a kernel that loads its arguments, one operand and stores takes 3-5 us on
 // this part however little it computes, and a boundary 1.2-1.5: MI355X_MICROARCH.md, price list - a grid barrier inside
 // one launch costs MORE than a boundary, 4-7 us, so this is not a persistent kernel). This file is that forward as FIVE
-// launches per layer, all fp32, the LayerNorms folded into their consumers:
+// launches per layer, activations and accumulation in fp32, the LayerNorms folded into their consumers; the GEMMs' products in one
+// of two arithmetics chosen at create (icd_encoder_desc.arithmetic): fp32-input MFMAs (round 5), or - the default since round 6 -
+// the split-bf16 form further down (three bf16 MFMAs per 32 k-values, ~1e-6 off the fp32 forward, a fifth of the matrix time):
 //
 //   enc_linear_kernel   Y = act(A W^T + b) (+ R): one work-group per NT (16 or 8) output columns and 16 tokens (grid.y: the token
 //                       tiles of a longer input side by side), its four waves split K (192 columns each; 256 at hidden 1 024). A
 //                       wave issues ALL its loads up front - its NT x 192 slice of W (12 x 16 B per lane: the whole slice in
 //                       flight at once) and its tokens' operand rows - so that the kernel is one memory round trip deep, then
 //                       runs v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate: exact products; the sum's order differs from the
-//                       vendor GEMM's like any two GEMMs differ); the waves' partial sums meet in LDS, where bias, erf-GELU and
+//                       vendor GEMM's like any two GEMMs differ) or v_mfma_f32_16x16x32_bf16 on the split operands (BF); the waves'
+//                       partial sums meet in LDS, where bias, erf-GELU and
 //                       the residual are applied. Operands are STORED in the order these loads want them (enc_pa / enc_pw);
 //                       the FFN-down GEMM splits K over four work-groups whose partial sums its readers add up (slabs).
 //       LNPRO           A = LayerNorm(X) without touching X: LN(x) W^T + b = rstd (x (W diag g)^T - mean c1) + c2 with c1, c2
