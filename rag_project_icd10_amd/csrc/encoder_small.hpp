@@ -557,7 +557,9 @@ __global__ __launch_bounds__(256) void enc_attention_group_kernel(EncAttnArgs a)
 
 struct EncPoolArgs {
     const int *meta;
-    const float *y;        // [TMAX][H] pre-norm output of the last layer, operand order
+    const float *y;        // [TMAX][H] pre-norm output of the last layer, ROW-MAJOR (the last FFN-down GEMM is launched without OUT_PA: nothing
+                           // reads its output as a GEMM operand, and a wave here wants a token's row in 1-KB pieces - in operand order
+                           // every lane's 16 bytes came from another 256-byte group: 10.5 us for 15 tokens, 51 for 98)
     const float *g, *b;    // its LayerNorm
     float eps;
     int H, KW;             // H = 256 NV
@@ -589,7 +591,7 @@ __global__ __launch_bounds__(ENC_POOL_WAVES * 64) void enc_pool_kernel(EncPoolAr
         float4 v[NV];
 #pragma unroll
         for (int j = 0; j < NV; ++j) {   // (every load of the row in flight before the first add)
-            const size_t idx = enc_pa(r, 4 * (lane + 64 * j), a.H, a.KW);
+            const size_t idx = (size_t)r * a.H + 4 * (lane + 64 * j);
             float4 u[NSLAB];
 #pragma unroll
             for (int sl = 0; sl < NSLAB; ++sl) u[sl] = *reinterpret_cast<const float4 *>(a.y + idx + (size_t)sl * a.slab);

@@ -29,6 +29,11 @@ struct icd_encoder {
     hipStream_t cap_stream = nullptr;
     hipEvent_t ev_done = nullptr;   // behind every launch: the next call may rewrite h_meta only after the copy node has run
     bool ev_pending = false;
+    // the workspaces (small and batch form) belong to the handle, not to a stream: a call that returned without waiting (device
+    // output) leaves ev_tail behind its last launch, and a call on ANOTHER stream waits for it on the device before its first
+    hipEvent_t ev_tail = nullptr;
+    hipStream_t tail_stream = nullptr;
+    bool tail_pending = false;
     static constexpr int NBUCKET = 6;   // 16, 32, 64, 128, 256, 512 tokens
     hipGraphExec_t exec[NBUCKET][2][2][2][2] = {};   // [bucket][pooling][normalize][one sequence][with the descriptor / result copy nodes]
     // icd_encoder_encode_many: the descriptors of consecutive calls come from a ring of pinned blocks, copied to d_meta on the
@@ -109,7 +114,9 @@ inline int enc_enqueue_t(icd_encoder *e, int bucket_tokens, int pooling, int nor
             a.res_src = y1; a.res_stats = e->sB; a.res_g = e->ln1_g[l]; a.res_b = e->ln1_b[l]; a.y = y2; a.K = I; a.N = H; a.stamps = (e->stamps && l == d.layers - 1) ? e->stamps + 48 : nullptr;
             // K = inter split over ENC_SLABS work-groups of (inter / 192 / ENC_SLABS) waves per 16 output columns: partial sums into the slabs of y2
             a.nwk = I / KW; a.slab = slab; a.res_nslab = 1;
-            hipLaunchKernelGGL((enc_linear_kernel<ITER, 16, 2, false, true, 4, 1, BF>), dim3(H / 16 * ENC_SLABS, tiles), dim3(64 * (I / KW / ENC_SLABS)), 0, s, a);
+            // (the last layer's output feeds the pooling kernel only: row-major)
+            if (l == d.layers - 1) hipLaunchKernelGGL((enc_linear_kernel<ITER, 16, 2, false, false, 4, 1, BF>), dim3(H / 16 * ENC_SLABS, tiles), dim3(64 * (I / KW / ENC_SLABS)), 0, s, a);
+            else hipLaunchKernelGGL((enc_linear_kernel<ITER, 16, 2, false, true, 4, 1, BF>), dim3(H / 16 * ENC_SLABS, tiles), dim3(64 * (I / KW / ENC_SLABS)), 0, s, a);
         }
         cur = (cur + 2) % 3;
         pg = e->ln2_g[l]; pb = e->ln2_b[l];
@@ -158,6 +165,18 @@ inline int enc_graph(icd_encoder *e, int bi, int pooling, int normalize, bool si
     return ICD_OK;
 }
 
+// a call on stream s after one that left work behind on another stream (see icd_encoder::ev_tail); enc_tail_mark: behind the last launch
+inline int enc_tail_wait(icd_encoder *e, hipStream_t s) {
+    if (e->tail_pending && e->tail_stream != s) HIP_TRY(hipStreamWaitEvent(s, e->ev_tail, 0));
+    return ICD_OK;
+}
+inline int enc_tail_mark(icd_encoder *e, hipStream_t s, bool synchronised) {
+    if (synchronised) { e->tail_pending = false; return ICD_OK; }   // (the stream was drained, and with it whatever it waited for)
+    HIP_TRY(hipEventRecord(e->ev_tail, s));
+    e->tail_stream = s; e->tail_pending = true;
+    return ICD_OK;
+}
+
 // the descriptor of one call (encoder_small.hpp, EncMeta): `nb` sequences of `lengths`, their ids back to back at `ids`
 template <typename M>
 inline void enc_fill_meta(int *m, const icd_encoder_desc &d, const int32_t *ids, const int32_t *lengths, int nb, int T) {
@@ -198,10 +217,12 @@ inline int enc_big_enqueue_t(icd_encoder *e, int T, int nb, int pooling, int nor
     auto k_ao = enc_linear_big_kernel<ITER, TM, TNO, 2, false, true, 1, PF, BF>;
     auto k_up = enc_linear_big_kernel<ITER, TM, TNU, 1, true, true, 1, PF, BF>;
     auto k_down = enc_linear_big_kernel<ITER, TM, TNO, 2, false, true, ENC_SLABS, PF, BF>;
+    auto k_down_last = enc_linear_big_kernel<ITER, TM, TNO, 2, false, false, ENC_SLABS, PF, BF>;   // the last layer's: row-major, for the pooling kernel
     {
-        static int c0[MAX_DEVICES] = {}, c1[MAX_DEVICES] = {}, c2[MAX_DEVICES] = {}, c3[MAX_DEVICES] = {};   // (per instantiation and device; calls on a handle are serialised)
+        static int c0[MAX_DEVICES] = {}, c1[MAX_DEVICES] = {}, c2[MAX_DEVICES] = {}, c3[MAX_DEVICES] = {}, c4[MAX_DEVICES] = {};   // (per instantiation and device; calls on a handle are serialised)
         HIP_TRY(ensure_dynamic_lds(k_qkv, e->device, lds_pin, c0)); HIP_TRY(ensure_dynamic_lds(k_ao, e->device, lds_pin, c1));
         HIP_TRY(ensure_dynamic_lds(k_up, e->device, lds_pin, c2)); HIP_TRY(ensure_dynamic_lds(k_down, e->device, lds_pin, c3));
+        HIP_TRY(ensure_dynamic_lds(k_down_last, e->device, lds_pin, c4));
     }
     {
         EncEmbedArgs a{};
@@ -257,7 +278,7 @@ inline int enc_big_enqueue_t(icd_encoder *e, int T, int nb, int pooling, int nor
             EncBigLinearArgs a{};
             a.x = g.mid; a.w = e->w_down[l]; a.NT = 16; a.bias = e->b_down[l];
             a.res_src = y1; a.res_stats = g.sB; a.res_g = e->ln1_g[l]; a.res_b = e->ln1_b[l]; a.y = y2; a.T = T; a.K = I; a.N = H; a.pps = I / KW / ENC_SLABS;
-            hipLaunchKernelGGL(k_down, dim3(H / (16 * TNO), gy), dim3(256), lds_pin, s, a);
+            hipLaunchKernelGGL(l == d.layers - 1 ? k_down_last : k_down, dim3(H / (16 * TNO), gy), dim3(256), lds_pin, s, a);
         }
         cur = (cur + 2) % 3;
         pg = e->ln2_g[l]; pb = e->ln2_b[l];
@@ -361,6 +382,7 @@ inline void enc_free(icd_encoder *e) {
     if (e->h_meta) hipHostFree(e->h_meta);
     if (e->h_out) hipHostFree(e->h_out);
     if (e->ev_done) hipEventDestroy(e->ev_done);
+    if (e->ev_tail) hipEventDestroy(e->ev_tail);
     if (e->cap_stream) hipStreamDestroy(e->cap_stream);
     e->magic = 0;
     delete e;
@@ -465,6 +487,7 @@ int icd_encoder_create(int32_t device, const icd_encoder_desc *desc, icd_encoder
 #endif
     ENC_TRY(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
     ENC_TRY(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
+    ENC_TRY(hipEventCreateWithFlags(&e->ev_tail, hipEventDisableTiming));
     ENC_TRY(hipDeviceSynchronize());
 #undef ENC_TRY
     *out = e;
@@ -522,6 +545,7 @@ int icd_encoder_encode(icd_encoder *e, const int32_t *ids, const int32_t *length
     enc_fill_meta<EncMetaSmall>(e->h_meta, d, ids, lengths, nseq, T);
     hipGraphExec_t gx = nullptr;
     { const int rc = enc_graph(e, enc_bucket(T), pooling, normalize, nseq == 1, true, &gx); if (rc) return rc; }
+    { const int rc = enc_tail_wait(e, s); if (rc) return rc; }
     HIP_TRY(hipGraphLaunch(gx, s));
     const size_t H = (size_t)d.hidden;
     if (hidden_out) HIP_TRY(hipMemcpyAsync(hidden_out, e->x, (size_t)T * H * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -529,11 +553,11 @@ int icd_encoder_encode(icd_encoder *e, const int32_t *ids, const int32_t *length
         HIP_TRY(hipMemcpyAsync(out, e->pooled, (size_t)nseq * H * sizeof(float), hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipEventRecord(e->ev_done, s));
         e->ev_pending = true;
-        return ICD_OK;
+        return enc_tail_mark(e, s, false);
     }
     HIP_TRY(hipStreamSynchronize(s));
     memcpy(out, e->h_out, (size_t)nseq * H * sizeof(float));
-    return ICD_OK;
+    return enc_tail_mark(e, s, true);
 }
 
 int icd_encoder_encode_many(icd_encoder *e, const int32_t *ids, const int32_t *lengths, int64_t nseq, int32_t pooling, int32_t normalize,
@@ -559,8 +583,9 @@ int icd_encoder_encode_many(icd_encoder *e, const int32_t *ids, const int32_t *l
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (s != nullptr && hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive)
         return fail(ICD_ERR_UNSUPPORTED, "icd_encoder_encode_many reads its token ids from host memory at call time: it cannot be captured into a graph");
-    // (a device-output call of icd_encoder_encode may still be reading h_meta / writing through d_meta's graph: same stream order
-    //  protects d_meta; h_meta is not touched here)
+    // (a device-output call of icd_encoder_encode may still be reading h_meta: not touched here; d_meta and the activations are
+    //  protected by stream order, across streams by ev_tail)
+    { const int rc = enc_tail_wait(e, s); if (rc) return rc; }
     const size_t H = (size_t)d.hidden;
     int64_t b0 = 0, t0 = 0;
     if (total > ENC_TMAX || nseq > ENC_BMAX) {
@@ -584,7 +609,7 @@ int icd_encoder_encode_many(icd_encoder *e, const int32_t *ids, const int32_t *l
             slot ^= 1;
         }
         if (!out_on_device) HIP_TRY(hipStreamSynchronize(s));
-        return ICD_OK;
+        return enc_tail_mark(e, s, !out_on_device);
     }
     int slot = 0;
     while (b0 < nseq) {
@@ -604,7 +629,7 @@ int icd_encoder_encode_many(icd_encoder *e, const int32_t *ids, const int32_t *l
         slot = (slot + 1) % icd_encoder::RING;
     }
     if (!out_on_device) HIP_TRY(hipStreamSynchronize(s));
-    return ICD_OK;
+    return enc_tail_mark(e, s, !out_on_device);
 }
 
 }  // extern "C"

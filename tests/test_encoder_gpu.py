@@ -582,3 +582,46 @@ def test_both_arithmetics_of_the_canonical_encoder(arithmetic):
         assert worst <= (5e-7 if arithmetic == "fp32" else TOL)
     finally:
         enc.close()
+
+
+@pytest.mark.gpu
+def test_calls_on_different_streams_share_the_handles_workspace_in_order():
+    """The activations belong to the handle, not to a stream. A device-output call returns without waiting; the next call may
+    come on ANOTHER stream (a serving process: the build thread's batches beside a request's query) and must not start on the
+    workspace before the first has left it (csrc/icd_encoder.hpp ev_tail: a device-side wait, the host never blocks). Every
+    combination of the two call forms on two streams, results against the same calls made one stream, one at a time."""
+    import torch
+    from transformers import BertConfig, BertModel
+    from rag_project_icd10_amd import _native
+    torch.manual_seed(5)
+    model = BertModel(BertConfig(vocab_size=2000, hidden_size=768, num_hidden_layers=4, num_attention_heads=12, intermediate_size=3072,
+                                 max_position_embeddings=512), add_pooling_layer=False).eval().cuda()
+    enc = _native.SmallEncoder(model)
+    rng = np.random.default_rng(2)
+    big = [[int(v) for v in rng.integers(5, 2000, size=int(n))] for n in rng.integers(20, 120, 200)]     # ~14 000 tokens: two passes of the batch form
+    mid = [[int(v) for v in rng.integers(5, 2000, size=int(n))] for n in rng.integers(5, 40, 30)]        # several small calls from the ring
+    one = [[int(v) for v in rng.integers(5, 2000, size=33)]]
+    try:
+        want = {"big": enc.encode_many(big), "mid": enc.encode_many(mid), "one": enc.encode(one)}
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        calls = {"big": lambda: enc.encode_many(big, to_device=True), "mid": lambda: enc.encode_many(mid, to_device=True),
+                 "one": lambda: enc.encode(one, to_device=True)}
+        for first in ("big", "mid", "one"):
+            for second in ("big", "mid", "one"):
+                for _ in range(3):
+                    with torch.cuda.stream(s1):
+                        a = calls[first]()
+                    with torch.cuda.stream(s2):
+                        b = calls[second]()
+                    torch.cuda.synchronize()
+                    assert np.array_equal(a.cpu().numpy(), want[first]), (first, second, "first call")
+                    assert np.array_equal(b.cpu().numpy(), want[second]), (first, second, "second call")
+        # ... and a host-output call behind a device-output one on another stream
+        with torch.cuda.stream(s1):
+            a = enc.encode_many(big, to_device=True)
+        with torch.cuda.stream(s2):
+            b = enc.encode(one)
+        torch.cuda.synchronize()
+        assert np.array_equal(a.cpu().numpy(), want["big"]) and np.array_equal(b, want["one"])
+    finally:
+        enc.close()
