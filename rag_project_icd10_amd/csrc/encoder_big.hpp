@@ -73,6 +73,7 @@ struct EncBigLinearArgs {
     const float *res_stats, *res_g, *res_b;
     float *y;              // [T][N]: operand order (OUT_PA) or row-major
     int T, K, N;
+    unsigned long long *stamps;   // diagnostic builds (ICD_ABLATE): 7 x (s_memtime, s_memrealtime) of wave 0 of a work-group in the middle of the grid; nullptr = none
     int pps;               // K pieces per slice: K = 16 ITER pps SLICES (4 where the small form's four waves cover K; inter / (64 ITER) for the FFN-down GEMM's four slabs)
 };
 // ITER: 16-column k-steps per K piece (12: hidden 768 / inter 3 072; 16: hidden 1 024 / inter 4 096); TM x TN: tiles of 16 tokens x
@@ -83,6 +84,14 @@ struct EncBigLinearArgs {
 // (measured and NOT kept, round 6: the W fragments of a pair through LDS - each wave loads a quarter, all four read all of them
 //  back, one barrier per pair: 394 against 228 us for the FFN-down GEMM; the four waves share their W fragments through the L1
 //  well enough, and the barrier puts the LDS round trip on every pair's critical path: profiles/r06_encoder_big_bf_sweep.log)
+#ifdef ICD_ABLATE
+#define ENC_BIG_STAMP(i) do { if (a.stamps && blockIdx.x == 1 && blockIdx.y == gridDim.y / 2 && threadIdx.x == 0) { __builtin_amdgcn_sched_barrier(0); \
+    a.stamps[2 * (i)] = __builtin_amdgcn_s_memtime(); a.stamps[2 * (i) + 1] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define ENC_BIG_DRAIN() do { if (a.stamps) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); } while (0)
+#else
+#define ENC_BIG_STAMP(i) do { } while (0)
+#define ENC_BIG_DRAIN() do { } while (0)
+#endif
 template <int ITER, int TM, int TN, int EPI, bool LNPRO, bool OUT_PA, int SLICES, int PF = 1, bool BF = false>
 __global__ __launch_bounds__(256) void enc_linear_big_kernel(EncBigLinearArgs a) {
     extern __shared__ char enc_big_occupancy_pin[];   // (never touched: the launch asks for more than half a CU's LDS so that a CU holds ONE work-group - see icd_encoder.hpp)
@@ -90,6 +99,7 @@ __global__ __launch_bounds__(256) void enc_linear_big_kernel(EncBigLinearArgs a)
     constexpr int STEPS = ITER / 2;           // an iteration: two k-steps (one MFMA group of each chain)
     constexpr int NBUF = PF + 1;
     static_assert(STEPS % NBUF == 0, "the register ring returns to buffer 0 at every piece");
+    ENC_BIG_STAMP(0);   // the first kernel argument is here
     const int NPIECE = a.pps * SLICES;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
@@ -132,6 +142,28 @@ __global__ __launch_bounds__(256) void enc_linear_big_kernel(EncBigLinearArgs a)
     }
     load_pair(0, 0, 0);
     if constexpr (PF == 2) load_pair(1, 0, 1);
+    // the epilogue's inputs, requested NOW: a work-group is one wave per SIMD, nothing fills a round trip to memory - the statistics and the
+    // residual rows arrive under the K walk instead of after it (the chain arguments -> first fragments -> ... -> epilogue inputs, every link
+    // a round trip, is ~8 us of each work-group's ~25: profiles/r06_encoder_big_ring_ablation.log)
+    float ln_mean[TM][4], ln_rstd[TM][4], rs_mean[TM][4], rs_rstd[TM][4], rs_src[TM][4][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = (tt0 + m) * 16 + 4 * kq + j;
+            const bool live = t < a.T;
+            ln_mean[m][j] = ln_rstd[m][j] = rs_mean[m][j] = rs_rstd[m][j] = 0.f;
+            if constexpr (LNPRO) { if (live) { ln_mean[m][j] = a.stats[2 * t]; ln_rstd[m][j] = a.stats[2 * t + 1]; } }
+            if constexpr (EPI == 2) { if (live) { rs_mean[m][j] = a.res_stats[2 * t]; rs_rstd[m][j] = a.res_stats[2 * t + 1]; } }
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+                rs_src[m][j][n] = 0.f;
+                if constexpr (EPI == 2) { if (live) rs_src[m][j][n] = a.res_src[enc_pa(t, (ct0 + n) * 16 + r16, a.N, KW)]; }
+            }
+        }
+    ENC_BIG_STAMP(1);   // bias, first fragments, epilogue inputs requested
+    ENC_BIG_DRAIN();
+    ENC_BIG_STAMP(2);   // ... and here
 #pragma unroll 1
     for (int sl = 0; sl < SLICES; ++sl) {
         enc_f32x4 s[TM][TN];
@@ -142,6 +174,7 @@ __global__ __launch_bounds__(256) void enc_linear_big_kernel(EncBigLinearArgs a)
 #pragma unroll 1
         for (int pw = 0; pw < a.pps; ++pw) {
             const int piece = sl * a.pps + pw;
+            if (piece == 1) ENC_BIG_STAMP(3);   // the first piece (six pairs of k-steps) done
             enc_f32x4 c0[TM][TN], c1[TM][TN];
 #pragma unroll
             for (int m = 0; m < TM; ++m)
@@ -192,20 +225,16 @@ __global__ __launch_bounds__(256) void enc_linear_big_kernel(EncBigLinearArgs a)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) s[m][n][j] += c0[m][n][j] + c1[m][n][j];
         }
+        if (sl == SLICES - 1) ENC_BIG_STAMP(4);   // the K walk done (the accumulators may still be in the pipe)
         // the slice's epilogue (slab `sl` of the small form), added to the output in slab order
 #pragma unroll
         for (int m = 0; m < TM; ++m) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int t = (tt0 + m) * 16 + 4 * kq + j;
-                const bool live = t < a.T;
-                float mean = 0.f, rstd = 0.f, rmean = 0.f, rrstd = 0.f;
-                if constexpr (LNPRO) { if (live) { mean = a.stats[2 * t]; rstd = a.stats[2 * t + 1]; } }
-                if constexpr (EPI == 2) { if (live && sl == 0) { rmean = a.res_stats[2 * t]; rrstd = a.res_stats[2 * t + 1]; } }
+                const float mean = ln_mean[m][j], rstd = ln_rstd[m][j], rmean = rs_mean[m][j], rrstd = rs_rstd[m][j];   // (rows past T: zeros, never stored; slices past the first ignore the residual)
 #pragma unroll
                 for (int n = 0; n < TN; ++n) {
-                    float rsrc = 0.f;
-                    if constexpr (EPI == 2) { if (live && sl == 0) rsrc = a.res_src[enc_pa(t, (ct0 + n) * 16 + r16, a.N, KW)]; }
+                    const float rsrc = rs_src[m][j][n];
                     const float e = enc_epilogue<EPI, LNPRO>(s[m][n][j], sl == 0, mean, rstd, c1_v[n], bias_v[n], rsrc, rmean, rrstd, rg[n], rb[n]);
                     if (sl == 0) v[m][n][j] = e;
                     else v[m][n][j] += e;
@@ -213,6 +242,7 @@ __global__ __launch_bounds__(256) void enc_linear_big_kernel(EncBigLinearArgs a)
             }
         }
     }
+    ENC_BIG_STAMP(5);   // epilogue arithmetic done
 #pragma unroll
     for (int m = 0; m < TM; ++m)
 #pragma unroll
@@ -226,6 +256,8 @@ __global__ __launch_bounds__(256) void enc_linear_big_kernel(EncBigLinearArgs a)
                 else a.y[(size_t)t * a.N + col] = v[m][n][j];
             }
         }
+    ENC_BIG_DRAIN();
+    ENC_BIG_STAMP(6);   // stores acknowledged
 }
 
 }  // namespace icd

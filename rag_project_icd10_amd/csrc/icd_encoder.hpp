@@ -242,7 +242,7 @@ inline int enc_big_enqueue_t(icd_encoder *e, int T, int nb, int pooling, int nor
         {   // Q | K | V = LayerNorm(y0) Wqkv^T + b
             EncBigLinearArgs a{};
             a.x = y0; a.stats = g.sA; a.c1 = e->c1_qkv[l]; a.w = e->w_qkv[l]; a.NT = 16; a.bias = e->c2_qkv[l]; a.y = g.qkv;
-            a.T = T; a.K = H; a.N = 3 * H; a.pps = H / KW;
+            a.T = T; a.K = H; a.N = 3 * H; a.pps = H / KW; a.stamps = (e->stamps && l == d.layers - 1) ? e->stamps : nullptr;
             hipLaunchKernelGGL(k_qkv, dim3(3 * H / (16 * TNQ), gy), dim3(256), lds_pin, s, a);
         }
         {
@@ -264,20 +264,20 @@ inline int enc_big_enqueue_t(icd_encoder *e, int T, int nb, int pooling, int nor
         {   // y1 = ctx Wo^T + b + LayerNorm(y0)
             EncBigLinearArgs a{};
             a.x = g.ctx; a.w = e->w_ao[l]; a.NT = 8; a.bias = e->b_ao[l];
-            a.res_src = y0; a.res_stats = g.sA; a.res_g = pg; a.res_b = pb; a.y = y1; a.T = T; a.K = H; a.N = H; a.pps = H / KW;
+            a.res_src = y0; a.res_stats = g.sA; a.res_g = pg; a.res_b = pb; a.y = y1; a.T = T; a.K = H; a.N = H; a.pps = H / KW; a.stamps = (e->stamps && l == d.layers - 1) ? e->stamps + 16 : nullptr;
             hipLaunchKernelGGL(k_ao, dim3(H / (16 * TNO), gy), dim3(256), lds_pin, s, a);
         }
         stats(y1, g.sB);
         {   // mid = GELU(LayerNorm1(y1) Wup^T + b)
             EncBigLinearArgs a{};
             a.x = y1; a.stats = g.sB; a.c1 = e->c1_up[l]; a.w = e->w_up[l]; a.NT = 16; a.bias = e->c2_up[l]; a.y = g.mid;
-            a.T = T; a.K = H; a.N = I; a.pps = H / KW;
+            a.T = T; a.K = H; a.N = I; a.pps = H / KW; a.stamps = (e->stamps && l == d.layers - 1) ? e->stamps + 32 : nullptr;
             hipLaunchKernelGGL(k_up, dim3(I / (16 * TNU), gy), dim3(256), lds_pin, s, a);
         }
         {   // y2 = mid Wdown^T + b + LayerNorm1(y1): the small form's ENC_SLABS K slices, added in slab order
             EncBigLinearArgs a{};
             a.x = g.mid; a.w = e->w_down[l]; a.NT = 16; a.bias = e->b_down[l];
-            a.res_src = y1; a.res_stats = g.sB; a.res_g = e->ln1_g[l]; a.res_b = e->ln1_b[l]; a.y = y2; a.T = T; a.K = I; a.N = H; a.pps = I / KW / ENC_SLABS;
+            a.res_src = y1; a.res_stats = g.sB; a.res_g = e->ln1_g[l]; a.res_b = e->ln1_b[l]; a.y = y2; a.T = T; a.K = I; a.N = H; a.pps = I / KW / ENC_SLABS; a.stamps = (e->stamps && l == d.layers - 1) ? e->stamps + 48 : nullptr;
             hipLaunchKernelGGL(l == d.layers - 1 ? k_down_last : k_down, dim3(H / (16 * TNO), gy), dim3(256), lds_pin, s, a);
         }
         cur = (cur + 2) % 3;
