@@ -38,6 +38,9 @@ bash scripts/gpu_encoder_big_profile.sh $TAG 4000 < /dev/null > gpurun_out/encod
 # (the tile sweeps of the batch form - scripts/gpu_encoder_big_sweep.sh (fp32 arithmetic: ICD_ENCODER_ARITH=fp32), gpu_encoder_big_bf_sweep.sh - ran mid-round on
 #  the diagnostic build of their moment: profiles/r06_encoder_big_sweep.log, r06_encoder_big_bf_sweep.log)
 (timeout 300 python3 scripts/probe/encode_many_probe.py 2>&1 < /dev/null | grep -v "amdgpu.ids\|SYNTHETIC") > gpurun_out/${TAG}_encode_many_probe.log
+# ... what bounds its GEMMs: PMC counters per kernel, clock stamps inside a work-group (diagnostic build csrc/abe)
+bash scripts/gpu_encoder_big_pmc.sh $TAG 2000 < /dev/null > gpurun_out/encoder_big_pmc_$TAG.out 2>&1   # -> gpurun_out/${TAG}_encoder_big_pmc.json
+if [ -f rag_project_icd10_amd/csrc/abe/libicdsearch.so ]; then (timeout 300 python3 scripts/probe/encoder_big_stamps.py 440 2>&1 < /dev/null | grep -v "amdgpu.ids\|not resolvable\|SYNTHETIC") > gpurun_out/${TAG}_encoder_big_stamps.log; fi
 (timeout 300 python3 scripts/probe/encoder_arith_probe.py 2>&1 < /dev/null | grep -v "amdgpu.ids\|SYNTHETIC") > gpurun_out/${TAG}_encoder_arith.log
 (ICD_ENCODER_ARITH=fp32 timeout 600 python -m pytest tests/test_encoder_gpu.py tests/test_ner_gpu.py -q -m gpu 2>&1 < /dev/null | tail -2) > gpurun_out/${TAG}_pytest_encoder_fp32_arith.log
 (timeout 400 python3 scripts/probe/k100_lists.py 2>&1 < /dev/null | grep -v amdgpu.ids) > gpurun_out/${TAG}_k100_lists.log
