@@ -373,7 +373,9 @@ int icd_encoder_create(int32_t device, const icd_encoder_desc *desc, icd_encoder
  * their sum <= ICD_ENCODER_MAX_TOKENS. pooling 0 = mean over a sequence's tokens, 1 = its first token; normalize 1 =
  * torch.nn.functional.normalize(p = 2). out: [nseq][hidden] fp32, host (the call returns when it is filled) or device
  * (out_on_device = 1: enqueued on `stream`, no synchronisation). hidden_out: NULL, or a DEVICE buffer [sum lengths][hidden]
- * that receives the last hidden state of every token (token classification heads). Calls on one handle are serialised. */
+ * that receives the last hidden state of every token (token classification heads). Calls on one handle are serialised; the
+ * handle's activations belong to the handle, not to a stream: a call on ANOTHER stream than the one before waits on the device
+ * (an event, no host block) until that call's work has left them - icd_encoder_encode and icd_encoder_encode_many alike. */
 int icd_encoder_encode(icd_encoder *e, const int32_t *ids, const int32_t *lengths, int32_t nseq, int32_t pooling, int32_t normalize,
                        float *out, int32_t out_on_device, float *hidden_out, void *stream);
 /* ANY number of sequences through the same kernels, in calls of at most ICD_ENCODER_MAX_TOKENS tokens / ICD_ENCODER_MAX_SEQS
