@@ -668,6 +668,82 @@ def two_streams_extra(ctx, args, index_factory, corpus, levels, queries, k, step
     return obj
 
 
+def host_buffers_extra(ctx, args, index_factory, corpus, levels, queries, k, steps):
+    """The PCIe-inclusive rates (never `value`, which starts with its inputs resident in HBM): the headline batch handed over in HOST
+    memory through the C ABI's host pointers - pageable numpy arrays, then the same arrays in pinned memory - and what a host
+    application reaches with the DEVICE-pointer ABI when it pipelines for itself: batch i + 1's queries on their way over PCIe (a
+    copy stream, pinned staging) and batch i - 1's results on their way back while batch i searches. Results of every form against
+    the device-resident call's (which the line checks against the oracle), bit for bit."""
+    from rag_project_icd10_amd._native import MODE_AUTO
+    torch = ctx.torch
+    index = index_factory(corpus, levels, ctx.local_rank, len(queries), max(k, 10))
+    dq = torch.from_numpy(queries).to(ctx.dev)
+    ref = [t.cpu().numpy() for t in index.search_reweighted(dq, k, MODE_AUTO)]
+    obj = {"workload": f"the headline batch ({len(queries)} x {queries.shape[1]} fp32 queries, {queries.nbytes / 1e6:.1f} MB in, "
+                       f"{sum(r.nbytes for r in ref) / 1e6:.2f} MB out per step) from and to HOST memory"}
+
+    def timed(fn, n):
+        for _ in range(3):
+            out = fn()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = fn()
+        ctx.sync()
+        return (time.perf_counter() - t0) / n * 1e3, out
+
+    same = lambda out: bool(all(np.array_equal(np.asarray(a), b) for a, b in zip(out, ref)))
+    ms, out = timed(lambda: index.search_reweighted(queries, k, MODE_AUTO), steps)
+    obj["pageable"] = {"ms_per_step": ms, "queries_per_sec": len(queries) / ms * 1e3, "equal_to_device_call": same(out),
+                       "what": "icd_index_search_reweighted with host pointers (numpy arrays): H2D, search, D2H, one after the other"}
+    pinned_q = torch.from_numpy(queries).pin_memory()
+    ms, out = timed(lambda: index.search_reweighted(pinned_q.numpy(), k, MODE_AUTO), steps)
+    obj["pinned"] = {"ms_per_step": ms, "queries_per_sec": len(queries) / ms * 1e3, "equal_to_device_call": same(out),
+                     "what": "the same call, the query array in pinned host memory"}
+    # pipelined by the caller over the device-pointer ABI: two device query buffers, a copy stream each way, pinned result blocks
+    cs_in, cs_out, main = torch.cuda.Stream(device=ctx.dev), torch.cuda.Stream(device=ctx.dev), torch.cuda.current_stream(ctx.dev)
+    dbuf = [torch.empty_like(dq), torch.empty_like(dq)]
+    hres = [[torch.empty(r.shape, dtype=torch.from_numpy(r).dtype).pin_memory() for r in ref] for _ in range(2)]
+    ev_in = [torch.cuda.Event(), torch.cuda.Event()]
+    ev_done = [torch.cuda.Event(), torch.cuda.Event()]
+    ev_out = [torch.cuda.Event(), torch.cuda.Event()]
+
+    def pipeline(n):
+        with torch.cuda.stream(cs_in):
+            dbuf[0].copy_(pinned_q, non_blocking=True)
+            ev_in[0].record(cs_in)
+        for i in range(n):
+            b = i & 1
+            if i + 1 < n:
+                with torch.cuda.stream(cs_in):
+                    if i >= 1:
+                        cs_in.wait_event(ev_done[1 - b])          # (the search that read this buffer two steps ago has finished)
+                    dbuf[1 - b].copy_(pinned_q, non_blocking=True)
+                    ev_in[1 - b].record(cs_in)
+            main.wait_event(ev_in[b])
+            outs = index.search_reweighted(dbuf[b], k, MODE_AUTO)
+            ev_done[b].record(main)
+            with torch.cuda.stream(cs_out):
+                cs_out.wait_event(ev_done[b])
+                if i >= 2:
+                    ev_out[b].synchronize()                        # (the host has had this pinned block since two steps ago)
+                for h, o in zip(hres[b], outs):
+                    h.copy_(o, non_blocking=True)
+                    o.record_stream(cs_out)
+                ev_out[b].record(cs_out)
+        ctx.sync()
+        return [h.numpy() for h in hres[(n - 1) & 1]]
+
+    pipeline(4)
+    t0 = time.perf_counter()
+    out = pipeline(steps)
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    obj["pipelined_by_the_caller"] = {"ms_per_step": ms, "queries_per_sec": len(queries) / ms * 1e3, "equal_to_device_call": same(out), "steps": steps,
+                                      "what": "device-pointer calls; batch i + 1's H2D (pinned, a copy stream) and batch i - 1's D2H under batch i's search"}
+    index.close()
+    return obj
+
+
 def _side_workload(ctx, args, index_factory, name, corpus, levels, queries, k, mode, steps, first_batch=False):
     """one of the line's `extra` objects: the same step on other data / another size / the exact kernel alone, timed
     over `steps` steps after a short warm-up and checked against the oracle on every query, in this run.
@@ -829,6 +905,11 @@ def run_replicated(ctx, args, index_factory=hip_index_factory):
                 ex["two_streams"] = two_streams_extra(ctx, args, index_factory, corpus, levels, queries, k, steps_x)
             except Exception as exc:   # pragma: no cover - reported, never fatal
                 ex["two_streams"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if mode == MODE_AUTO and not ctx.cpu_only:
+            try:
+                ex["host_buffers"] = host_buffers_extra(ctx, args, index_factory, corpus, levels, queries, k, steps_x)
+            except Exception as exc:   # pragma: no cover - reported, never fatal
+                ex["host_buffers"] = {"error": f"{type(exc).__name__}: {exc}"}
         if mode == MODE_AUTO:
             ex["exact_mode"] = side_workload(ctx, args, index_factory, f"--mode exact: the fp32-MFMA kernel alone, {nq} x {n}x768",
                                              corpus, levels, queries, k, MODE_EXACT, max(3, steps_x // 4))
