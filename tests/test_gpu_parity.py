@@ -1392,3 +1392,31 @@ def test_pack_winners_carries_int64_ids_as_bit_patterns():
     assert torch.equal(out[3], order[:, :kk].double().cpu())
     for plane, t in zip((4, 5, 6, 7), (enh, vs, hb, boost)):
         assert torch.equal(out[plane], t[:, :kk].cpu())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nq", [30, 2000])
+def test_host_query_arrays_pageable_pinned_and_offset_views_give_the_device_calls_results(oracle, nq):
+    """The ABI takes host pointers (include/icd_search.h: `queries_on_device` 0): a large query array goes through the runtime's
+    copy - pageable or PINNED, whole or a view that starts in the middle of an allocation - a small one through the handle's pinned
+    block; every form gives what the device-resident call gives (bench.py extra.host_buffers prices them)."""
+    import torch
+    n, dim, k = 20000, 768, 10
+    corpus, levels = unit_rows(n, dim, 171), icd_levels(n, 172)
+    queries = unit_rows(nq + 5, dim, 173)
+    idx = IcdIndex(corpus, levels, max_nq=nq, max_k=10)
+    try:
+        want = [t.cpu().numpy() for t in idx.search_reweighted(torch.from_numpy(queries[5:]).cuda(), k)]
+        os_, oi = oracle.flat_ip_topk(corpus, queries[5:], k)
+        w_adj, w_raw, w_ids, w_lv = oracle.reweight(os_, oi, levels)
+        assert np.array_equal(want[2], w_ids) and np.array_equal(want[0], w_adj)
+        pinned = torch.from_numpy(queries).pin_memory()
+        forms = {"pageable": queries[5:].copy(), "pinned": pinned[5:].numpy(), "pageable view": queries[5:]}
+        assert forms["pinned"].ctypes.data == pinned.data_ptr() + 5 * dim * 4
+        for name, arr in forms.items():
+            for _ in range(2):
+                got = idx.search_reweighted(arr, k)
+                for g, w in zip(got, want):
+                    assert np.array_equal(g, w), (name, nq)
+    finally:
+        idx.close()
