@@ -865,7 +865,11 @@ def run_replicated(ctx, args, index_factory=hip_index_factory):
                          "traffic_unit": "bytes per launch (rocprofv3 PMC passes of this kernel, 2 x FETCH_SIZE + WRITE_SIZE); a citation "
                                          "of the committed profile of this workload, not measured in this run",
                          "flops_per_launch": flops, "launch_ms": dom_ms, "launches_averaged": prof["count"],
-                         "launches_sampled": f"every {args.profile_every}th step of the timed region carries hipEvents"},
+                         "launches_sampled": f"every {args.profile_every}th step of the timed region carries hipEvents",
+                         #  the WHOLE step priced the same way: the kernel's algorithmic flops over ms_per_step - what the
+                         # prep, finalize and gated launches around the dominant kernel cost the step
+                         "whole_step": {"achieved": flops / (elapsed / args.steps) / 1e12, "frac": flops / (elapsed / args.steps) / 1e12 / peak,
+                                        "what": "flops_per_launch / ms_per_step: the dominant kernel's algorithmic work over the whole step's wall time"}},
             "extra": {"windows": {"what": f"the {args.steps}-step window repeated {1 + len(info['repeat_s'])} times back to back (the first is `value`), ms per step",
                                   "min": per_step[0], "median": per_step[len(per_step) // 2], "max": per_step[-1],
                                   "first_window_of_the_process": (info["first_window_s"] / args.steps * 1e3) if info["first_window_s"] else None}},
