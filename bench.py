@@ -150,6 +150,8 @@ def cpu_baseline(corpus, levels, queries, k, budget_s=12.0, with_encoder=True):
             c40 = unit_rows(40474, corpus.shape[1], 1234)
             l40 = icd_levels(40474, 1235)
             orc.reference_shaped_search(c40, l40, queries[0], 5)
+            # (a BOUNDED sample: at most 32 strings and ~30 s - a loaded or oversubscribed host has run this forward at 0.6 s and, once, at
+            #  minutes per string; the line must still come out within minutes)
             vecs, d_enc, d_search = [], 0.0, 0.0
             for t in texts[:32]:
                 t0 = time.perf_counter()
@@ -160,19 +162,23 @@ def cpu_baseline(corpus, levels, queries, k, budget_s=12.0, with_encoder=True):
                 d_enc += t1 - t0
                 d_search += t2 - t1
                 vecs.append(v)
+                if d_enc + d_search > 30.0 and len(vecs) >= 4:
+                    break
+            ns = len(vecs)
             _CPU_CONFIG0["vectors"] = np.stack(vecs)
             d1 = d_enc
-            extra["config0"] = {"value": 32 / (d_enc + d_search), "unit": "strings/s", "kind": "port",
-                                "sample": "32 of the 100 golden strings: encode_query one per call (HF BertModel fp32 on the CPU, synthetic weights) -> "
+            extra["config0"] = {"value": ns / (d_enc + d_search), "unit": "strings/s", "kind": "port",
+                                "sample": f"{ns} of the 100 golden strings: encode_query one per call (HF BertModel fp32 on the CPU, synthetic weights) -> "
                                           "reference-shaped search (oracle/oracle.py), top_k=5, 40474x768 fp32 rows",
-                                "encode_ms_per_string": d_enc / 32 * 1e3, "search_ms_per_string": d_search / 32 * 1e3,
+                                "encode_ms_per_string": d_enc / ns * 1e3, "search_ms_per_string": d_search / ns * 1e3,
                                 "cores": int(np_threads or os.cpu_count() or threads)}
-            t0 = time.perf_counter()
-            emb.encode_batch(texts[32:160], show_progress=False)
-            d2 = time.perf_counter() - t0
-            extra["encoder_reference_shaped"] = {"value": 32 / d1, "unit": "strings/s", "sample": "32 strings, encode_query one per call (batch 1)",
+            extra["encoder_reference_shaped"] = {"value": ns / d1, "unit": "strings/s", "sample": f"{ns} strings, encode_query one per call (batch 1)",
                                                  "synthetic_weights": bool(emb.get_model_info().get("synthetic"))}
-            extra["encoder_embed_shaped"] = {"value": 128 / d2, "unit": "strings/s", "sample": "128 strings, encode_batch (batch 32)"}
+            nb = 128 if d1 / ns < 0.5 else 32   # (the batch-32 leg too: a quarter of it on a host that slow)
+            t0 = time.perf_counter()
+            emb.encode_batch(texts[32:32 + nb], show_progress=False)
+            d2 = time.perf_counter() - t0
+            extra["encoder_embed_shaped"] = {"value": nb / d2, "unit": "strings/s", "sample": f"{nb} strings, encode_batch (batch 32)"}
         except Exception as exc:
             extra["encoder"] = {"error": str(exc)}
     out["extra"] = extra
