@@ -10,6 +10,7 @@ cut to top_k; 503 when services are missing, 500 with a `detail` string on any e
 from __future__ import annotations
 
 import logging
+import os
 from contextlib import asynccontextmanager
 
 from fastapi import FastAPI, HTTPException
@@ -43,7 +44,19 @@ async def lifespan(app: FastAPI):
         from ..services.embedding_service import EmbeddingService
         from ..services.milvus_service import MilvusService
         emb = EmbeddingService()
-        install_services(emb, MilvusService(emb))
+        mil = MilvusService(emb)
+        # like the reference's MultiDiagnosisService (services/multi_diagnosis_service.py:28,44-47): an NER service - its classifier when the
+        # checkpoint resolves, its rules otherwise - and with it the ENHANCED text mode (entities fused with semantic boundaries);
+        # ICD_QUERY_NER=0: neither (delimiter extraction, the whole request on the device)
+        ner = None
+        if os.getenv("ICD_QUERY_NER", "1") != "0":
+            try:
+                from ..services.medical_ner_service import MedicalNERService
+                ner = MedicalNERService()
+            except Exception as exc:
+                logger.error("no NER service (%s): /query extracts by delimiters", exc)
+        from ..services.multi_diagnosis_service import MultiDiagnosisService
+        install_services(emb, mil, MultiDiagnosisService(emb, mil, ner_service=ner))
     try:
         yield
     finally:

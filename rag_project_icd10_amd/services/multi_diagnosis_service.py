@@ -63,7 +63,8 @@ class MultiDiagnosisService:
         self.ner_service = ner_service
         self.hierarchical_similarity = HierarchicalSimilarityService(embedding_service=embedding_service,
                                                                      ner_service=ner_service)
-        self.text_processor = DiagnosisTextProcessor(embedding_service=embedding_service)
+        # the reference's default text mode is "enhanced" (entities + semantic boundaries, :44-47): here whenever there is an NER service
+        self.text_processor = DiagnosisTextProcessor(embedding_service=embedding_service, ner_service=ner_service)
         # row N3: only the embedding cosine and the score statistics of the reference's confidence service
         self.confidence_service = MultiDimensionalConfidenceService(
             embedding_service=embedding_service, hierarchical_similarity_service=self.hierarchical_similarity)
@@ -93,7 +94,7 @@ class MultiDiagnosisService:
                     "total_matches": sum(len(m.candidates) for m in matches), "processing_mode": mode,
                     "extraction_metadata": {"enhanced_results_count": len(enhanced),
                                             "avg_extraction_confidence": sum(confs) / len(confs),
-                                            "extraction_method": "simple", "drug_filtering_enabled": False}}
+                                            "extraction_method": mode, "drug_filtering_enabled": mode == "enhanced"}}
         # The entities of the request's diagnoses do not depend on their embeddings: the token classifier runs in a worker thread on
         # its own stream WHILE this thread embeds and searches (both forwards are latency-bound - a few work-groups each, csrc/
         # encoder_small.hpp - and overlap almost entirely: a one-diagnosis request with NER 1.14 -> 0.8 ms). Same results either way.
@@ -110,7 +111,7 @@ class MultiDiagnosisService:
                 "total_matches": sum(len(m.candidates) for m in matches), "processing_mode": mode,
                 "extraction_metadata": {"enhanced_results_count": len(enhanced),
                                         "avg_extraction_confidence": sum(confs) / len(confs),
-                                        "extraction_method": "simple", "drug_filtering_enabled": False}}
+                                        "extraction_method": mode, "drug_filtering_enabled": mode == "enhanced"}}
 
     def _ner_pool(self):
         pool = getattr(self, "_ner_executor", None)

@@ -166,11 +166,17 @@ def test_request_path_extracts_all_entities_in_one_batch():
     ner.extract_medical_entities_batch = lambda texts, filter_drugs=True: calls.append(list(texts)) or inner(texts, filter_drugs)
     md = MultiDiagnosisService(Emb(), Milvus(), ner_service=ner)
     got = md.match_multiple_diagnoses("急性心肌梗死；高血压病", top_k=2)
-    assert calls == [["急性心肌梗死", "高血压病"]]
+    # with an NER service the text mode is the reference's default, "enhanced": the TEXT's entities first (one call: they are fused
+    # with its boundaries into the diagnoses), then ONE batch for the diagnoses' own
+    assert got["processing_mode"] == "enhanced" and got["extraction_metadata"]["extraction_method"] == "enhanced"
+    assert sorted(got["extracted_diagnoses"]) == sorted(["急性心肌梗死", "高血压病"])
+    assert calls == [["急性心肌梗死；高血压病"], got["extracted_diagnoses"]]
     plain = MultiDiagnosisService(Emb(), Milvus())
-    for d, m in zip(["急性心肌梗死", "高血压病"], got["matches"]):
+    for d, m in zip(got["extracted_diagnoses"], got["matches"]):
         want = plain._match_from_hits(d, hits(), 2, MedicalNERService(use_model=False).extract_medical_entities(d))
         assert [(c.code, c.score, c.similarity_factors) for c in m.candidates] == \
                [(c.code, c.score, c.similarity_factors) for c in want.candidates]
     without = plain.match_multiple_diagnoses("急性心肌梗死；高血压病", top_k=2)
-    assert got["matches"][0].candidates[0].score != without["matches"][0].candidates[0].score
+    assert without["processing_mode"] == "simple" and without["extracted_diagnoses"] == ["急性心肌梗死", "高血压病"]
+    first = without["extracted_diagnoses"].index(got["extracted_diagnoses"][0])
+    assert got["matches"][0].candidates[0].score != without["matches"][first].candidates[0].score
