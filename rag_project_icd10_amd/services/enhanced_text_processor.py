@@ -43,11 +43,17 @@ class EnhancedTextProcessor:
         if not text or not text.strip():
             return []
         try:
-            entities = self.ner_service.extract_medical_entities(text, filter_drugs=filter_drugs)
             if self.config["use_semantic_boundary"] and self.embedding_service:
-                boundaries = self.boundary_detector.detect_diagnosis_boundaries(text)
-                confidences = self.boundary_detector.get_boundary_confidence(boundaries)
+                # the text's entities and its boundaries do not depend on each other: the token classifier runs in a worker thread (its
+                # own encoder handle and stream) while this thread embeds the segments - both forwards are latency-bound and overlap
+                job = self._pool().submit(self.ner_service.extract_medical_entities, text, filter_drugs=filter_drugs)
+                try:
+                    boundaries = self.boundary_detector.detect_diagnosis_boundaries(text)
+                    confidences = self.boundary_detector.get_boundary_confidence(boundaries)
+                finally:
+                    entities = job.result()
             else:
+                entities = self.ner_service.extract_medical_entities(text, filter_drugs=filter_drugs)
                 boundaries = self._simple_boundary_detection(text)
                 confidences = [0.5] * len(boundaries)
             fused = self._fuse_entity_boundary_info(text, entities, boundaries, confidences)
@@ -55,6 +61,13 @@ class EnhancedTextProcessor:
         except Exception as exc:
             logger.error("enhanced diagnosis extraction failed: %s", exc)
             return self._fallback_extraction(text)
+
+    def _pool(self):
+        pool = getattr(self, "_executor", None)
+        if pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = self._executor = ThreadPoolExecutor(max_workers=1, thread_name_prefix="icd-text-ner")
+        return pool
 
     # ---- delimiter boundaries (no encoder; also the fallback) -----------------------------------------------------------------------
     def _pieces(self, text: str, parts: List[str]) -> List[Boundary]:

@@ -99,7 +99,7 @@ class MultiDiagnosisService:
         # its own stream WHILE this thread embeds and searches (both forwards are latency-bound - a few work-groups each, csrc/
         # encoder_small.hpp - and overlap almost entirely: a one-diagnosis request with NER 1.14 -> 0.8 ms). Same results either way.
         ner_job = self._ner_pool().submit(self._entities_of, diagnoses) if self.ner_service else None
-        vectors = self.embedding_service.encode_query_batch(diagnoses)
+        vectors = self._embed_diagnoses(diagnoses)
         try:
             hit_lists = self.milvus_service.search_batch(vectors, top_k * 2, as_dicts=True)
         except Exception as exc:
@@ -112,6 +112,18 @@ class MultiDiagnosisService:
                 "extraction_metadata": {"enhanced_results_count": len(enhanced),
                                         "avg_extraction_confidence": sum(confs) / len(confs),
                                         "extraction_method": mode, "drug_filtering_enabled": mode == "enhanced"}}
+
+    def _embed_diagnoses(self, diagnoses: List[str]):
+        """the request's diagnoses embedded in one batch - minus those the enhanced text mode has embedded already: a diagnosis that is a
+        boundary's text was embedded when the boundaries were scored (services/semantic_boundary_service.py), and the canonical batch
+        arithmetic gives a string the same bits whatever shares its call"""
+        detector = getattr(getattr(self.text_processor, "_enhanced_processor", None), "boundary_detector", None)
+        known = [detector.cached_vector(d) if detector is not None else None for d in diagnoses]
+        missing = [d for d, v in zip(diagnoses, known) if v is None]
+        if len(missing) == len(diagnoses):
+            return self.embedding_service.encode_query_batch(diagnoses)
+        fresh = iter(self.embedding_service.encode_query_batch(missing)) if missing else iter(())
+        return np.stack([np.asarray(v) if v is not None else np.asarray(next(fresh)) for v in known])
 
     def _ner_pool(self):
         pool = getattr(self, "_ner_executor", None)

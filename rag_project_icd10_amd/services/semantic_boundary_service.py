@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import logging
 import re
+import threading
 from collections import OrderedDict
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
@@ -45,19 +46,31 @@ class SemanticBoundaryDetector:
         self.delimiter_priority = dict(_DELIMITERS)
         self.connection_patterns = [p.pattern for p in _CONNECTIONS]
         self._vectors: "OrderedDict[str, np.ndarray]" = OrderedDict()   # text -> embedding, most recent last
+        self._lock = threading.Lock()                                   # (requests of a server run in a pool of threads)
 
     # ---- embeddings: one batch per text, kept by string ---------------------------------------------------------------------------
     def _embed(self, texts: Sequence[str]) -> List[np.ndarray]:
-        missing = [t for t in dict.fromkeys(texts) if t not in self._vectors]
+        with self._lock:
+            have = {t: self._vectors[t] for t in texts if t in self._vectors}
+        missing = [t for t in dict.fromkeys(texts) if t not in have]
         if missing:
             svc = self.embedding_service
             batch = getattr(svc, "encode_query_batch", None)
             rows = batch(missing) if batch is not None else [svc.encode_query(t) for t in missing]
             for t, v in zip(missing, rows):
-                self._vectors[t] = np.asarray(v)
-            while len(self._vectors) > _CACHE_ENTRIES:
-                self._vectors.popitem(last=False)
-        return [self._vectors[t] for t in texts]
+                have[t] = np.asarray(v)
+            with self._lock:
+                for t in missing:
+                    self._vectors[t] = have[t]
+                while len(self._vectors) > _CACHE_ENTRIES:
+                    self._vectors.popitem(last=False)
+        return [have[t] for t in texts]
+
+    def cached_vector(self, text: str) -> Optional[np.ndarray]:
+        """the embedding of `text` if a boundary step of this detector has computed it (MultiDiagnosisService: a diagnosis that IS a
+        boundary's text is not embedded a second time - the vector is the one encode_query would return, bit for bit)"""
+        with self._lock:
+            return self._vectors.get(text)
 
     @staticmethod
     def _cosine(a: np.ndarray, b: np.ndarray) -> float:

@@ -166,3 +166,37 @@ def test_the_text_processor_is_enhanced_with_an_ner_service_and_simple_without()
     # a failing NER service costs the text its entities, not the request: delimiter boundaries at confidence 0.5 (:392-420)
     out = DiagnosisTextProcessor(Batched(), ner_service=Broken()).extract_diagnoses_enhanced("高血压病；糖尿病")
     assert [d["text"] for d in out] == ["高血压病", "糖尿病"] and all(d["metadata"].get("is_fallback") for d in out)
+
+
+def test_a_request_embeds_its_text_once_when_the_diagnoses_are_the_boundaries():
+    """/query in the enhanced mode (MultiDiagnosisService with an NER service): the text's segments are embedded in ONE batch for the
+    boundary confidences; a diagnosis that IS a boundary's text is searched with that vector (the canonical batch arithmetic gives
+    a string the same bits in any call) - the reference embeds every segment three times and every diagnosis once more
+    (services/semantic_boundary_service.py:184-192,290-292; services/multi_diagnosis_service.py:152-153)."""
+    from rag_project_icd10_amd.services.multi_diagnosis_service import MultiDiagnosisService
+
+    class Emb(Batched):
+        def encode_query_batch(self, texts, batch_size=256, to_device=False):
+            return super().encode_query_batch(texts)
+
+    seen = []
+
+    class Milvus:
+        def search_batch(self, vectors, top_k, as_dicts=False):
+            seen.append(np.asarray(vectors))
+            hit = {"code": "I10", "title": "高血压病", "score": 0.7, "original_score": 0.7,
+                   "metadata": {"level": 3, "parent_code": "I10", "semantic_text": "高血压病"}}
+            return [[dict(hit)] for _ in range(len(vectors))]
+
+    emb = Emb()
+    md = MultiDiagnosisService(emb, Milvus(), ner_service=MedicalNERService(use_model=False))
+    out = md.match_multiple_diagnoses("2型糖尿病伴有多个并发症；慢性肾功能不全；高血压病", top_k=1)
+    assert out["processing_mode"] == "enhanced" and len(out["extracted_diagnoses"]) == 3
+    assert emb.calls == 0 and len(emb.batches) == 1 and sorted(emb.batches[0]) == sorted(out["extracted_diagnoses"])
+    assert np.array_equal(seen[0], np.stack([bag_of_characters(d) for d in out["extracted_diagnoses"]]))
+    # a text whose boundary is cut at its disease entities: the pieces are new strings, embedded in a second batch, the rest reused
+    emb.batches.clear()
+    seen.clear()
+    out = md.match_multiple_diagnoses("高血压病 糖尿病 冠状动脉粥样硬化性心脏病；慢性胃炎", top_k=1)
+    assert np.array_equal(seen[0], np.stack([bag_of_characters(d) for d in out["extracted_diagnoses"]]))
+    assert sum(len(b) for b in emb.batches) <= len(set(out["extracted_diagnoses"])) + 2
