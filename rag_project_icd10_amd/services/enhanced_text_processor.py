@@ -35,6 +35,7 @@ class EnhancedTextProcessor:
         self.ner_service = ner_service
         self.boundary_detector = SemanticBoundaryDetector(embedding_service)
         self.embedding_service = embedding_service
+        self.last_text_entities = None
         self.config = {"min_diagnosis_length": 2, "max_diagnosis_length": 50, "min_entity_confidence": 0.6,
                        "use_semantic_boundary": True, "fallback_to_simple_split": True}
 
@@ -44,18 +45,23 @@ class EnhancedTextProcessor:
             return []
         try:
             if self.config["use_semantic_boundary"] and self.embedding_service:
-                # the text's entities and its boundaries do not depend on each other: the token classifier runs in a worker thread (its
-                # own encoder handle and stream) while this thread embeds the segments - both forwards are latency-bound and overlap
-                job = self._pool().submit(self.ner_service.extract_medical_entities, text, filter_drugs=filter_drugs)
+                # the text's entities and its boundaries do not depend on each other: when there are segments to embed the token
+                # classifier runs in a worker thread (its own encoder handle and stream) while this thread embeds them - both forwards
+                # are latency-bound and overlap; a one-segment text embeds nothing, its NER runs here
+                overlap = len(self.boundary_detector._initial_segmentation(text)) > 1
+                job = self._pool().submit(self.ner_service.extract_medical_entities, text, filter_drugs=filter_drugs) if overlap else None
                 try:
                     boundaries = self.boundary_detector.detect_diagnosis_boundaries(text)
                     confidences = self.boundary_detector.get_boundary_confidence(boundaries)
                 finally:
-                    entities = job.result()
+                    entities = job.result() if job is not None else None
+                if job is None:
+                    entities = self.ner_service.extract_medical_entities(text, filter_drugs=filter_drugs)
             else:
                 entities = self.ner_service.extract_medical_entities(text, filter_drugs=filter_drugs)
                 boundaries = self._simple_boundary_detection(text)
                 confidences = [0.5] * len(boundaries)
+            self.last_text_entities = (text, bool(filter_drugs), entities)   # (MultiDiagnosisService: a diagnosis that IS the text is not classified twice)
             fused = self._fuse_entity_boundary_info(text, entities, boundaries, confidences)
             return self._filter_and_rank_diagnoses(fused)
         except Exception as exc:

@@ -149,6 +149,14 @@ class MultiDiagnosisService:
         except Exception:   # (no torch / no GPU: the caller's stream, which is then the CPU)
             stream_ctx = None
         import contextlib
+        # a diagnosis that IS the request's text (the usual one-diagnosis request) was classified when the text was cut: the same string,
+        # the same switches, the same entities - not a second forward
+        last = getattr(getattr(self.text_processor, "_enhanced_processor", None), "last_text_entities", None)
+        if last is not None and last[1] and last[2] is not None and any(d == last[0] for d in diagnoses):
+            import copy
+            rest = [d for d in diagnoses if d != last[0]]
+            rest_entities = iter(self._entities_of(rest)) if rest else iter(())
+            return [copy.deepcopy(last[2]) if d == last[0] else next(rest_entities) for d in diagnoses]
         with (stream_ctx if stream_ctx is not None else contextlib.nullcontext()):
             try:
                 entities = self.ner_service.extract_medical_entities_batch(diagnoses, filter_drugs=True)

@@ -200,3 +200,31 @@ def test_a_request_embeds_its_text_once_when_the_diagnoses_are_the_boundaries():
     out = md.match_multiple_diagnoses("高血压病 糖尿病 冠状动脉粥样硬化性心脏病；慢性胃炎", top_k=1)
     assert np.array_equal(seen[0], np.stack([bag_of_characters(d) for d in out["extracted_diagnoses"]]))
     assert sum(len(b) for b in emb.batches) <= len(set(out["extracted_diagnoses"])) + 2
+
+
+def test_a_one_diagnosis_request_classifies_its_text_once():
+    """The usual /query request is ONE diagnosis: the text and the diagnosis are the same string. The reference runs its token classifier
+    on it twice (the text, :57 of the enhanced processor; the diagnosis, services/multi_diagnosis_service.py:147-150) and embeds it once;
+    here the diagnosis takes the text's entities (same string, same switches) - one forward each."""
+    from rag_project_icd10_amd.services.multi_diagnosis_service import MultiDiagnosisService
+
+    class Milvus:
+        def search_batch(self, vectors, top_k, as_dicts=False):
+            hit = {"code": "I10", "title": "高血压病", "score": 0.7, "original_score": 0.7,
+                   "metadata": {"level": 3, "parent_code": "I10", "semantic_text": "高血压病"}}
+            return [[dict(hit)] for _ in range(len(vectors))]
+
+    class Emb(Batched):
+        def encode_query_batch(self, texts, batch_size=256, to_device=False):
+            return super().encode_query_batch(texts)
+
+    ner = MedicalNERService(use_model=False)
+    calls = []
+    inner = ner.extract_medical_entities_batch
+    ner.extract_medical_entities_batch = lambda texts, filter_drugs=True: calls.append(list(texts)) or inner(texts, filter_drugs)
+    md = MultiDiagnosisService(Emb(), Milvus(), ner_service=ner)
+    out = md.match_multiple_diagnoses("原发性高血压病", top_k=1)
+    assert out["extracted_diagnoses"] == ["原发性高血压病"] and calls == [["原发性高血压病"]]
+    want = MultiDiagnosisService(Emb(), Milvus())._match_from_hits("原发性高血压病", Milvus().search_batch([0], 2, True)[0], 1,
+                                                                MedicalNERService(use_model=False).extract_medical_entities("原发性高血压病"))
+    assert [(c.code, c.score, c.similarity_factors) for c in out["matches"][0].candidates] == [(c.code, c.score, c.similarity_factors) for c in want.candidates]
