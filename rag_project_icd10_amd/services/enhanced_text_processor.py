@@ -45,18 +45,21 @@ class EnhancedTextProcessor:
             return []
         try:
             if self.config["use_semantic_boundary"] and self.embedding_service:
-                # the text's entities and its boundaries do not depend on each other: when there are segments to embed the token
-                # classifier runs in a worker thread (its own encoder handle and stream) while this thread embeds them - both forwards
-                # are latency-bound and overlap; a one-segment text embeds nothing, its NER runs here
-                overlap = len(self.boundary_detector._initial_segmentation(text)) > 1
-                job = self._pool().submit(self.ner_service.extract_medical_entities, text, filter_drugs=filter_drugs) if overlap else None
+                # the text's entities and its boundaries do not depend on each other: the token classifier runs in a worker thread (its own
+                # encoder handle and stream) while this thread embeds the segments - both forwards are latency-bound and overlap
+                job = self._pool().submit(self.ner_service.extract_medical_entities, text, filter_drugs=filter_drugs)
                 try:
                     boundaries = self.boundary_detector.detect_diagnosis_boundaries(text)
                     confidences = self.boundary_detector.get_boundary_confidence(boundaries)
+                    if len(boundaries) == 1:
+                        # a one-segment text embeds nothing for its boundaries - and is, as a rule, its own diagnosis: embed it NOW, beside
+                        # the classifier (MultiDiagnosisService finds the vector ready; a text that is cut after all has cost one hidden forward)
+                        try:
+                            self.boundary_detector._embed([boundaries[0][2]])
+                        except Exception as exc:
+                            logger.debug("speculative embedding failed: %s", exc)
                 finally:
-                    entities = job.result() if job is not None else None
-                if job is None:
-                    entities = self.ner_service.extract_medical_entities(text, filter_drugs=filter_drugs)
+                    entities = job.result()
             else:
                 entities = self.ner_service.extract_medical_entities(text, filter_drugs=filter_drugs)
                 boundaries = self._simple_boundary_detection(text)
