@@ -80,6 +80,10 @@ def main():
 
     strings = [l.strip() for l in open(os.path.join(HERE, "diagnosis_strings.txt"), encoding="utf-8") if l.strip()]
     texts = TEXTS + strings[:30] + ["；".join(strings[40:44]), "，".join(strings[50:53]), " ".join(strings[60:65])]
+    import random
+    rng = random.Random(5)     # seeded combinations of golden strings under every delimiter (and one that is none: 、)
+    for _ in range(60):
+        texts.append(rng.choice(["；", ";", "，", ",", " ", "+", "。", "\n", "、"]).join(rng.sample(strings, rng.randint(2, 5))))
     emb = Embedding()
     det, det0 = SemanticBoundaryDetector(emb), SemanticBoundaryDetector(None)
     enh, enh0 = EnhancedTextProcessor(emb, use_model_ner=False), EnhancedTextProcessor(None, use_model_ner=False)
