@@ -1005,6 +1005,26 @@ def test_services_end_to_end_on_gpu(oracle, tmp_path, monkeypatch):
     for m in res["matches"]:
         single = ms.search(es.encode_query(m.diagnosis_text), 6)
         assert {c.code for c in m.candidates} <= {h["code"] for h in single}
+    # ... and with an NER service (its rules here): the reference's default, ENHANCED text mode - the text's segments embedded in one batch
+    # for the boundary confidences, a diagnosis that is a boundary's text searched with that vector. Every DiagnosisMatch is what
+    # the one-at-a-time calls give: encode_query -> search(2 top_k) -> rescoring with the diagnosis's own entities.
+    from rag_project_icd10_amd.services.medical_ner_service import MedicalNERService
+    ner = MedicalNERService(use_model=False)
+    md = MultiDiagnosisService(es, ms, ner_service=ner)
+    text = "霍乱，伤寒；副伤寒；细菌性食物中毒"
+    res_e = md.match_multiple_diagnoses(text, top_k=3)
+    assert res_e["processing_mode"] == "enhanced" and len(res_e["extracted_diagnoses"]) >= 2
+    detector = md.text_processor._enhanced_processor.boundary_detector
+    reused = 0
+    for d, m in zip(res_e["extracted_diagnoses"], res_e["matches"]):
+        vec = es.encode_query(d)
+        cached = detector.cached_vector(d)
+        if cached is not None:
+            reused += 1
+            assert np.array_equal(np.asarray(cached), vec), d          # the batch gave the string the one-string call's bits
+        want = md._match_from_hits(d, ms.search(vec, 6), 3, ner.extract_medical_entities(d))
+        assert m.model_dump() == want.model_dump(), d
+    assert reused >= 2
     assert ms.release_collection()["success"] and ms.get_collection_load_state()["loaded"] is False
     assert ms.load_collection() is True and ms.disconnect()["success"]
 
